@@ -1,0 +1,453 @@
+"""CPU oracle for the exact-GP inner loop -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+This module restates, with numpy/scipy only, the algorithm GPmp's NumPy backend
+runs on the hot path (Gram build -> Cholesky -> triangular solves -> NLL / REML /
+LOO / predict).  Each function follows the reference's own operation sequence
+(same LAPACK / cdist calls in the same order) and cites the reference file:line it
+restates (paths relative to the gpmp-dev/gpmp checkout, v0.9.37).
+
+Who may import this file: ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` -- only as the *checker* / reported CPU
+baseline.  Nothing under ``gpmp_amd/`` imports it; the product path is the HIP
+library and fails loudly when that library is missing.
+
+Parity pinning: the reference's own test-suite holds no golden vectors for this
+path, so the oracle is pinned against outputs of the
+reference itself, captured in this container by ``tests/golden/make_fixtures.py``
+(imports the reference's NumPy backend; torch-CPU backend for autograd gradients)
+and committed as ``tests/golden/*.npz``.  ``tests/test_oracle_vs_golden.py`` checks
+every function below against those vectors.
+
+The analytic gradient functions at the bottom have no NumPy-backend counterpart in
+the reference (``gradient = None``, gpmp/num/numpy_backend.py:333); they are pinned
+against the reference's torch-autograd gradients (gpmp/num/torch_backend.py:585-604).
+"""
+from __future__ import annotations
+
+import math
+import warnings
+
+import numpy as np
+from scipy.linalg import solve as _sp_solve
+from scipy.linalg import solve_triangular as _sp_solve_triangular
+from scipy.spatial.distance import cdist as _sp_cdist
+from scipy.special import gammaln as _sp_gammaln
+
+EPS = np.finfo(np.float64).eps
+FMAX = np.finfo(np.float64).max
+
+
+# --------------------------------------------------------------------------
+# gpmp.num (NumPy backend) pieces on the path
+# --------------------------------------------------------------------------
+def scaled_distance(loginvrho, x, y):
+    """gpmp/num/numpy_backend.py:432-436 -- cdist on points pre-scaled by exp(loginvrho)."""
+    invrho = np.exp(loginvrho)
+    return _sp_cdist(invrho * x, invrho * y)
+
+
+def scaled_distance_elementwise(loginvrho, x, y):
+    """gpmp/num/numpy_backend.py:438-446."""
+    if x is y or y is None:
+        return np.zeros((x.shape[0],))
+    invrho = np.exp(loginvrho)
+    return np.sqrt(np.sum((invrho * (x - y)) ** 2, axis=1))
+
+
+def cholesky_solve(A, b):
+    """gpmp/num/numpy_backend.py:465-469 -- returns (x, L) with A = L L^T (lower)."""
+    L = np.linalg.cholesky(A)
+    y = _sp_solve_triangular(L, b, lower=True)
+    x = _sp_solve_triangular(L.T, y, lower=False)
+    return x, L
+
+
+def inftobigf(a, bigf=FMAX / 1000.0):
+    """gpmp/num/numpy_backend.py:250-252."""
+    return np.where(np.isinf(a), np.full_like(a, bigf), a)
+
+
+def compute_gammaln(up_to_p):
+    """gpmp/num/shared.py:21-41 -- gammaln(k), k = 0 .. 2p+1 (gammaln(0) = +inf, unused)."""
+    with np.errstate(divide="ignore"):
+        return _sp_gammaln(np.arange(2 * up_to_p + 2))
+
+
+# --------------------------------------------------------------------------
+# gpmp.kernel.matern
+# --------------------------------------------------------------------------
+def maternp_coefficients(p):
+    """Polynomial weights a_i, i < p, of gpmp/kernel/matern.py:59-63."""
+    gln = compute_gammaln(p)
+    return np.array(
+        [
+            math.exp(gln[p + 1] - gln[2 * p + 1] + gln[p + i + 1] - gln[i + 1] - gln[p - i + 1])
+            for i in range(p)
+        ]
+    )
+
+
+def maternp_kernel(p, h):
+    """gpmp/kernel/matern.py:32-64 -- half-integer Matern correlation, nu = p + 1/2."""
+    gln = compute_gammaln(p)
+    h = inftobigf(np.asarray(h, dtype=np.float64))
+    c = 2.0 * math.sqrt(p + 0.5)
+    twoch = 2.0 * c * h
+    polynomial = np.ones(h.shape)
+    for i in range(p):
+        a = np.exp(gln[p + 1] - gln[2 * p + 1] + gln[p + i + 1] - gln[i + 1] - gln[p - i + 1])
+        polynomial += a * (twoch ** (p - i))
+    return np.exp(-c * h) * polynomial
+
+
+def maternp_covariance_ii_or_tt(x, p, param, pairwise=False):
+    """gpmp/kernel/matern.py:67-94 (nugget 10 sigma^2 eps on the diagonal)."""
+    sigma2 = np.exp(param[0])
+    loginvrho = param[1:]
+    nugget = 10.0 * sigma2 * EPS
+    if pairwise:
+        return sigma2 * np.ones((x.shape[0],))
+    K = scaled_distance(loginvrho, x, x)
+    return sigma2 * maternp_kernel(p, K) + nugget * np.eye(K.shape[0])
+
+
+def maternp_covariance_it(x, y, p, param, pairwise=False):
+    """gpmp/kernel/matern.py:97-121."""
+    sigma2 = np.exp(param[0])
+    loginvrho = param[1:]
+    if pairwise:
+        D = scaled_distance_elementwise(loginvrho, x, y)
+    else:
+        D = scaled_distance(loginvrho, x, y)
+    return sigma2 * maternp_kernel(p, D)
+
+
+def maternp_covariance(x, y, p, param, pairwise=False):
+    """gpmp/kernel/matern.py:124-141 (dispatch on identity, not equality)."""
+    if y is x or y is None:
+        return maternp_covariance_ii_or_tt(x, p, param, pairwise)
+    return maternp_covariance_it(x, y, p, param, pairwise)
+
+
+def noisy_maternp_covariance(x, y, p, param, pairwise=False):
+    """Matern + homoscedastic noise, param = [log s2, log s2_noise, log 1/rho...].
+
+    Restates examples/gpmp_example07_nd_regression.py:95-131 (p = 2 there)."""
+    sigma2 = np.exp(param[0])
+    noise_variance = np.exp(param[1])
+    loginvrho = param[2:]
+    if y is x or y is None:
+        if pairwise:
+            return sigma2 * np.ones((x.shape[0],))
+        D = scaled_distance(loginvrho, x, x)
+        return sigma2 * maternp_kernel(p, D) + noise_variance * np.eye(D.shape[0])
+    if pairwise:
+        D = scaled_distance_elementwise(loginvrho, x, y)
+    else:
+        D = scaled_distance(loginvrho, x, y)
+    return sigma2 * maternp_kernel(p, D)
+
+
+# --------------------------------------------------------------------------
+# gpmp.core -- a minimal model record + the numerical routines
+# --------------------------------------------------------------------------
+class OracleModel:
+    """Holds (mean, covariance, meanparam, covparam, meantype) -- gpmp/core/model.py:136-166."""
+
+    def __init__(self, mean, covariance, meanparam=None, covparam=None, meantype="linear_predictor"):
+        if meantype not in {"zero", "parameterized", "linear_predictor"}:
+            raise ValueError("meantype must be one of 'zero', 'parameterized', or 'linear_predictor'")
+        if meantype == "zero" and mean is not None:
+            raise ValueError("For meantype 'zero', mean must be None")
+        if meantype != "zero" and not callable(mean):
+            raise TypeError("mean must be a callable function")
+        self.mean, self.covariance = mean, covariance
+        self.meanparam, self.covparam, self.meantype = meanparam, covparam, meantype
+
+
+def _posterior_variance(model, xt, lambdamu_t, RHS, return_type=0):
+    """gpmp/core/kriging.py:170-199."""
+    if return_type == -1:
+        return None
+    if return_type == 0:
+        prior = model.covariance(xt, None, model.covparam, pairwise=True)
+        return prior - np.einsum("i..., i...", lambdamu_t, RHS)
+    if return_type == 1:
+        prior = model.covariance(xt, None, model.covparam, pairwise=False)
+        return prior - np.matmul(lambdamu_t.T, RHS)
+    raise ValueError("return_type must be in {-1, 0, 1}")
+
+
+def kriging_predictor_with_zero_mean(model, xi, xt, return_type=0):
+    """gpmp/core/kriging.py:35-67."""
+    Kii = model.covariance(xi, xi, model.covparam)
+    Kit = model.covariance(xi, xt, model.covparam)
+    lambda_t, _ = cholesky_solve(Kii, Kit)
+    return lambda_t, _posterior_variance(model, xt, lambda_t, Kit, return_type)
+
+
+def kriging_predictor(model, xi, xt, return_type=0):
+    """gpmp/core/kriging.py:70-116 (block system [[K,P],[P^T,0]], LAPACK sysv)."""
+    Kii = model.covariance(xi, xi, model.covparam)
+    Pi = model.mean(xi, model.meanparam)
+    ni, q = Pi.shape
+    LHS = np.vstack((np.hstack((Kii, Pi)), np.hstack((Pi.T, np.zeros((q, q))))))
+    Kit = model.covariance(xi, xt, model.covparam)
+    Pt = model.mean(xt, model.meanparam)
+    RHS = np.vstack((Kit, Pt.T))
+    lambdamu_t = _sp_solve(LHS, RHS, overwrite_a=True, overwrite_b=False, assume_a="sym")
+    lambda_t = lambdamu_t[0:ni, :]
+    return lambda_t, _posterior_variance(model, xt, lambdamu_t, RHS, return_type)
+
+
+def predict(model, xi, zi, xt, return_lambdas=False, zero_neg_variances=True):
+    """gpmp/core/model.py:227-307 + gpmp/core/kriging.py:119-164."""
+    xi = np.asarray(xi, dtype=np.float64)
+    xt = np.asarray(xt, dtype=np.float64)
+    zi = np.asarray(zi, dtype=np.float64).reshape(-1)
+    zt_prior_mean = 0.0
+    zi_centered = zi
+    if model.meantype == "zero":
+        lambda_t, var = kriging_predictor_with_zero_mean(model, xi, xt)
+    elif model.meantype == "linear_predictor":
+        lambda_t, var = kriging_predictor(model, xi, xt)
+    elif model.meantype == "parameterized":
+        if model.meanparam is None:
+            raise ValueError("For meantype 'parameterized', meanparam should not be None.")
+        lambda_t, var = kriging_predictor_with_zero_mean(model, xi, xt)
+        zi_centered = zi - model.mean(xi, model.meanparam).reshape(-1)
+        zt_prior_mean = model.mean(xt, model.meanparam).reshape(-1)
+    else:
+        raise ValueError(f"Invalid meantype {model.meantype}.")
+    if np.any(var < 0.0):
+        warnings.warn("Negative variances detected. Consider using jitter.", RuntimeWarning)
+    if zero_neg_variances:
+        var = np.maximum(var, 0.0)
+    zpm = np.einsum("i..., i...", lambda_t, zi_centered) + zt_prior_mean
+    if return_lambdas:
+        return zpm, var, lambda_t
+    return zpm, var
+
+
+def negative_log_likelihood_zero_mean(model, covparam, xi, zi):
+    """gpmp/core/likelihood.py:18-52 (LinAlgError propagates; RuntimeError -> +inf)."""
+    K = model.covariance(xi, xi, covparam)
+    n = K.shape[0]
+    try:
+        Kinv_zi, C = cholesky_solve(K, zi)
+    except RuntimeError:
+        return np.inf
+    norm2 = np.einsum("i..., i...", zi, Kinv_zi)
+    ldetK = 2.0 * np.sum(np.log(np.diag(C)))
+    L = 0.5 * (n * np.log(2.0 * np.pi) + ldetK + norm2)
+    return L.reshape(())
+
+
+def negative_log_likelihood(model, meanparam, covparam, xi, zi):
+    """gpmp/core/likelihood.py:55-89."""
+    centered = zi - model.mean(xi, meanparam).reshape(-1)
+    return negative_log_likelihood_zero_mean(model, covparam, xi, centered)
+
+
+def compute_contrast_matrix(P):
+    """gpmp/core/linalg.py:49-70 -- last n-q columns of a complete QR."""
+    n, q = P.shape
+    Q, _ = np.linalg.qr(P, mode="complete")
+    return Q[:, q:n]
+
+
+def negative_log_restricted_likelihood(model, covparam, xi, zi):
+    """gpmp/core/likelihood.py:92-129."""
+    K = model.covariance(xi, xi, covparam)
+    P = model.mean(xi, model.meanparam)
+    W = compute_contrast_matrix(P)
+    Wzi = np.matmul(W.T, zi)
+    G = np.matmul(W.T, np.matmul(K, W))
+    try:
+        WKWinv_Wzi, C = cholesky_solve(G, Wzi)
+    except RuntimeError:
+        return np.inf
+    norm2 = np.einsum("i..., i...", Wzi, WKWinv_Wzi)
+    ldet = 2.0 * np.sum(np.log(np.diag(C)))
+    n, q = P.shape
+    L = 0.5 * ((n - q) * np.log(2.0 * np.pi) + ldet + norm2)
+    return L.reshape(())
+
+
+def diag_Kinv_from_chol(C):
+    """gpmp/core/linalg.py:17-46 (lower)."""
+    n = C.shape[0]
+    T = _sp_solve_triangular(C, np.eye(n), lower=True)
+    return np.sum(T * T, axis=0)
+
+
+def loo(model, xi, zi):
+    """gpmp/core/loo.py:21-130 -> (zloo, sigma2loo, eloo)."""
+    xi = np.asarray(xi, dtype=np.float64)
+    zi = np.asarray(zi, dtype=np.float64).reshape(-1)
+    if model.meantype == "zero":
+        return _loo_zero(model, model.covparam, xi, zi)
+    if model.meantype == "parameterized":
+        m = model.mean(xi, model.meanparam).reshape(-1)
+        zl, s2, el = _loo_zero(model, model.covparam, xi, zi - m)
+        return zl + m, s2, el
+    if model.meantype == "linear_predictor":
+        K = model.covariance(xi, xi, model.covparam)
+        P = model.mean(xi, model.meanparam)
+        Q, _ = np.linalg.qr(P, mode="complete")
+        W = Q[:, P.shape[1]:]
+        G = np.matmul(W.T, np.matmul(K, W))
+        S, _ = cholesky_solve(G, W.T)
+        Qinvzi = np.matmul(W, np.matmul(S, zi))
+        Qinvdiag = np.sum(W * S.T, axis=1)
+        eloo = Qinvzi / Qinvdiag
+        return zi - eloo, 1.0 / Qinvdiag, eloo
+    raise ValueError(f"Unknown mean type: {model.meantype}")
+
+
+def _loo_zero(model, covparam, xi, zi):
+    """gpmp/core/loo.py:65-83."""
+    K = model.covariance(xi, xi, covparam)
+    Kinv_zi, C = cholesky_solve(K, zi)
+    d = diag_Kinv_from_chol(C)
+    eloo = Kinv_zi.reshape(-1) / d
+    return zi - eloo, 1.0 / d, eloo
+
+
+def norm_k_sqrd_with_zero_mean(model, xi, zi, covparam):
+    """gpmp/core/linalg.py:113-118."""
+    K = model.covariance(xi, xi, covparam)
+    Kinv_zi, _ = cholesky_solve(K, zi)
+    return np.einsum("i..., i...", zi, Kinv_zi)
+
+
+def k_inverses(model, xi, zi, covparam):
+    """gpmp/core/linalg.py:121-129 (cholesky_inv = numpy.linalg.inv, numpy_backend.py:458-463)."""
+    K = model.covariance(xi, xi, covparam)
+    ones_vector = np.ones(zi.shape)
+    Kinv = np.linalg.inv(K)
+    Kinv_zi = np.einsum("...i, i...", Kinv, zi)
+    Kinv_1 = np.einsum("...i, i...", Kinv, ones_vector)
+    zTKinvz = np.einsum("i..., i...", zi, Kinv_zi)
+    return zTKinvz, Kinv_1, Kinv_zi
+
+
+def norm_k_sqrd(model, xi, zi, covparam):
+    """gpmp/core/linalg.py:132-141."""
+    K = model.covariance(xi, xi, covparam)
+    P = model.mean(xi, model.meanparam)
+    W = compute_contrast_matrix(P)
+    Wzi = np.matmul(W.T, zi)
+    G = np.matmul(W.T, np.matmul(K, W))
+    x, _ = cholesky_solve(G, Wzi)
+    return np.einsum("i..., i...", Wzi, x)
+
+
+def anisotropic_parameters_initial_guess(model, xi, zi):
+    """gpmp/kernel/init.py:54-66 (arrays path)."""
+    xi = np.asarray(xi, dtype=np.float64)
+    zi = np.asarray(zi, dtype=np.float64).reshape(-1, 1)
+    n, d = xi.shape
+    delta = np.max(xi, axis=0) - np.min(xi, axis=0)
+    rho = np.exp(_sp_gammaln(d / 2 + 1) / d) / (np.pi ** 0.5) * delta
+    covparam = np.concatenate((np.array([math.log(1.0)]), -np.log(rho)))
+    sigma2_GLS = (1.0 / n) * norm_k_sqrd(model, xi, zi, covparam)
+    return np.concatenate((np.asarray(np.log(sigma2_GLS)).reshape(1), -np.log(rho)))
+
+
+# --------------------------------------------------------------------------
+# Analytic gradients (pinned against the reference's torch autograd fixtures)
+# --------------------------------------------------------------------------
+def maternp_dkernel_over_h(p, h):
+    """(dK/dh)/h for the Matern-p correlation, regular at h = 0 for p >= 1.
+
+    With t = 2 c h (c = 2 sqrt(p + 1/2)), K = e^{-t/2} q(t), q(t) = 1 + sum_i a_i t^{p-i}:
+    dK/dh = 2c e^{-t/2} (q'(t) - q(t)/2).  The constant and linear terms of
+    (q' - q/2) vanish for p >= 1 (a_{p-1} = 1/2), so dK/dh = O(h) and the ratio is finite.
+    """
+    h = np.asarray(h, dtype=np.float64)
+    a = maternp_coefficients(p)  # a_i multiplies t^{p-i}
+    c = 2.0 * math.sqrt(p + 0.5)
+    t = 2.0 * c * h
+    # coefficients of q(t) by power: q_k, k = 0..p
+    q = np.zeros(p + 1)
+    q[0] = 1.0
+    for i in range(p):
+        q[p - i] = a[i]
+    # r(t) = q'(t) - q(t)/2 ; r_k = (k+1) q_{k+1} - q_k / 2
+    r = np.zeros(p + 1)
+    for k in range(p + 1):
+        r[k] = ((k + 1) * q[k + 1] if k + 1 <= p else 0.0) - 0.5 * q[k]
+    if p == 0:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return 2.0 * c * np.exp(-t / 2) * r[0] / h
+    # r_0 = q_1 - 1/2 = 0 for p >= 1; divide r(t) by t analytically: r(t)/t = sum_{k>=1} r_k t^{k-1}
+    s = np.zeros_like(t)
+    for k in range(p, 0, -1):
+        s = s * t + r[k]
+    # dK/dh / h = 2c e^{-t/2} r(t) / h = 2c e^{-t/2} (r(t)/t) * 2c
+    return (2.0 * c) ** 2 * np.exp(-t / 2) * s
+
+
+def covariance_gradient_traces(M, x, p, theta, noise_index=None):
+    """sum_ik M_ik dK_ik/dtheta_j for the Matern-p covariance (optionally + noise).
+
+    theta = [log s2, (log s2_noise,) log 1/rho_1..d].  dK/dlog s2 = K (the default nugget
+    10 s2 eps scales with s2, matern.py:90; with an explicit noise term there is no nugget).
+    dK_ik/dlog(1/rho_j) = s2 * (K'(h)/h) * (Delta_j / rho_j)^2.
+    """
+    x = np.asarray(x, dtype=np.float64)
+    n, d = x.shape
+    off = 1 if noise_index is None else 2
+    sigma2 = math.exp(theta[0])
+    invrho = np.exp(np.asarray(theta[off:], dtype=np.float64))
+    xs = x * invrho
+    H = _sp_cdist(xs, xs)
+    g = np.zeros(len(theta))
+    Kc = sigma2 * maternp_kernel(p, H)
+    if noise_index is None:
+        g[0] = np.sum(M * Kc) + 10.0 * sigma2 * EPS * np.trace(M)
+    else:
+        g[0] = np.sum(M * Kc)
+        g[noise_index] = math.exp(theta[noise_index]) * np.trace(M)
+    R = sigma2 * maternp_dkernel_over_h(p, H) * M
+    for j in range(d):
+        D2 = (xs[:, j][:, None] - xs[:, j][None, :]) ** 2
+        g[off + j] = np.sum(R * D2)
+    return g
+
+
+def nll_zero_mean_value_and_grad(x, z, p, theta, noise_index=None):
+    """Analytic d/dtheta of likelihood.py:18-52: g_j = 1/2 tr((K^-1 - a a^T) dK_j), a = K^-1 z."""
+    cov = (lambda a, b, t, pw=False: maternp_covariance(a, b, p, t, pw)) if noise_index is None else (
+        lambda a, b, t, pw=False: noisy_maternp_covariance(a, b, p, t, pw))
+    K = cov(x, x, theta)
+    n = K.shape[0]
+    L = np.linalg.cholesky(K)
+    Kinv = np.linalg.inv(K)
+    a = Kinv @ z
+    val = 0.5 * (n * math.log(2 * math.pi) + 2 * np.sum(np.log(np.diag(L))) + z @ a)
+    M = Kinv - np.outer(a, a)
+    return val, 0.5 * covariance_gradient_traces(M, x, p, theta, noise_index)
+
+
+def reml_value_and_grad(x, z, P, p, theta, noise_index=None):
+    """Analytic d/dtheta of likelihood.py:92-129 via Q^-1 = K^-1 - K^-1 P (P^T K^-1 P)^-1 P^T K^-1.
+
+    (W orthonormal basis of Null(P^T):  W (W^T K W)^-1 W^T = Q^-1,
+     ln|W^T K W| = ln|K| + ln|P^T K^-1 P| - ln|P^T P|.)
+    """
+    cov = (lambda a, b, t, pw=False: maternp_covariance(a, b, p, t, pw)) if noise_index is None else (
+        lambda a, b, t, pw=False: noisy_maternp_covariance(a, b, p, t, pw))
+    K = cov(x, x, theta)
+    n, q = P.shape
+    L = np.linalg.cholesky(K)
+    Kinv = np.linalg.inv(K)
+    KiP = Kinv @ P
+    S = P.T @ KiP
+    Qinv = Kinv - KiP @ np.linalg.solve(S, KiP.T)
+    b = Qinv @ z
+    ldet = 2 * np.sum(np.log(np.diag(L))) + np.linalg.slogdet(S)[1] - np.linalg.slogdet(P.T @ P)[1]
+    val = 0.5 * ((n - q) * math.log(2 * math.pi) + ldet + z @ b)
+    M = Qinv - np.outer(b, b)
+    return val, 0.5 * covariance_gradient_traces(M, x, p, theta, noise_index)

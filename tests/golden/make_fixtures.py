@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE (gpmp v0.9.37).
+
+Run in the build container only (the reference does not travel to the GPU box):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg PYTHONPATH=/root/reference \
+        GPMP_BACKEND=numpy python3 /root/repo/tests/golden/make_fixtures.py numpy
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg PYTHONPATH=/root/reference \
+        GPMP_BACKEND=torch python3 /root/repo/tests/golden/make_fixtures.py torch
+
+The "numpy" pass pins values (Matern, covariance, predict, NLL, REML, LOO, init guess,
+example02 flow) with the reference's NumPy backend -- the parity target named by
+BASELINE.json.  The "torch" pass pins the ML / REML gradients with the reference's
+torch-CPU autograd route (the NumPy backend has no gradient: numpy_backend.py:333).
+
+Only inputs and outputs (plain arrays) are stored; no reference source is copied.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+backend = sys.argv[1] if len(sys.argv) > 1 else "numpy"
+os.environ["GPMP_BACKEND"] = backend
+os.environ.setdefault("GPMP_LOG_LEVEL", "WARNING")
+
+import gpmp as gp  # noqa: E402  (the reference)
+import gpmp.num as gnp  # noqa: E402
+
+assert gnp._gpmp_backend_ == backend, (gnp._gpmp_backend_, backend)
+
+
+# ---------------------------------------------------------------- helpers
+def make_xz(n, d, seed, noise=0.0):
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, d))
+    z = np.sin(2 * np.pi * x[:, 0]) + x[:, 1:].sum(axis=1)
+    if noise:
+        z = z + noise * rng.standard_normal(n)
+    return x, z
+
+
+def theta_aniso(d, sigma2=1.0, scale=1.0):
+    rho = scale * 0.5 * (1.0 + np.arange(d) / d)
+    return np.concatenate(([np.log(sigma2)], -np.log(rho)))
+
+
+def constant_mean(x, param):
+    return gnp.ones((x.shape[0], 1))
+
+
+def linear_mean(x, param):
+    return gnp.hstack((gnp.ones((x.shape[0], 1)), gnp.asarray(x)))
+
+
+def param_mean(x, param):
+    return (param[0] + param[1] * x[:, 0]).reshape(-1, 1)
+
+
+def make_kernel(p):
+    def kernel(x, y, covparam, pairwise=False):
+        return gp.kernel.maternp_covariance(x, y, p, covparam, pairwise)
+
+    return kernel
+
+
+def make_noisy_kernel(p):
+    # same construction as examples/gpmp_example07_nd_regression.py:95-131
+    def kernel(x, y, param, pairwise=False):
+        sigma2 = gnp.exp(param[0])
+        noise_variance = gnp.exp(param[1])
+        loginvrho = param[2:]
+        if y is x or y is None:
+            if pairwise:
+                return sigma2 * gnp.ones((x.shape[0],))
+            K = gnp.scaled_distance(loginvrho, x, x)
+            return sigma2 * gp.kernel.maternp_kernel(p, K) + noise_variance * gnp.eye(K.shape[0])
+        if pairwise:
+            K = gnp.scaled_distance_elementwise(loginvrho, x, y)
+        else:
+            K = gnp.scaled_distance(loginvrho, x, y)
+        return sigma2 * gp.kernel.maternp_kernel(p, K)
+
+    return kernel
+
+
+def tonp(a):
+    return np.asarray(gnp.to_np(a) if backend == "numpy" else a.detach().cpu().numpy(), dtype=np.float64)
+
+
+# ---------------------------------------------------------------- numpy pass
+def gen_matern(out):
+    h = np.array([0.0, 1e-300, 1e-12, 1e-6, 0.01, 0.1, 0.5, 1.0, 2.0, 5.0, 10.0, 40.0, 100.0, 400.0, np.inf])
+    out["matern_h"] = h
+    for p in (0, 1, 2, 3, 6, 10):
+        with np.errstate(over="ignore", invalid="ignore"):
+            out[f"matern_k_p{p}"] = gp.kernel.maternp_kernel(p, h.copy())
+    for tag, (n, m, d), p in (("a", (37, 53, 3), 2), ("b", (160, 64, 8), 2), ("c", (33, 17, 2), 3), ("d", (40, 40, 5), 0)):
+        x, _ = make_xz(n, d, 11)
+        y, _ = make_xz(m, d, 12)
+        th = theta_aniso(d, sigma2=1.7)
+        out[f"cov_{tag}_x"], out[f"cov_{tag}_y"], out[f"cov_{tag}_theta"], out[f"cov_{tag}_p"] = x, y, th, np.array(p)
+        out[f"cov_{tag}_ii"] = gp.kernel.maternp_covariance(x, x, p, th)            # identity dispatch y is x
+        out[f"cov_{tag}_ii_none_equal"] = np.array(np.array_equal(out[f"cov_{tag}_ii"], gp.kernel.maternp_covariance(x, None, p, th)))
+        out[f"cov_{tag}_it"] = gp.kernel.maternp_covariance(x, y, p, th)
+        out[f"cov_{tag}_ii_pw"] = gp.kernel.maternp_covariance(x, None, p, th, True)
+        ym = y[: min(n, m)]
+        xm = x[: min(n, m)]
+        out[f"cov_{tag}_it_pw"] = gp.kernel.maternp_covariance(xm, ym, p, th, True)
+        # equal-but-not-identical copy goes down the "it" path (no nugget)
+        out[f"cov_{tag}_copy"] = gp.kernel.maternp_covariance(x, x.copy(), p, th)
+        out[f"dist_{tag}"] = gnp.scaled_distance(th[1:], x, y)
+
+
+def gen_predict(out):
+    cases = []
+    for tag, (n, m, d), p in (("s", (64, 10, 3), 2), ("m", (200, 120, 8), 2), ("p3", (50, 20, 2), 3)):
+        xi, zi = make_xz(n, d, 21)
+        xt, _ = make_xz(m, d, 22)
+        th = theta_aniso(d, sigma2=0.8)
+        out[f"pred_{tag}_xi"], out[f"pred_{tag}_zi"], out[f"pred_{tag}_xt"] = xi, zi, xt
+        out[f"pred_{tag}_theta"], out[f"pred_{tag}_p"] = th, np.array(p)
+        k = make_kernel(p)
+        mp = np.array([0.3, -0.7])
+        out[f"pred_{tag}_meanparam"] = mp
+        models = {
+            "zero": gp.core.Model(None, k, None, th, "zero"),
+            "const": gp.core.Model(constant_mean, k, None, th, "linear_predictor"),
+            "lin": gp.core.Model(linear_mean, k, None, th, "linear_predictor"),
+            "param": gp.core.Model(param_mean, k, mp, th, "parameterized"),
+        }
+        for mt, model in models.items():
+            zpm, zpv, lam = model.predict(xi, zi, xt, return_lambdas=True)
+            out[f"pred_{tag}_{mt}_zpm"], out[f"pred_{tag}_{mt}_zpv"], out[f"pred_{tag}_{mt}_lambda"] = zpm, zpv, lam
+            zl, s2, el = model.loo(xi, zi)
+            out[f"loo_{tag}_{mt}_zloo"], out[f"loo_{tag}_{mt}_s2"], out[f"loo_{tag}_{mt}_eloo"] = zl, s2, el
+        lam, cov = models["zero"].kriging_predictor_with_zero_mean(xi, xt, return_type=1)
+        out[f"pred_{tag}_zero_fullcov"] = cov
+        # zi given as a column
+        zpm, zpv = models["zero"].predict(xi, zi.reshape(-1, 1), xt)
+        out[f"pred_{tag}_zero_zpm_col"] = zpm
+        cases.append(tag)
+    # near-singular: duplicated observation points -> clamp + warning path (model.py:290-296)
+    xi, zi = make_xz(40, 2, 23)
+    xi = np.vstack((xi, xi[:5] + 1e-9))
+    zi = np.concatenate((zi, zi[:5]))
+    xt = np.vstack((xi[:7], make_xz(20, 2, 24)[0]))  # predicting AT observation points: var ~ 0 (+-)
+    th = theta_aniso(2, sigma2=1.0, scale=4.0)
+    model = gp.core.Model(None, make_kernel(2), None, th, "zero")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        zpm, zpv = model.predict(xi, zi, xt)
+        zpm2, zpv_raw = model.predict(xi, zi, xt, zero_neg_variances=False)
+    out["pred_dup_xi"], out["pred_dup_zi"], out["pred_dup_xt"], out["pred_dup_theta"] = xi, zi, xt, th
+    out["pred_dup_zpm"], out["pred_dup_zpv"], out["pred_dup_zpv_raw"] = zpm, zpv, zpv_raw
+    out["pred_dup_warned"] = np.array(any(issubclass(x.category, RuntimeWarning) for x in w))
+    out["pred_cases"] = np.array(cases)
+
+
+def gen_likelihood(out):
+    rng = np.random.default_rng(31)
+    for tag, (n, d), p in (("a", (64, 3), 2), ("b", (256, 8), 2), ("c", (512, 20), 2), ("d", (100, 4), 1)):
+        xi, zi = make_xz(n, d, 32)
+        out[f"lik_{tag}_xi"], out[f"lik_{tag}_zi"], out[f"lik_{tag}_p"] = xi, zi, np.array(p)
+        k = make_kernel(p)
+        mz = gp.core.Model(None, k, None, None, "zero")
+        mc = gp.core.Model(constant_mean, k, None, None, "linear_predictor")
+        ml = gp.core.Model(linear_mean, k, None, None, "linear_predictor")
+        mpm = gp.core.Model(param_mean, k, np.array([0.2, 0.5]), None, "parameterized")
+        thetas = np.stack([theta_aniso(d) + 0.3 * rng.standard_normal(d + 1) for _ in range(5)])
+        out[f"lik_{tag}_thetas"] = thetas
+        out[f"lik_{tag}_nll"] = np.array([mz.negative_log_likelihood_zero_mean(t, xi, zi) for t in thetas])
+        out[f"lik_{tag}_nll_param"] = np.array([mpm.negative_log_likelihood(np.array([0.2, 0.5]), t, xi, zi) for t in thetas])
+        out[f"lik_{tag}_reml_const"] = np.array([mc.negative_log_restricted_likelihood(t, xi, zi) for t in thetas])
+        out[f"lik_{tag}_reml_lin"] = np.array([ml.negative_log_restricted_likelihood(t, xi, zi) for t in thetas])
+        out[f"lik_{tag}_normk0"] = np.array([mz.norm_k_sqrd_with_zero_mean(xi, zi, t) for t in thetas])
+        out[f"lik_{tag}_normk_const"] = np.array([mc.norm_k_sqrd(xi, zi, t) for t in thetas])
+        a, b, c = mz.k_inverses(xi, zi, thetas[0])
+        out[f"lik_{tag}_kinv_ztKz"], out[f"lik_{tag}_kinv_1"], out[f"lik_{tag}_kinv_z"] = np.array(a), b, c
+        out[f"lik_{tag}_init_const"] = gp.kernel.anisotropic_parameters_initial_guess(mc, xi, zi)
+        out[f"lik_{tag}_init_zero"] = gp.kernel.anisotropic_parameters_initial_guess_zero_mean(mz, xi, zi)
+    # non positive-definite: enormous length-scales -> numerically singular K.
+    xi, zi = make_xz(300, 2, 33)
+    th_bad = np.array([0.0, -12.0, -12.0])
+    mz = gp.core.Model(None, make_kernel(2), None, None, "zero")
+    crit = gp.kernel.make_selection_criterion_with_gradient(mz, gp.kernel.negative_log_likelihood_zero_mean, xi, zi)
+    try:
+        mz.negative_log_likelihood_zero_mean(th_bad, xi, zi)
+        raised = ""
+    except Exception as exc:  # reference raises numpy.linalg.LinAlgError here
+        raised = type(exc).__name__ + ": " + str(exc)
+    out["lik_bad_xi"], out["lik_bad_zi"], out["lik_bad_theta"] = xi, zi, th_bad
+    out["lik_bad_raised"] = np.array(raised)
+    out["lik_bad_pre_grad_value"] = np.array(crit[1](th_bad))  # evaluate_pre_grad -> inf
+
+
+def gen_example02(out):
+    # config 1: examples/gpmp_example02_1d_interpolation.py (ldrandunif is unseeded -> capture xi)
+    xt = gp.misc.designs.regulargrid(1, 200, [[-1], [1]])
+    zt = gp.misc.testfunctions.twobumps(xt)
+    np.random.seed(20261004)
+    xi = gp.misc.designs.ldrandunif(1, 6, [[-1], [1]])
+    zi = gp.misc.testfunctions.twobumps(xi)
+    kernel = make_kernel(3)
+    model = gp.core.Model(constant_mean, kernel)
+    covparam0 = gp.kernel.anisotropic_parameters_initial_guess(model, xi, zi)
+    reml0 = model.negative_log_restricted_likelihood(covparam0, xi, zi)
+    model, info = gp.kernel.select_parameters_with_reml(model, xi, zi, info=True)
+    zpm, zpv = model.predict(xi, zi, xt)
+    out["ex02_xt"], out["ex02_zt"], out["ex02_xi"], out["ex02_zi"] = xt, zt, xi, zi
+    out["ex02_covparam0"], out["ex02_reml0"] = covparam0, np.array(reml0)
+    out["ex02_covparam"] = np.asarray(model.covparam)
+    out["ex02_reml_opt"] = np.array(model.negative_log_restricted_likelihood(model.covparam, xi, zi))
+    out["ex02_zpm"], out["ex02_zpv"] = zpm, zpv
+    out["ex02_nevals"] = np.array(len(info["history_criterion"]))
+
+
+def numpy_pass():
+    for name, fn in (("matern", gen_matern), ("predict", gen_predict), ("likelihood", gen_likelihood), ("example02", gen_example02)):
+        out = {}
+        fn(out)
+        path = os.path.join(HERE, f"ref_{name}.npz")
+        np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
+        print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
+# ---------------------------------------------------------------- torch pass (gradients)
+def torch_pass():
+    import torch
+
+    out = {}
+    rng = np.random.default_rng(41)
+    cases = (("a", (64, 3), 2), ("b", (256, 8), 2), ("c", (512, 20), 2), ("d", (100, 4), 1), ("e", (80, 2), 3))
+    for tag, (n, d), p in cases:
+        xi, zi = make_xz(n, d, 42)
+        out[f"grad_{tag}_xi"], out[f"grad_{tag}_zi"], out[f"grad_{tag}_p"] = xi, zi, np.array(p)
+        k = make_kernel(p)
+        mz = gp.core.Model(None, k, None, None, "zero")
+        mc = gp.core.Model(constant_mean, k, None, None, "linear_predictor")
+        ml = gp.core.Model(linear_mean, k, None, None, "linear_predictor")
+        thetas = np.stack([theta_aniso(d) + 0.2 * rng.standard_normal(d + 1) for _ in range(3)])
+        out[f"grad_{tag}_thetas"] = thetas
+        for name, model, crit_fn in (
+            ("nll", mz, gp.kernel.negative_log_likelihood_zero_mean),
+            ("reml_const", mc, gp.kernel.negative_log_restricted_likelihood),
+            ("reml_lin", ml, gp.kernel.negative_log_restricted_likelihood),
+        ):
+            _, pre, _, grad = gp.kernel.make_selection_criterion_with_gradient(model, crit_fn, xi, zi)
+            vals, grads = [], []
+            for t in thetas:
+                tt = torch.as_tensor(t, dtype=torch.float64)
+                vals.append(float(pre(tt)))
+                grads.append(tonp(grad(tt)))
+            out[f"grad_{tag}_{name}_val"], out[f"grad_{tag}_{name}_grad"] = np.array(vals), np.stack(grads)
+    # noisy kernel theta = [log s2, log s2_noise, log 1/rho ...] (example07 construction)
+    for tag, (n, d), p in (("na", (120, 3), 2), ("nb", (300, 6), 2)):
+        xi, zi = make_xz(n, d, 43, noise=0.05)
+        out[f"grad_{tag}_xi"], out[f"grad_{tag}_zi"], out[f"grad_{tag}_p"] = xi, zi, np.array(p)
+        k = make_noisy_kernel(p)
+        mz = gp.core.Model(None, k, None, None, "zero")
+        mc = gp.core.Model(constant_mean, k, None, None, "linear_predictor")
+        base = np.concatenate(([0.0, np.log(0.05 ** 2)], theta_aniso(d)[1:]))
+        thetas = np.stack([base + 0.2 * rng.standard_normal(d + 2) for _ in range(3)])
+        out[f"grad_{tag}_thetas"] = thetas
+        for name, model, crit_fn in (
+            ("nll", mz, gp.kernel.negative_log_likelihood_zero_mean),
+            ("reml_const", mc, gp.kernel.negative_log_restricted_likelihood),
+        ):
+            _, pre, _, grad = gp.kernel.make_selection_criterion_with_gradient(model, crit_fn, xi, zi)
+            vals, grads = [], []
+            for t in thetas:
+                tt = torch.as_tensor(t, dtype=torch.float64)
+                vals.append(float(pre(tt)))
+                grads.append(tonp(grad(tt)))
+            out[f"grad_{tag}_{name}_val"], out[f"grad_{tag}_{name}_grad"] = np.array(vals), np.stack(grads)
+    path = os.path.join(HERE, "ref_gradients.npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    if backend == "numpy":
+        numpy_pass()
+    else:
+        torch_pass()
