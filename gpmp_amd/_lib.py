@@ -1,0 +1,75 @@
+"""ctypes binding of libgpmp_hip.so (include/gpmp_hip.h).
+
+The library is the product path: there is NO CPU fallback.  Importing this module never touches the
+GPU; the first call that needs the library loads it and raises if it is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpmp_hip.so")
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/gpmp_hip.h line by line
+_P = c_void_p
+SIGNATURES = {
+    "gpmp_hip_abi_version": (c_int, []),
+    "gpmp_last_error": (c_char_p, []),
+    "gpmp_matern_gram": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_double, c_int, _P, c_long, _P]),
+    "gpmp_matern_pairwise": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P]),
+    "gpmp_scaled_distance": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_long, _P]),
+    "gpmp_maternp_kernel": (c_int, [_P, c_long, c_int, _P, _P]),
+    "gpmp_dinv_elems": (c_size_t, [c_int]),
+    "gpmp_potrf_lower_async": (c_int, [_P, c_int, c_long, _P, _P, _P]),
+    "gpmp_trsm_lower": (c_int, [_P, c_int, c_long, _P, _P, c_int, c_long, c_int, _P, _P]),
+    "gpmp_trtri_diag_blocks": (c_int, [_P, c_int, c_long, _P, _P]),
+    "gpmp_trtri_lower": (c_int, [_P, c_int, c_long, _P, _P, c_long, _P]),
+    "gpmp_lauum_lower": (c_int, [_P, c_int, c_long, _P, c_long, _P]),
+    "gpmp_tril": (c_int, [_P, c_int, c_long, _P]),
+    "gpmp_symmetrize_from_lower": (c_int, [_P, c_int, c_long, _P]),
+    "gpmp_dgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_double, _P, c_long, _P, c_long, c_double, _P, c_long, c_int, _P]),
+    "gpmp_coldots": (c_int, [_P, c_int, c_int, c_long, _P, c_int, c_long, _P, c_long, _P, _P]),
+    "gpmp_coldots_ws_rows": (c_int, [c_int]),
+    "gpmp_logdet_chol": (c_int, [_P, c_int, c_long, _P, _P]),
+    "gpmp_matern_grad_trace": (c_int, [_P, c_long, _P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, c_long, _P, _P, _P]),
+    "gpmp_grad_ws_elems": (c_size_t, [c_int, c_int]),
+}
+
+
+class GpmpHipError(RuntimeError):
+    """Raised when a libgpmp_hip entry point returns a non-zero status."""
+
+
+def load():
+    """Load libgpmp_hip.so (once) and declare every signature.  Fails loudly if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C gpmp_amd/csrc`). gpmp_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gpmp_last_error()
+        raise GpmpHipError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+
+def host_vec(values):
+    """Small host parameter vector -> ctypes double array (kept alive by the caller)."""
+    vals = [float(v) for v in values]
+    return (c_double * len(vals))(*vals)

@@ -1,0 +1,61 @@
+// Shared declarations for libgpmp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include "../../include/gpmp_hip.h"
+
+namespace gpmp {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int NB = GPMP_NB;       // diagonal block (potf2 / Dinv granularity) == GEMM tile edge
+constexpr int OUTER_BLOCKS = 4;   // outer panel = 4 diagonal blocks (rank-512 trailing updates)
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define GPMP_HIP_TRY(expr)                                   \
+  do {                                                       \
+    hipError_t e__ = (expr);                                 \
+    if (e__ != hipSuccess) return ::gpmp::hip_fail(e__, #expr); \
+  } while (0)
+
+#define GPMP_ARG(cond, k, msg)                                          \
+  do {                                                                  \
+    if (!(cond)) { ::gpmp::set_error("argument %d: %s", (k), (msg)); return -(k); } \
+  } while (0)
+
+inline hipStream_t as_stream(gpmp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- GEMM (gemm_f64.hip) --------------------------------------------------------------------
+// C (M x N, row-major) = alpha * A(M x K) * B(K x N) + beta * C.
+//   a_kc != 0: A(i,l) = A[i*lda + l]   (k-contiguous)   else A(i,l) = A[l*lda + i]
+//   b_kc != 0: B(l,j) = B[j*ldb + l]   (k-contiguous)   else B(l,j) = B[l*ldb + j]
+// lower_only: tiles strictly above the diagonal are skipped.  kstart_row: the k loop of tile row i
+// starts at row0(i) (lauum; K and M index the same axis).  kend_row: the k loop of tile row i ends
+// at row0(i) + 128 (triangular A: A(i,l) = 0 for l > i).
+struct GemmOpts {
+  int lower_only = 0;
+  int kstart_row = 0;
+  int kend_row = 0;
+};
+int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, long lda,
+                const double* B, long ldb, double beta, double* C, long ldc, const GemmOpts& o,
+                hipStream_t st);
+
+// ---- diagonal block kernels (potf2.hip) -------------------------------------------------------
+// Factor the jb x jb block at A (lower, in place) and write inv(L) (NB x NB, ld NB, zero padded /
+// identity padded) to dinv.  info_dev: set to (offset + k + 1) at the first non-positive pivot.
+int launch_potf2_inv(double* A, long lda, int jb, double* dinv, int* info_dev, int offset, hipStream_t st);
+// inv(L_kk) of every NB diagonal block of an already factored n x n lower L (one launch).
+int launch_trtri_blocks(const double* L, long ldl, int n, double* dinv, hipStream_t st);
+
+// ---- misc kernels (reduce.hip) -----------------------------------------------------------------
+int launch_tril(double* A, int n, long lda, hipStream_t st);
+int launch_symmetrize(double* A, int n, long lda, hipStream_t st);
+int launch_set_identity_lower(double* T, int n, long ldt, hipStream_t st);
+
+}  // namespace gpmp

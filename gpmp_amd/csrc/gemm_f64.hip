@@ -1,0 +1,277 @@
+// fp64 MFMA GEMM for gfx950 (MI355X) -- the one dense contraction behind the blocked Cholesky
+// (trailing syrk update, panel scaling), the blocked triangular solves, trtri and lauum.
+//
+// Design (measured on MI355X, see DESIGN.md / tools/mfma_f64_probe2.hip):
+//  * v_mfma_f64_16x16x4_f64 issues back-to-back every 64 cycles from ONE wave *only in its VGPR
+//    form*; with the accumulator in AGPRs it issues every ~147 cycles.  The library is therefore
+//    built with -mllvm -amdgpu-mfma-vgpr-form=1 and keeps accumulators in architectural VGPRs.
+//  * 128 x 128 x 16 block tile, 256 threads = 4 waves (2 x 2), each wave a 64 x 64 sub-tile =
+//    4 x 4 MFMA tiles = 128 accumulator VGPRs; 2 workgroups per CU.
+//  * Operands staged global -> registers -> LDS (double buffered, one barrier per k-tile).
+//    LDS images are padded so that the MFMA fragment reads (ds_read_b64) are bank-conflict free:
+//      k-contiguous operand:  [128 rows][16 k] with row stride 18 doubles
+//      m/n-contiguous operand: [16 k][128 cols] with row stride 144 doubles
+//  * Fragment / accumulator lane maps of v_mfma_f64_16x16x4_f64 (verified on hardware):
+//      A: lane l holds A[row = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][col = l & 15];
+//      C/D register r of lane l: row = (l >> 4) + 4 r, col = l & 15.
+//  * blockIdx -> tile map is XCD aware: each XCD (own L2) gets a contiguous run of tiles.
+#include "common.h"
+
+namespace gpmp {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDK = 18;    // row stride of a k-contiguous tile image
+constexpr int LDN = 144;   // row stride of an m/n-contiguous tile image
+constexpr int TILE = 2304; // doubles per operand tile image (128*18 == 16*144)
+constexpr int NXCD = 8;
+
+struct GemmParams {
+  const double* A;
+  const double* B;
+  double* C;
+  long lda, ldb, ldc;
+  int M, N, K;
+  double alpha, beta;
+  int lower_only, kstart_row, kend_row;
+  int tiles_m, tiles_n, ntiles;
+  int aligned;  // 16-byte loads allowed on A and B
+};
+
+__device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& ti, int& tj) {
+  // XCD-aware remap (bijective for any grid size): workgroups are dealt round-robin over the 8
+  // XCDs, so give XCD x the x-th contiguous chunk of the tile list.
+  const int nwg = p.ntiles;
+  const int q = nwg / NXCD, r = nwg % NXCD;
+  const int xcd = bid % NXCD;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int v = base + bid / NXCD;
+  if (p.lower_only) {
+    const int tn = p.tiles_n < p.tiles_m ? p.tiles_n : p.tiles_m;
+    const int t1 = tn * (tn + 1) / 2;
+    if (v < t1) {
+      int i = (int)((sqrt(8.0 * (double)v + 1.0) - 1.0) * 0.5);
+      while ((i + 1) * (i + 2) / 2 <= v) ++i;
+      while (i * (i + 1) / 2 > v) --i;
+      ti = i;
+      tj = v - i * (i + 1) / 2;
+    } else {
+      const int rr = v - t1;
+      ti = tn + rr / tn;
+      tj = rr % tn;
+    }
+  } else {
+    constexpr int GM = 8;
+    const int per_group = GM * p.tiles_n;
+    const int g = v / per_group;
+    const int first = g * GM;
+    const int gsize = (p.tiles_m - first) < GM ? (p.tiles_m - first) : GM;
+    const int w = v - g * per_group;
+    ti = first + w % gsize;
+    tj = w / gsize;
+  }
+}
+
+// ---- global -> register staging --------------------------------------------------------------
+// KC: element (idx, k) at G[idx * ld + k].  Thread t loads k pair (t & 7), rows (t >> 3) + 32 s.
+template <bool FAST>
+__device__ __forceinline__ void load_kc(const double* __restrict__ G, long ld, int idx0, int lim,
+                                        int k0, int kend, int t, d2 (&r)[4]) {
+  const int kp = (t & 7) * 2;
+  const int rr = t >> 3;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int row = idx0 + rr + 32 * s;
+    const double* ptr = G + (long)row * ld + k0 + kp;
+    if constexpr (FAST) {
+      r[s] = *reinterpret_cast<const d2*>(ptr);
+    } else {
+      d2 v = {0.0, 0.0};
+      if (row < lim) {
+        if (k0 + kp < kend) v[0] = ptr[0];
+        if (k0 + kp + 1 < kend) v[1] = ptr[1];
+      }
+      r[s] = v;
+    }
+  }
+}
+// MC: element (idx, k) at G[k * ld + idx].  Thread t loads column pair (t & 63), k rows (t >> 6) + 4 s.
+template <bool FAST>
+__device__ __forceinline__ void load_mc(const double* __restrict__ G, long ld, int idx0, int lim,
+                                        int k0, int kend, int t, d2 (&r)[4]) {
+  const int cp = (t & 63) * 2;
+  const int kr = t >> 6;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = k0 + kr + 4 * s;
+    const double* ptr = G + (long)k * ld + idx0 + cp;
+    if constexpr (FAST) {
+      r[s] = *reinterpret_cast<const d2*>(ptr);
+    } else {
+      d2 v = {0.0, 0.0};
+      if (k < kend) {
+        if (idx0 + cp < lim) v[0] = ptr[0];
+        if (idx0 + cp + 1 < lim) v[1] = ptr[1];
+      }
+      r[s] = v;
+    }
+  }
+}
+__device__ __forceinline__ void store_kc(double* __restrict__ S, int t, const d2 (&r)[4]) {
+  const int kp = (t & 7) * 2;
+  const int rr = t >> 3;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) *reinterpret_cast<d2*>(S + (rr + 32 * s) * LDK + kp) = r[s];
+}
+__device__ __forceinline__ void store_mc(double* __restrict__ S, int t, const d2 (&r)[4]) {
+  const int cp = (t & 63) * 2;
+  const int kr = t >> 6;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) *reinterpret_cast<d2*>(S + (kr + 4 * s) * LDN + cp) = r[s];
+}
+
+template <bool AKC, bool BKC>
+__global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // [2 buffers][A tile | B tile]
+  int ti, tj;
+  decode_tile(p, blockIdx.x, ti, tj);
+  const int row0 = ti * BM, col0 = tj * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int lr = lane & 15, lk = lane >> 4;
+
+  int kbeg = p.kstart_row ? row0 : 0;
+  int kend = p.K;
+  if (p.kend_row && row0 + BM < kend) kend = row0 + BM;
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  const bool full_mn = p.aligned && (row0 + BM <= p.M) && (col0 + BN <= p.N);
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  d2 ra[4], rb[4];
+  auto load_tiles = [&](int kt) {
+    const int k0 = kbeg + kt * BK;
+    if (full_mn && k0 + BK <= kend) {
+      if constexpr (AKC) load_kc<true>(p.A, p.lda, row0, p.M, k0, kend, t, ra);
+      else load_mc<true>(p.A, p.lda, row0, p.M, k0, kend, t, ra);
+      if constexpr (BKC) load_kc<true>(p.B, p.ldb, col0, p.N, k0, kend, t, rb);
+      else load_mc<true>(p.B, p.ldb, col0, p.N, k0, kend, t, rb);
+    } else {
+      if constexpr (AKC) load_kc<false>(p.A, p.lda, row0, p.M, k0, kend, t, ra);
+      else load_mc<false>(p.A, p.lda, row0, p.M, k0, kend, t, ra);
+      if constexpr (BKC) load_kc<false>(p.B, p.ldb, col0, p.N, k0, kend, t, rb);
+      else load_mc<false>(p.B, p.ldb, col0, p.N, k0, kend, t, rb);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    double* sa = smem + buf * 2 * TILE;
+    double* sb = sa + TILE;
+    if constexpr (AKC) store_kc(sa, t, ra); else store_mc(sa, t, ra);
+    if constexpr (BKC) store_kc(sb, t, rb); else store_mc(sb, t, rb);
+  };
+
+  if (nk > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);  // global loads fly while the MFMAs below run
+    const double* sa = smem + cur * 2 * TILE;
+    const double* sb = sa + TILE;
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (AKC) a[i] = sa[(wm + i * 16 + lr) * LDK + ks * 4 + lk];
+        else a[i] = sa[(ks * 4 + lk) * LDN + wm + i * 16 + lr];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (BKC) b[j] = sb[(wn + j * 16 + lr) * LDK + ks * 4 + lk];
+        else b[j] = sb[(ks * 4 + lk) * LDN + wn + j * 16 + lr];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C = alpha * acc + beta * C
+  const double alpha = p.alpha, beta = p.beta;
+  const bool full_c = (row0 + BM <= p.M) && (col0 + BN <= p.N);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + wm + i * 16 + lk + 4 * r;
+      double* crow = p.C + (long)row * p.ldc + col0 + wn + lr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = col0 + wn + j * 16 + lr;
+        if (full_c || (row < p.M && col < p.N)) {
+          double v = alpha * acc[i][j][r];
+          if (beta != 0.0) v += beta * crow[j * 16];
+          crow[j * 16] = v;
+        }
+      }
+    }
+  }
+}
+
+template <bool AKC, bool BKC>
+int launch_t(const GemmParams& p, hipStream_t st) {
+  static bool attr_done = false;
+  const size_t lds = sizeof(double) * 4 * TILE;  // 73,728 B
+  if (!attr_done) {
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<AKC, BKC>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC>), dim3(p.ntiles), dim3(256), lds, st, p);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, long lda,
+                const double* B, long ldb, double beta, double* C, long ldc, const GemmOpts& o,
+                hipStream_t st) {
+  if (M <= 0 || N <= 0) return 0;
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K;
+  p.alpha = alpha; p.beta = beta;
+  p.lower_only = o.lower_only; p.kstart_row = o.kstart_row; p.kend_row = o.kend_row;
+  p.tiles_m = (M + BM - 1) / BM;
+  p.tiles_n = (N + BN - 1) / BN;
+  if (o.lower_only) {
+    const int tn = p.tiles_n < p.tiles_m ? p.tiles_n : p.tiles_m;
+    p.ntiles = tn * (tn + 1) / 2 + (p.tiles_m - tn) * tn;
+  } else {
+    p.ntiles = p.tiles_m * p.tiles_n;
+  }
+  p.aligned = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0) &&
+              ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((ldb & 1) == 0);
+  if (a_kc && b_kc) return launch_t<true, true>(p, st);
+  if (a_kc && !b_kc) return launch_t<true, false>(p, st);
+  if (!a_kc && !b_kc) return launch_t<false, false>(p, st);
+  return launch_t<false, true>(p, st);
+}
+
+}  // namespace gpmp

@@ -1,0 +1,528 @@
+// Fused anisotropic-distance + Matern Gram kernels for gfx950, and the analytic-gradient trace pass.
+//
+// One pass replaces gnp.scaled_distance (scipy cdist on pre-scaled points, direct sum of squared
+// differences -- gpmp/num/numpy_backend.py:432-436), maternp_kernel's ~2p+3 full-size temporaries
+// (gpmp/kernel/matern.py:54-64) and the dense "+ nugget * eye(n)" (matern.py:94).  The distance
+// matrix is never stored: algorithmic HBM traffic is the 8 n m bytes of K written.
+//
+// Tiling: 64 x 64 output tile per 256-thread workgroup, 4 x 4 outputs per thread.  The x / y row
+// blocks are pre-scaled by 1/rho while staged into LDS ([k][64] images, 16 dimensions per chunk);
+// each lane then writes 4 x 32 contiguous bytes per row (coalesced 512 B per 16 lanes).
+#include "common.h"
+#include <cmath>
+
+namespace gpmp {
+namespace {
+
+constexpr int GT = 64;   // tile edge
+constexpr int DC = 16;   // dimensions per LDS chunk
+
+struct MaternSpec {
+  int p;
+  double c;                      // 2 sqrt(p + 1/2)
+  double q[GPMP_MAX_P + 1];      // K(h) = exp(-t/2) sum_k q[k] t^k, t = 2 c h
+  double s[GPMP_MAX_P + 1];      // (dK/dh)/h = (2c)^2 exp(-t/2) sum_{k>=1} s[k] t^(k-1)   (p >= 1)
+};
+
+struct GramParams {
+  const double* x;
+  const double* y;
+  double* K;
+  long ldk;
+  int n, m, d;
+  int same, lower_only, aligned;
+  int mode;                      // 0: covariance, 1: distance only
+  double sigma2, diag_add;
+  double invrho[GPMP_MAX_DIM];
+  MaternSpec ms;
+};
+
+__device__ __forceinline__ double matern_eval(const MaternSpec& ms, double h) {
+  // maternp_kernel, gpmp/kernel/matern.py:54-64 (Horner form of the same polynomial).
+  const double t = 2.0 * ms.c * h;
+  double poly = ms.q[ms.p];
+  for (int k = ms.p - 1; k >= 0; --k) poly = poly * t + ms.q[k];
+  return exp(-ms.c * h) * poly;
+}
+
+template <int P>
+__device__ __forceinline__ double matern_eval_p(const MaternSpec& ms, double h) {
+  const double t = 2.0 * ms.c * h;
+  double poly = ms.q[P];
+#pragma unroll
+  for (int k = P - 1; k >= 0; --k) poly = poly * t + ms.q[k];
+  return exp(-ms.c * h) * poly;
+}
+
+__device__ __forceinline__ double matern_dispatch(const MaternSpec& ms, double h) {
+  switch (ms.p) {
+    case 0: return matern_eval_p<0>(ms, h);
+    case 1: return matern_eval_p<1>(ms, h);
+    case 2: return matern_eval_p<2>(ms, h);
+    case 3: return matern_eval_p<3>(ms, h);
+    case 4: return matern_eval_p<4>(ms, h);
+    default: return matern_eval(ms, h);
+  }
+}
+
+__global__ void __launch_bounds__(256) gram_kernel(GramParams p) {
+  __shared__ __attribute__((aligned(16))) double xs[DC][GT];
+  __shared__ __attribute__((aligned(16))) double ys[DC][GT];
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  if (p.lower_only && tj > ti) return;
+  const int row0 = ti * GT, col0 = tj * GT;
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  const double* __restrict__ yp = p.same ? p.x : p.y;
+
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+
+  for (int k0 = 0; k0 < p.d; k0 += DC) {
+    if (k0) __syncthreads();
+    // stage 64 rows x 16 dims of x and y, scaled by 1/rho (numpy_backend.py:433-435)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = t + 256 * e;       // 0..1023
+      const int r = idx / DC, k = idx % DC;
+      double vx = 0.0, vy = 0.0;
+      if (k0 + k < p.d) {
+        const double ir = p.invrho[k0 + k];
+        if (row0 + r < p.n) vx = ir * p.x[(long)(row0 + r) * p.d + k0 + k];
+        if (col0 + r < p.m) vy = ir * yp[(long)(col0 + r) * p.d + k0 + k];
+      }
+      xs[k][r] = vx;
+      ys[k][r] = vy;
+    }
+    __syncthreads();
+    const int kmax = (p.d - k0) < DC ? (p.d - k0) : DC;
+    for (int k = 0; k < kmax; ++k) {
+      const d4 xa = *reinterpret_cast<const d4*>(&xs[k][ty * 4]);
+      const d4 yb = *reinterpret_cast<const d4*>(&ys[k][tx * 4]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double df = xa[a] - yb[b];
+          acc[a][b] = fma(df, df, acc[a][b]);
+        }
+    }
+  }
+
+  const bool full = p.aligned && (row0 + GT <= p.n) && (col0 + GT <= p.m);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int row = row0 + ty * 4 + a;
+    double v[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = col0 + tx * 4 + b;
+      const double h = sqrt(acc[a][b]);
+      double val = h;
+      if (p.mode == 0) {
+        val = p.sigma2 * matern_dispatch(p.ms, h);
+        if (p.same && row == col) val += p.diag_add;
+      }
+      v[b] = val;
+    }
+    double* out = p.K + (long)row * p.ldk + col0 + tx * 4;
+    if (full) {
+      *reinterpret_cast<d2*>(out) = (d2){v[0], v[1]};
+      *reinterpret_cast<d2*>(out + 2) = (d2){v[2], v[3]};
+    } else if (row < p.n) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (col0 + tx * 4 + b < p.m) out[b] = v[b];
+    }
+  }
+}
+
+struct PairParams {
+  const double* x;
+  const double* y;
+  double* out;
+  int n, d, same;
+  double sigma2;
+  double invrho[GPMP_MAX_DIM];
+  MaternSpec ms;
+};
+
+__global__ void pairwise_kernel(PairParams p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n) return;
+  double h = 0.0;
+  if (!p.same) {
+    double s = 0.0;
+    for (int k = 0; k < p.d; ++k) {
+      const double df = p.invrho[k] * (p.x[(long)i * p.d + k] - p.y[(long)i * p.d + k]);
+      s = fma(df, df, s);
+    }
+    h = sqrt(s);
+  }
+  p.out[i] = p.sigma2 * matern_dispatch(p.ms, h);
+}
+
+__global__ void matern_elementwise_kernel(const double* __restrict__ h, long count, MaternSpec ms,
+                                          double* __restrict__ out) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) {
+    double hv = h[i];
+    if (isinf(hv)) hv = 1.7976931348623157e308 / 1000.0;  // inftobigf, numpy_backend.py:250-252
+    out[i] = matern_dispatch(ms, hv);
+  }
+}
+
+// ---- gradient trace pass ----------------------------------------------------------------------
+// g[0]      = sum M_ik K_ik                       (d/d log sigma^2; diag_add scales with sigma^2
+//                                                  when it is the default nugget, see host code)
+// g[1 + j]  = sum M_ik sigma2 (K'(h)/h) (xs_ij - xs_kj)^2          (d/d log(1/rho_j))
+// g[DT + 1] = trace(M)                            (for the noise-variance parameter)
+// with M_ik = Kinv_ik - sum_a F_ia G_ka, summed over the full symmetric matrix by visiting tiles on
+// and below the diagonal (off-diagonal entries weigh 2).
+struct GradParams {
+  const double* Kinv;
+  long ldk;
+  const double* x;
+  const double* F;
+  const double* G;
+  long ldf;
+  int n, d, r;
+  int ntiles_side, ntiles;
+  double sigma2;
+  double* partial;  // [gridDim.x][DT + 2]
+  double invrho[GPMP_MAX_DIM];
+  MaternSpec ms;
+};
+
+__device__ __forceinline__ double matern_dk_over_h(const MaternSpec& ms, double h, double& kval) {
+  const double t = 2.0 * ms.c * h;
+  const double e = exp(-ms.c * h);
+  double poly = ms.q[ms.p];
+  for (int k = ms.p - 1; k >= 0; --k) poly = poly * t + ms.q[k];
+  kval = e * poly;
+  if (ms.p == 0) return h > 0.0 ? -ms.c * e / h : 0.0;
+  double s = ms.s[ms.p];
+  for (int k = ms.p - 1; k >= 1; --k) s = s * t + ms.s[k];
+  return (2.0 * ms.c) * (2.0 * ms.c) * e * s;
+}
+
+template <int DT>
+__global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* xs = sm;                    // [DT][GT]
+  double* ys = xs + DT * GT;          // [DT][GT]
+  double* fs = ys + DT * GT;          // [r][GT]  F rows of the tile's i block
+  double* gs = fs + p.r * GT;         // [r][GT]  G rows of the tile's k block
+  __shared__ double red[4][DT + 2];
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+
+  double gacc[DT];
+#pragma unroll
+  for (int k = 0; k < DT; ++k) gacc[k] = 0.0;
+  double g0 = 0.0, gtr = 0.0;
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    int ti = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    while (ti * (ti + 1) / 2 > tile) --ti;
+    const int tj = tile - ti * (ti + 1) / 2;
+    const int row0 = ti * GT, col0 = tj * GT;
+    __syncthreads();
+    for (int idx = t; idx < DT * GT; idx += 256) {
+      const int r = idx / DT, k = idx % DT;
+      double vx = 0.0, vy = 0.0;
+      if (k < p.d) {
+        const double ir = p.invrho[k];
+        if (row0 + r < p.n) vx = ir * p.x[(long)(row0 + r) * p.d + k];
+        if (col0 + r < p.n) vy = ir * p.x[(long)(col0 + r) * p.d + k];
+      }
+      xs[k * GT + r] = vx;
+      ys[k * GT + r] = vy;
+    }
+    for (int idx = t; idx < p.r * GT; idx += 256) {
+      const int r = idx / p.r, a = idx % p.r;
+      fs[a * GT + r] = (row0 + r < p.n) ? p.F[(long)(row0 + r) * p.ldf + a] : 0.0;
+      gs[a * GT + r] = (col0 + r < p.n) ? p.G[(long)(col0 + r) * p.ldf + a] : 0.0;
+    }
+    __syncthreads();
+
+    double h2[4][4], w[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { h2[a][b] = 0.0; w[a][b] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < DT; ++k) {
+      if (k < p.d) {
+        const d4 xa = *reinterpret_cast<const d4*>(&xs[k * GT + ty * 4]);
+        const d4 yb = *reinterpret_cast<const d4*>(&ys[k * GT + tx * 4]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const double df = xa[a] - yb[b];
+            h2[a][b] = fma(df, df, h2[a][b]);
+          }
+      }
+    }
+    // low-rank part of M
+    for (int a2 = 0; a2 < p.r; ++a2) {
+      const d4 fa = *reinterpret_cast<const d4*>(&fs[a2 * GT + ty * 4]);
+      const d4 gb = *reinterpret_cast<const d4*>(&gs[a2 * GT + tx * 4]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) w[a][b] = fma(fa[a], gb[b], w[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int row = row0 + ty * 4 + a;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int col = col0 + tx * 4 + b;
+        double wt = 0.0;
+        if (row < p.n && col < p.n) wt = col < row ? 2.0 : (col == row ? 1.0 : 0.0);
+        double mval = 0.0;
+        if (wt != 0.0) mval = wt * (p.Kinv[(long)row * p.ldk + col] - w[a][b]);
+        double kval;
+        const double dk = matern_dk_over_h(p.ms, sqrt(h2[a][b]), kval);
+        g0 = fma(mval, kval, g0);
+        if (row == col) gtr += mval;
+        w[a][b] = mval * dk;  // weight of (delta_j)^2 for every dimension j
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < DT; ++k) {
+      if (k < p.d) {
+        const d4 xa = *reinterpret_cast<const d4*>(&xs[k * GT + ty * 4]);
+        const d4 yb = *reinterpret_cast<const d4*>(&ys[k * GT + tx * 4]);
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const double df = xa[a] - yb[b];
+            s = fma(w[a][b], df * df, s);
+          }
+        gacc[k] += s;
+      }
+    }
+  }
+
+  // block reduction: wave shuffle, then across the 4 waves through LDS
+  const int lane = t & 63, wave = t >> 6;
+  auto wave_sum = [](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  g0 = wave_sum(g0);
+  gtr = wave_sum(gtr);
+#pragma unroll
+  for (int k = 0; k < DT; ++k) gacc[k] = wave_sum(gacc[k]);
+  if (lane == 0) {
+    red[wave][0] = g0;
+#pragma unroll
+    for (int k = 0; k < DT; ++k) red[wave][1 + k] = gacc[k];
+    red[wave][DT + 1] = gtr;
+  }
+  __syncthreads();
+  if (t < DT + 2) {
+    p.partial[(long)blockIdx.x * (DT + 2) + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+  }
+}
+
+__global__ void grad_finalize_kernel(const double* __restrict__ partial, int nblocks, int width,
+                                     int d, int noise, double sigma2, double nugget_scale,
+                                     double noise_var, double* __restrict__ g) {
+  // one thread per output column of `partial`
+  const int k = threadIdx.x;
+  if (k >= width) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * width + k];
+  __shared__ double tot[GPMP_MAX_DIM + 2];
+  tot[k] = s;
+  __syncthreads();
+  const double tr = tot[width - 1];
+  if (k == 0) {
+    // K = sigma2 * Kc (+ nugget 10 eps sigma2 I when there is no noise parameter)
+    g[0] = sigma2 * tot[0] + nugget_scale * sigma2 * tr;
+    if (noise) g[1] = noise_var * tr;
+  }
+  if (k >= 1 && k <= d) g[(noise ? 1 : 0) + k] = sigma2 * tot[k];
+}
+
+// ---- host-side helpers -------------------------------------------------------------------------
+int fill_matern(MaternSpec& ms, int p) {
+  if (p < 0 || p > GPMP_MAX_P) return -1;
+  ms.p = p;
+  ms.c = 2.0 * std::sqrt(p + 0.5);
+  for (int k = 0; k <= GPMP_MAX_P; ++k) ms.q[k] = ms.s[k] = 0.0;
+  ms.q[0] = 1.0;
+  for (int i = 0; i < p; ++i) {  // a_i multiplies t^(p-i), gpmp/kernel/matern.py:59-63
+    const double a = std::exp(std::lgamma(p + 1.0) - std::lgamma(2.0 * p + 1.0) + std::lgamma(p + i + 1.0) -
+                              std::lgamma(i + 1.0) - std::lgamma(p - i + 1.0));
+    ms.q[p - i] = a;
+  }
+  for (int k = 0; k <= p; ++k) ms.s[k] = (k + 1 <= p ? (k + 1) * ms.q[k + 1] : 0.0) - 0.5 * ms.q[k];
+  return 0;
+}
+
+}  // namespace
+}  // namespace gpmp
+
+using namespace gpmp;
+
+extern "C" int gpmp_matern_gram(const double* x, const double* y, int n, int m, int d, int p,
+                                const double* theta_host, int noise, double diag_add, int lower_only,
+                                double* K, long ldk, gpmp_stream_t stream) {
+  GPMP_ARG(x != nullptr, 1, "x is NULL");
+  GPMP_ARG(n >= 0, 3, "n < 0");
+  GPMP_ARG(m >= 0, 4, "m < 0");
+  GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 5, "d outside [1, GPMP_MAX_DIM]");
+  GPMP_ARG(p >= 0 && p <= GPMP_MAX_P, 6, "p outside [0, GPMP_MAX_P]");
+  GPMP_ARG(theta_host != nullptr, 7, "theta is NULL");
+  GPMP_ARG(K != nullptr, 11, "K is NULL");
+  if (y == nullptr) m = n;
+  GPMP_ARG(ldk >= m, 12, "ldk < m");
+  if (n == 0 || m == 0) return 0;
+  GramParams gp;
+  gp.x = x; gp.y = y; gp.K = K; gp.ldk = ldk;
+  gp.n = n; gp.m = m; gp.d = d;
+  gp.same = (y == nullptr); gp.lower_only = (y == nullptr) ? lower_only : 0;
+  gp.aligned = ((reinterpret_cast<uintptr_t>(K) & 15) == 0) && ((ldk & 1) == 0);
+  gp.mode = 0;
+  gp.sigma2 = std::exp(theta_host[0]);
+  gp.diag_add = diag_add;
+  const int off = noise ? 2 : 1;
+  for (int k = 0; k < d; ++k) gp.invrho[k] = std::exp(theta_host[off + k]);
+  fill_matern(gp.ms, p);
+  dim3 grid((m + GT - 1) / GT, (n + GT - 1) / GT);
+  hipLaunchKernelGGL(gram_kernel, grid, dim3(256), 0, as_stream(stream), gp);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gpmp_scaled_distance(const double* x, const double* y, int n, int m, int d,
+                                    const double* loginvrho_host, double* D, long ldd,
+                                    gpmp_stream_t stream) {
+  GPMP_ARG(x != nullptr && y != nullptr, 1, "x or y is NULL");
+  GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 5, "d outside [1, GPMP_MAX_DIM]");
+  GPMP_ARG(D != nullptr && ldd >= m, 7, "D is NULL or ldd < m");
+  if (n <= 0 || m <= 0) return 0;
+  GramParams gp;
+  gp.x = x; gp.y = y; gp.K = D; gp.ldk = ldd;
+  gp.n = n; gp.m = m; gp.d = d;
+  gp.same = 0; gp.lower_only = 0;
+  gp.aligned = ((reinterpret_cast<uintptr_t>(D) & 15) == 0) && ((ldd & 1) == 0);
+  gp.mode = 1; gp.sigma2 = 1.0; gp.diag_add = 0.0;
+  for (int k = 0; k < d; ++k) gp.invrho[k] = std::exp(loginvrho_host[k]);
+  fill_matern(gp.ms, 0);
+  dim3 grid((m + GT - 1) / GT, (n + GT - 1) / GT);
+  hipLaunchKernelGGL(gram_kernel, grid, dim3(256), 0, as_stream(stream), gp);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gpmp_matern_pairwise(const double* x, const double* y, int n, int d, int p,
+                                    const double* theta_host, int noise, double* out,
+                                    gpmp_stream_t stream) {
+  GPMP_ARG(x != nullptr, 1, "x is NULL");
+  GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 4, "d outside [1, GPMP_MAX_DIM]");
+  GPMP_ARG(p >= 0 && p <= GPMP_MAX_P, 5, "p outside [0, GPMP_MAX_P]");
+  GPMP_ARG(out != nullptr, 8, "out is NULL");
+  if (n <= 0) return 0;
+  PairParams pp;
+  pp.x = x; pp.y = y; pp.out = out; pp.n = n; pp.d = d; pp.same = (y == nullptr || y == x);
+  pp.sigma2 = std::exp(theta_host[0]);
+  const int off = noise ? 2 : 1;
+  for (int k = 0; k < d; ++k) pp.invrho[k] = std::exp(theta_host[off + k]);
+  fill_matern(pp.ms, p);
+  hipLaunchKernelGGL(pairwise_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), pp);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gpmp_maternp_kernel(const double* h, long count, int p, double* out, gpmp_stream_t stream) {
+  GPMP_ARG(h != nullptr, 1, "h is NULL");
+  GPMP_ARG(p >= 0 && p <= GPMP_MAX_P, 3, "p outside [0, GPMP_MAX_P]");
+  GPMP_ARG(out != nullptr, 4, "out is NULL");
+  if (count <= 0) return 0;
+  MaternSpec ms;
+  fill_matern(ms, p);
+  long blocks = (count + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(matern_elementwise_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), h, count, ms, out);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+namespace {
+constexpr int GRAD_BLOCKS = 1024;
+int grad_tier(int d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : 64; }
+
+template <int DT>
+int launch_grad(GradParams& gp, int nblocks, hipStream_t st) {
+  const size_t lds = sizeof(double) * (2 * DT * GT + 2 * (size_t)gp.r * GT);
+  static bool attr_done = false;
+  if (!attr_done) {
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grad_trace_kernel<DT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((grad_trace_kernel<DT>), dim3(nblocks), dim3(256), lds, st, gp);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" size_t gpmp_grad_ws_elems(int n, int d) {
+  (void)n;
+  return (size_t)GRAD_BLOCKS * (grad_tier(d) + 2);
+}
+
+extern "C" int gpmp_matern_grad_trace(const double* Kinv, long ldk, const double* x, int n, int d, int p,
+                                      const double* theta_host, int noise, const double* F,
+                                      const double* G, int r, long ldf, double* g_dev, double* ws,
+                                      gpmp_stream_t stream) {
+  GPMP_ARG(Kinv != nullptr, 1, "Kinv is NULL");
+  GPMP_ARG(x != nullptr, 3, "x is NULL");
+  GPMP_ARG(n >= 1, 4, "n < 1");
+  GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 5, "d outside [1, GPMP_MAX_DIM]");
+  GPMP_ARG(p >= 0 && p <= GPMP_MAX_P, 6, "p outside [0, GPMP_MAX_P]");
+  GPMP_ARG(r >= 0 && r <= GPMP_MAX_RANK, 11, "r outside [0, GPMP_MAX_RANK]");
+  GPMP_ARG(r == 0 || (F != nullptr && G != nullptr), 9, "F/G NULL with r > 0");
+  GPMP_ARG(g_dev != nullptr && ws != nullptr, 13, "g or ws is NULL");
+  GradParams gp;
+  gp.Kinv = Kinv; gp.ldk = ldk; gp.x = x; gp.F = F; gp.G = G; gp.ldf = ldf;
+  gp.n = n; gp.d = d; gp.r = r;
+  gp.ntiles_side = (n + GT - 1) / GT;
+  gp.ntiles = gp.ntiles_side * (gp.ntiles_side + 1) / 2;
+  gp.sigma2 = std::exp(theta_host[0]);
+  gp.partial = ws;
+  const int off = noise ? 2 : 1;
+  for (int k = 0; k < d; ++k) gp.invrho[k] = std::exp(theta_host[off + k]);
+  fill_matern(gp.ms, p);
+  const int nblocks = gp.ntiles < GRAD_BLOCKS ? gp.ntiles : GRAD_BLOCKS;
+  const int dt = grad_tier(d);
+  int rc = 0;
+  hipStream_t st = as_stream(stream);
+  switch (dt) {
+    case 4: rc = launch_grad<4>(gp, nblocks, st); break;
+    case 8: rc = launch_grad<8>(gp, nblocks, st); break;
+    case 16: rc = launch_grad<16>(gp, nblocks, st); break;
+    case 32: rc = launch_grad<32>(gp, nblocks, st); break;
+    default: rc = launch_grad<64>(gp, nblocks, st); break;
+  }
+  if (rc) return rc;
+  const double eps = 2.220446049250313e-16;
+  const double nugget_scale = noise ? 0.0 : 10.0 * eps;   // matern.py:90: nugget = 10 sigma2 eps
+  const double noise_var = noise ? std::exp(theta_host[1]) : 0.0;
+  hipLaunchKernelGGL(grad_finalize_kernel, dim3(1), dim3(128), 0, st, ws, nblocks, dt + 2, d, noise,
+                     gp.sigma2, nugget_scale, noise_var, g_dev);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}

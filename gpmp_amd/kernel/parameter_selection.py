@@ -1,0 +1,169 @@
+"""Selection criteria and the SciPy driver -- counterpart of the parts of
+gpmp/kernel/parameter_selection.py that configs 1 and 4 exercise:
+``make_selection_criterion_with_gradient`` (:35-124), ``autoselect_parameters`` (:128-276),
+``select_parameters_with_criterion`` (:280-437) and ``select_parameters_with_reml`` (:747-808).
+The optimiser stays SciPy on the host; each evaluation is one Gram build + Cholesky (+ gradient) on
+the GPU.  The REMAP family is out of scope (host-side priors, section 8f).
+"""
+import time
+
+import numpy as np
+from scipy.optimize import minimize
+
+from .. import num as gnp
+from .init import anisotropic_parameters_initial_guess
+from .matern import MaternCovariance
+
+
+# criteria with the reference's call signatures (parameter_selection.py re-exports of core.likelihood)
+def negative_log_likelihood_zero_mean(model, covparam, xi, zi):
+    return model.negative_log_likelihood_zero_mean(covparam, xi, zi)
+
+
+def negative_log_likelihood(model, meanparam, covparam, xi, zi):
+    return model.negative_log_likelihood(meanparam, covparam, xi, zi)
+
+
+def negative_log_restricted_likelihood(model, covparam, xi, zi):
+    return model.negative_log_restricted_likelihood(covparam, xi, zi)
+
+
+def _analytic_for(model, selection_criterion, parameterized_mean):
+    if parameterized_mean or not isinstance(model.covariance, MaternCovariance):
+        return None
+    from ..core import gradients as _gradients  # deferred: core imports kernel.matern
+
+    if selection_criterion is negative_log_likelihood_zero_mean:
+        return _gradients.MLZeroMeanAnalytic(model)
+    if selection_criterion is negative_log_restricted_likelihood:
+        return _gradients.REMLAnalytic(model)
+    return None
+
+
+def make_selection_criterion_with_gradient(model, selection_criterion, xi=None, zi=None, dataloader=None,
+                                           batches_per_eval=0, parameterized_mean=False, meanparam_len=1):
+    """gpmp/kernel/parameter_selection.py:35-124 -> (evaluate, evaluate_pre_grad, evaluate_no_grad, gradient).
+
+    ``gradient`` is analytic for the library's ML / REML criteria on a ``MaternCovariance`` and None
+    otherwise (SciPy then differentiates numerically, as with the reference's NumPy backend).
+    """
+    if dataloader is not None:
+        raise NotImplementedError("dataloaders are outside the hot path (SURVEY.md section 2, row 23)")
+    if xi is None or zi is None:
+        raise ValueError("Provide either (xi, zi) or dataloader.")
+    if parameterized_mean:
+
+        def crit_(param, xi, zi):
+            return selection_criterion(model, param[:meanparam_len], param[meanparam_len:], xi, zi)
+
+    else:
+
+        def crit_(covparam, xi, zi):
+            return selection_criterion(model, covparam, xi, zi)
+
+    xi_, zi_ = gnp.asarray(xi), gnp.asarray(zi)
+    crit = gnp.DifferentiableSelectionCriterion(crit_, xi_, zi_, analytic=_analytic_for(model, selection_criterion, parameterized_mean))
+    return crit.evaluate, crit.evaluate_pre_grad, crit.evaluate_no_grad, crit.gradient
+
+
+def autoselect_parameters(p0, criterion, gradient, bounds=None, bounds_auto=True, bounds_delta=10.0, silent=True,
+                          info=False, method="SLSQP", method_options=None):
+    """gpmp/kernel/parameter_selection.py:128-276 (same options, bounds, history and best-seen rule)."""
+    if method_options is None:
+        method_options = {}
+    tic = time.time()
+    p0 = np.asarray(gnp.to_np(p0), dtype=np.float64).reshape(-1)
+    safe_lower, safe_upper = -500, 500
+    if bounds is None and bounds_auto:
+        bounds = [(max(p - bounds_delta, safe_lower), min(p + bounds_delta, safe_upper)) for p in p0]
+
+    history_params, history_criterion = [], []
+    best = {"p": None, "J": float("inf")}
+
+    def criterion_with_history(p):
+        try:
+            J = float(criterion(p))
+        except Exception as exc:  # linear-algebra failure -> +inf (parameter_selection.py:222-231)
+            if gnp._is_linalg_exception(exc):
+                J = np.inf
+            else:
+                raise
+        history_params.append(p.copy())
+        history_criterion.append(J)
+        if J < best["J"]:
+            best["J"], best["p"] = J, p.copy()
+        return J
+
+    options = {"disp": not silent}
+    if method == "L-BFGS-B":
+        options.update(dict(maxcor=20, ftol=1e-6, gtol=1e-5, eps=1e-8, maxfun=15000, maxiter=15000, maxls=40))
+    elif method == "SLSQP":
+        options.update(dict(ftol=1e-6, eps=1e-8, maxiter=15000))
+    else:
+        raise ValueError("Optimization method not implemented.")
+    options.update(method_options)
+    if method == "L-BFGS-B":
+        options.pop("disp", None)
+
+    r = minimize(criterion_with_history, p0, method=method, jac=gradient, bounds=bounds, options=options)
+    if best["p"] is not None and r.fun > best["J"]:
+        r.x, r.fun, r.best_value_returned = best["p"], best["J"], False
+    else:
+        r.best_value_returned = True
+    r.history_params, r.history_criterion = history_params, history_criterion
+    r.initial_params, r.final_params, r.bounds = p0, r.x, bounds
+    r.selection_criterion = criterion
+    r.total_time = time.time() - tic
+    return (r.x, r) if info else (r.x, None)
+
+
+def select_parameters_with_criterion(model, criterion, xi=None, zi=None, dataloader=None, meanparam0=None,
+                                     covparam0=None, parameterized_mean=False, meanparam_len=1, info=False,
+                                     verbosity=0, *, bounds=None, bounds_auto=True, bounds_delta=10.0,
+                                     batches_per_eval=0, method="SLSQP", method_options=None):
+    """gpmp/kernel/parameter_selection.py:280-437."""
+    tic = time.time()
+    if covparam0 is None:
+        covparam0 = anisotropic_parameters_initial_guess(model, xi, zi, dataloader)
+    covparam0 = np.asarray(gnp.to_np(covparam0), dtype=np.float64)
+    if parameterized_mean:
+        if meanparam0 is None:
+            raise ValueError("meanparam0 must be provided when parameterized_mean=True.")
+        param0 = np.concatenate([np.asarray(gnp.to_np(meanparam0), dtype=np.float64), covparam0])
+    else:
+        param0 = covparam0
+    crit, crit_pre_grad, crit_no_grad, crit_grad = make_selection_criterion_with_gradient(
+        model, criterion, xi, zi, dataloader, batches_per_eval=batches_per_eval,
+        parameterized_mean=parameterized_mean, meanparam_len=meanparam_len)
+    if verbosity == 1:
+        print("Parameter selection using custom criterion...")
+    param_opt, info_ret = autoselect_parameters(param0, crit_pre_grad, crit_grad, bounds=bounds, bounds_auto=bounds_auto,
+                                                bounds_delta=bounds_delta, silent=not (verbosity == 2), info=True,
+                                                method=method, method_options=method_options)
+    if verbosity == 1:
+        print("done.")
+    if parameterized_mean:
+        meanparam_opt, covparam_opt = param_opt[:meanparam_len], param_opt[meanparam_len:]
+        model.meanparam = np.asarray(meanparam_opt)
+    else:
+        meanparam_opt, covparam_opt = None, param_opt
+    model.covparam = np.asarray(covparam_opt)
+    if info:
+        info_ret["meanparam0"] = meanparam0 if parameterized_mean else None
+        info_ret["covparam0"] = covparam0
+        info_ret["meanparam"] = meanparam_opt
+        info_ret["covparam"] = covparam_opt
+        info_ret["selection_criterion"] = crit
+        info_ret["selection_criterion_nograd"] = crit_no_grad
+        info_ret["time"] = time.time() - tic
+        return model, info_ret
+    return model, None
+
+
+def select_parameters_with_reml(model, xi=None, zi=None, dataloader=None, covparam0=None, info=False, verbosity=0, *,
+                                bounds=None, bounds_auto=True, bounds_delta=10.0, method="SLSQP", method_options=None):
+    """gpmp/kernel/parameter_selection.py:747-808."""
+    return select_parameters_with_criterion(model, negative_log_restricted_likelihood, xi=xi, zi=zi, dataloader=dataloader,
+                                            covparam0=covparam0, info=info, verbosity=verbosity, bounds=bounds,
+                                            bounds_auto=bounds_auto, bounds_delta=bounds_delta, method=method,
+                                            method_options=method_options)

@@ -1,0 +1,137 @@
+/* gpmp_hip.h -- C ABI of libgpmp_hip.so, the MI355X (gfx950) exact-GP inner loop.
+ *
+ * Drop-in boundary for GPmp's numerical backend contract (gpmp/num/__init__.py:25-46): every entry
+ * point below replaces the arithmetic one `gnp.*` call (or one fused run of them) performs on the
+ * hot path.  The host side (Python: gpmp_amd/, ctypes) keeps GPmp's names and semantics.
+ *
+ * Conventions
+ *  - All matrices are fp64, ROW-MAJOR, in device memory (HBM), described by (pointer, rows, cols, ld)
+ *    with ld = leading dimension in elements (ld >= cols).  Fast paths need 16-byte aligned base
+ *    pointers and even ld; anything else is still correct (checked/scalar loads).
+ *  - Small parameter vectors (theta, mean parameters) are HOST pointers: they come from SciPy on the
+ *    host (gpmp/kernel/parameter_selection.py:253-260) and are passed by value to the kernels.
+ *  - Every function returns 0 on success, <0 for a bad argument (-k = k-th argument), or a LAPACK
+ *    style info > 0 where stated.  No entry point synchronises: every function only enqueues work
+ *    on `stream` (a hipStream_t passed as void*; NULL = the default stream); scalar results
+ *    (info, log-det, gradient) land in caller-provided DEVICE words.
+ *  - The library owns no device memory: callers (the torch allocator) own every buffer including
+ *    workspaces, whose sizes come from the gpmp_*_ws_* queries.
+ *  - covparam layout (gpmp/kernel/matern.py:78-79,88-89): theta = [log sigma^2, log(1/rho_1..d)];
+ *    with `noise` != 0 the layout is [log sigma^2, log sigma_noise^2, log(1/rho_1..d)]
+ *    (examples/gpmp_example07_nd_regression.py:95-131).
+ */
+#ifndef GPMP_HIP_H
+#define GPMP_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gpmp_stream_t;
+
+#define GPMP_NB 128          /* diagonal block size of the blocked factorisation */
+#define GPMP_MAX_DIM 64      /* largest input dimension d handled by the Gram kernels */
+#define GPMP_MAX_P 16        /* largest Matern half-integer index p (nu = p + 1/2) */
+#define GPMP_MAX_RANK 72     /* largest low-rank correction width in gpmp_matern_grad_trace */
+
+int gpmp_hip_abi_version(void);
+/* Last error text of the calling thread (HIP error string or argument message). */
+const char* gpmp_last_error(void);
+
+/* ---- Matern kernels ------------------------------------------------------------------------ */
+
+/* K[i,j] = sigma2 * Matern_p( || invrho * (x_i - y_j) || )  (+ diag_add on i == j when y == NULL).
+ * Replaces gnp.scaled_distance + maternp_kernel + "+ nugget*eye" (gpmp/num/numpy_backend.py:432-436,
+ * gpmp/kernel/matern.py:32-64,88-94,114-121) in one pass; the distance matrix is never stored.
+ * y == NULL selects the ii/tt path (matern.py:139-141): nugget 10*sigma2*eps (or the noise variance)
+ * is passed by the caller as diag_add.  lower_only != 0 (ii path only) writes tiles on/below the
+ * diagonal only (enough for gpmp_potrf_lower_async). */
+int gpmp_matern_gram(const double* x, const double* y, int n, int m, int d, int p,
+                     const double* theta_host, int noise, double diag_add, int lower_only,
+                     double* K, long ldk, gpmp_stream_t stream);
+
+/* out[i] = sigma2 * Matern_p(|| invrho * (x_i - y_i) ||)  -- the pairwise=True path
+ * (matern.py:114-121; gnp.scaled_distance_elementwise numpy_backend.py:438-446). */
+int gpmp_matern_pairwise(const double* x, const double* y, int n, int d, int p,
+                         const double* theta_host, int noise, double* out, gpmp_stream_t stream);
+
+/* D[i,j] = || invrho * (x_i - y_j) ||  -- gnp.scaled_distance (numpy_backend.py:432-436). */
+int gpmp_scaled_distance(const double* x, const double* y, int n, int m, int d,
+                         const double* loginvrho_host, double* D, long ldd, gpmp_stream_t stream);
+
+/* Matern_p(h) elementwise on a device vector -- maternp_kernel (matern.py:32-64). */
+int gpmp_maternp_kernel(const double* h, long count, int p, double* out, gpmp_stream_t stream);
+
+/* ---- Cholesky and triangular solves ---------------------------------------------------------- */
+
+/* Number of doubles of the diagonal-block-inverse workspace for an n x n factorisation. */
+size_t gpmp_dinv_elems(int n);
+
+/* In-place lower Cholesky A = L L^T (replaces numpy.linalg.cholesky, numpy_backend.py:466).
+ * Only the lower triangle of A is read; the strict upper triangle is left unspecified (use
+ * gpmp_tril to zero it).  dinv receives inv(L_kk) for every GPMP_NB diagonal block (used by the
+ * solves below).  *info_dev (a DEVICE int, written asynchronously): 0, or k > 0 if the leading
+ * minor of order k is not positive definite (reference: numpy.linalg.LinAlgError, see
+ * gpmp/num/numpy_backend.py:30-46,158-162); the factor is then unspecified.  Enqueue only. */
+int gpmp_potrf_lower_async(double* A, int n, long lda, double* dinv, int* info_dev, gpmp_stream_t stream);
+
+/* B <- op(L)^-1 B for an n x m row-major B; trans = 0: L, 1: L^T.  Replaces
+ * scipy.linalg.solve_triangular (numpy_backend.py:467-468, gpmp/core/linalg.py:41).  If
+ * dinv == NULL the diagonal-block inverses are recomputed into `scratch` (gpmp_dinv_elems(n)). */
+int gpmp_trsm_lower(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb,
+                    int trans, double* scratch, gpmp_stream_t stream);
+
+/* inv(L_kk) for every diagonal block of a given lower-triangular L (no factorisation). */
+int gpmp_trtri_diag_blocks(const double* L, int n, long ldl, double* dinv, gpmp_stream_t stream);
+
+/* T <- L^-1 (lower triangular, n x n, ldt); strict upper triangle of T is zeroed.
+ * (diag_Kinv_from_chol forms this with solve_triangular(C, eye(n)), gpmp/core/linalg.py:39-41.) */
+int gpmp_trtri_lower(const double* L, int n, long ldl, const double* dinv, double* T, long ldt,
+                     gpmp_stream_t stream);
+
+/* Kinv(lower) <- T^T T for lower-triangular T = L^-1 (n x n).  Only tiles on/below the diagonal of
+ * Kinv are written. */
+int gpmp_lauum_lower(const double* T, int n, long ldt, double* Kinv, long ldk, gpmp_stream_t stream);
+
+/* Zero the strict upper triangle of an n x n matrix. */
+int gpmp_tril(double* A, int n, long lda, gpmp_stream_t stream);
+/* Mirror the lower triangle into the upper one. */
+int gpmp_symmetrize_from_lower(double* A, int n, long lda, gpmp_stream_t stream);
+
+/* C = alpha * op(A) op(B) + beta * C on the fp64 MFMA GEMM used by all the blocked routines
+ * (exported for tests).  ta/tb: 0 = as stored, 1 = transposed; all row-major. */
+int gpmp_dgemm(int ta, int tb, int M, int N, int K, double alpha, const double* A, long lda,
+               const double* B, long ldb, double beta, double* C, long ldc, int lower_only,
+               gpmp_stream_t stream);
+
+/* ---- reductions ------------------------------------------------------------------------------ */
+
+/* out[k*ldo + j] = sum_i V[i,j] * Y[i,k]  (k < r),   out[r*ldo + j] = sum_i V[i,j]^2.
+ * V is n x m (ldv), Y is n x r (ldy, r <= GPMP_MAX_RANK).  Replaces the einsum("i..., i...") column
+ * dots of gpmp/core/kriging.py:194 and gpmp/core/model.py:298-300, and the column sum-of-squares
+ * of gpmp/core/linalg.py:44.  ws: m * gpmp_coldots_ws_rows(n) doubles. */
+int gpmp_coldots(const double* V, int n, int m, long ldv, const double* Y, int r, long ldy,
+                 double* out, long ldo, double* ws, gpmp_stream_t stream);
+int gpmp_coldots_ws_rows(int n);
+
+/* *out_dev (device double) = 2 * sum_i log(L[i,i])  (gpmp/core/likelihood.py:50).  Enqueue only. */
+int gpmp_logdet_chol(const double* L, int n, long ldl, double* out_dev, gpmp_stream_t stream);
+
+/* ---- analytic gradient of the Matern covariance ---------------------------------------------- */
+
+/* g_dev[j] (device vector) = sum_{i,k} M[i,k] * dK[i,k]/dtheta_j, j < 1 + noise + d, with
+ *   M[i,k] = Kinv[i,k] - sum_{a<r} F[i,a] * G[k,a]     (Kinv: lower triangle used, symmetric)
+ * and K the covariance of gpmp_matern_gram (ii path, diag_add = nugget or noise).  The reference has
+ * no analytic form (torch autograd, gpmp/num/torch_backend.py:574-604); formulas in DESIGN.md.
+ * ws: gpmp_grad_ws_elems(n, d) doubles.  Enqueue only. */
+int gpmp_matern_grad_trace(const double* Kinv, long ldk, const double* x, int n, int d, int p,
+                           const double* theta_host, int noise, const double* F, const double* G,
+                           int r, long ldf, double* g_dev, double* ws, gpmp_stream_t stream);
+size_t gpmp_grad_ws_elems(int n, int d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPMP_HIP_H */

@@ -1,0 +1,427 @@
+"""GPU parity tests: the HIP path (through the C ABI) against (i) the golden vectors produced by the
+reference and (ii) the CPU oracle on seeded inputs.  fp64 tolerances, conditioning-aware
+(SURVEY.md section 8c): Gram entries rel 1e-14; NLL / REML rel 1e-10; posterior mean abs
+1e-9 |z|_inf; posterior variance abs 1e-9 sigma^2; gradients rel 1e-7 (vs the reference autograd).
+"""
+import math
+import warnings
+
+import numpy as np
+import pytest
+
+from tests.helpers import constant_mean as np_constant_mean
+from tests.helpers import linear_mean as np_linear_mean
+from tests.helpers import make_xz, rel_err, theta_aniso
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gpmp_amd
+
+    return gpmp_amd
+
+
+@pytest.fixture(scope="module")
+def gnp(gp):
+    import gpmp_amd.num as gnp
+
+    return gnp
+
+
+def constant_mean(x, param):
+    import gpmp_amd.num as gnp
+
+    return gnp.ones((x.shape[0], 1))
+
+
+def linear_mean(x, param):
+    import gpmp_amd.num as gnp
+
+    return gnp.hstack((gnp.ones((x.shape[0], 1)), gnp.asarray(x)))
+
+
+def param_mean(x, param):
+    return (param[0] + param[1] * x[:, 0]).reshape(-1, 1)
+
+
+# ------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 384, 64), (130, 70, 33), (1, 5, 3), (257, 129, 130), (64, 1, 200)])
+def test_dgemm_matches_numpy(gnp, ta, tb, M, N, K):
+    import torch
+    from gpmp_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(M * 1000 + N * 10 + K)
+    A = rng.standard_normal((K, M) if ta else (M, K))
+    B = rng.standard_normal((N, K) if tb else (K, N))
+    C0 = rng.standard_normal((M, N))
+    At, Bt = gnp.as_matrix(gnp.asarray(A), copy=True), gnp.as_matrix(gnp.asarray(B), copy=True)
+    Ct = gnp.as_matrix(gnp.asarray(C0), copy=True)
+    _lib.check(lib.gpmp_dgemm(ta, tb, M, N, K, -0.5, gnp._ptr(At), gnp._ld(At), gnp._ptr(Bt), gnp._ld(Bt), 2.0, gnp._ptr(Ct),
+                              gnp._ld(Ct), 0, gnp._stream()), "gpmp_dgemm")
+    ref = -0.5 * (A.T if ta else A) @ (B.T if tb else B) + 2.0 * C0
+    torch.cuda.synchronize()
+    assert rel_err(gnp.to_np(Ct), ref) < 1e-13
+
+
+def test_dgemm_unaligned_operands(gnp):
+    """odd leading dimensions / unaligned pointers take the checked scalar path"""
+    import torch
+    from gpmp_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    M, N, K = 150, 131, 77
+    A, B = rng.standard_normal((M, K)), rng.standard_normal((K, N))
+    At = torch.as_tensor(A, device=gnp._dev()).contiguous()   # ld = 77 (odd)
+    Bt = torch.as_tensor(B, device=gnp._dev()).contiguous()   # ld = 131 (odd)
+    Ct = torch.zeros((M, N), dtype=torch.float64, device=gnp._dev())
+    _lib.check(lib.gpmp_dgemm(0, 0, M, N, K, 1.0, gnp._ptr(At), K, gnp._ptr(Bt), N, 0.0, gnp._ptr(Ct), N, 0, gnp._stream()), "gpmp_dgemm")
+    assert rel_err(gnp.to_np(Ct), A @ B) < 1e-13
+
+
+def test_dgemm_lower_only_skips_upper_tiles(gnp):
+    from gpmp_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    M, K = 512, 96
+    A = rng.standard_normal((M, K))
+    C0 = rng.standard_normal((M, M))
+    At, Ct = gnp.as_matrix(gnp.asarray(A), copy=True), gnp.as_matrix(gnp.asarray(C0), copy=True)
+    _lib.check(lib.gpmp_dgemm(0, 1, M, M, K, -1.0, gnp._ptr(At), gnp._ld(At), gnp._ptr(At), gnp._ld(At), 1.0, gnp._ptr(Ct), gnp._ld(Ct), 1,
+                              gnp._stream()), "gpmp_dgemm")
+    got, ref = gnp.to_np(Ct), C0 - A @ A.T
+    tile = np.add.outer(np.arange(M) // 128, -(np.arange(M) // 128))  # tile_row - tile_col
+    assert rel_err(got[tile >= 0], ref[tile >= 0]) < 1e-13
+    assert np.array_equal(got[tile < 0], C0[tile < 0])  # untouched
+
+
+# ------------------------------------------------------------------------------ Matern / Gram
+def test_matern_kernel_grid(gp, gnp, golden):
+    g = golden("matern")
+    h = g["matern_h"]
+    finite = np.isfinite(h)
+    for p in (0, 1, 2, 3, 6, 10):
+        k = gnp.to_np(gp.kernel.maternp_kernel(p, h[finite]))
+        ref = g[f"matern_k_p{p}"][finite]
+        np.testing.assert_allclose(k, ref, rtol=2e-14, atol=1e-300)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_covariance_vs_reference(gp, gnp, golden, tag):
+    g = golden("matern")
+    x, y, th, p = g[f"cov_{tag}_x"], g[f"cov_{tag}_y"], g[f"cov_{tag}_theta"], int(g[f"cov_{tag}_p"])
+    xt, yt = gnp.asarray(x), gnp.asarray(y)
+    mc = gp.kernel.maternp_covariance
+    np.testing.assert_allclose(gnp.to_np(gnp.scaled_distance(th[1:], xt, yt)), g[f"dist_{tag}"], rtol=1e-14, atol=1e-16)
+    np.testing.assert_allclose(gnp.to_np(mc(xt, xt, p, th)), g[f"cov_{tag}_ii"], rtol=1e-14)
+    np.testing.assert_allclose(gnp.to_np(mc(xt, None, p, th)), g[f"cov_{tag}_ii"], rtol=1e-14)
+    np.testing.assert_allclose(gnp.to_np(mc(xt, yt, p, th)), g[f"cov_{tag}_it"], rtol=1e-14)
+    np.testing.assert_allclose(gnp.to_np(mc(xt, None, p, th, True)), g[f"cov_{tag}_ii_pw"], rtol=1e-15)
+    k = min(len(x), len(y))
+    np.testing.assert_allclose(gnp.to_np(mc(xt[:k], yt[:k], p, th, True)), g[f"cov_{tag}_it_pw"], rtol=1e-14)
+    # equal but not identical -> "it" path without nugget (matern.py:139-141)
+    np.testing.assert_allclose(gnp.to_np(mc(xt, xt.clone(), p, th)), g[f"cov_{tag}_copy"], rtol=1e-14)
+
+
+def test_gram_lower_only_and_noise(gp, gnp):
+    from oracle import gp_oracle as orc
+
+    x, _ = make_xz(333, 5, 3)
+    th = np.concatenate(([0.3, math.log(1e-2)], theta_aniso(5)[1:]))
+    cov = gp.kernel.MaternCovariance(2, noise=True)
+    K = gnp.to_np(cov(gnp.asarray(x), None, th))
+    ref = orc.noisy_maternp_covariance(x, None, 2, th)
+    np.testing.assert_allclose(K, ref, rtol=1e-14)
+    Kl = gnp.to_np(cov.gram_lower(gnp.asarray(x), th))
+    tile = np.add.outer(np.arange(333) // 64, -(np.arange(333) // 64))
+    np.testing.assert_allclose(Kl[tile >= 0], ref[tile >= 0], rtol=1e-14)
+
+
+# ------------------------------------------------------------------------------ Cholesky / solves
+@pytest.mark.parametrize("n", [1, 6, 64, 127, 128, 129, 300, 512, 640, 1000, 1537])
+def test_cholesky_and_solves_vs_lapack(gp, gnp, n):
+    import scipy.linalg as sla
+
+    x, z = make_xz(n, 3, n)
+    th = theta_aniso(3, scale=0.4)
+    from oracle import gp_oracle as orc
+
+    K = orc.maternp_covariance(x, None, 2, th) + 1e-6 * np.eye(n)
+    L = gnp.to_np(gnp.cholesky(gnp.asarray(K)))
+    Lref = np.linalg.cholesky(K)
+    assert np.all(np.triu(L, 1) == 0.0)
+    assert rel_err(L, Lref) < 1e-10
+    assert rel_err(L @ L.T, K) < 1e-14
+    B = np.random.default_rng(n).standard_normal((n, 37))
+    xs, Lt = gnp.cholesky_solve(gnp.asarray(K), gnp.asarray(B))
+    assert rel_err(gnp.to_np(xs), np.linalg.solve(K, B)) < 1e-8
+    xv, _ = gnp.cholesky_solve(gnp.asarray(K), gnp.asarray(z))
+    assert xv.shape == (n,)
+    assert rel_err(gnp.to_np(xv), np.linalg.solve(K, z)) < 1e-8
+    y = gnp.solve_triangular(Lt, gnp.asarray(B), lower=True)
+    assert rel_err(gnp.to_np(y), sla.solve_triangular(Lref, B, lower=True)) < 1e-9
+    y2 = gnp.solve_triangular(Lt.T, gnp.asarray(B), lower=False)
+    assert rel_err(gnp.to_np(y2), sla.solve_triangular(Lref.T, B, lower=False)) < 1e-9
+    Ki = gnp.to_np(gnp.cholesky_inv(gnp.asarray(K)))
+    assert rel_err(Ki, np.linalg.inv(K)) < 1e-7
+    F = gnp.cholesky_factor(gnp.asarray(K))
+    assert abs(F.logdet() - np.linalg.slogdet(K)[1]) < 1e-9 * max(1.0, abs(np.linalg.slogdet(K)[1]))
+
+
+def test_cholesky_not_positive_definite_raises_linalgerror(gp, gnp, golden):
+    g = golden("likelihood")
+    from oracle import gp_oracle as orc
+
+    K = orc.maternp_covariance(g["lik_bad_xi"], None, 2, g["lik_bad_theta"])
+    with pytest.raises(np.linalg.LinAlgError) as ei:
+        gnp.cholesky(gnp.asarray(K))
+    assert gnp._is_linalg_exception(ei.value) and "not positive definite" in str(ei.value)
+    A = np.eye(200)
+    A[150, 150] = -1.0
+    with pytest.raises(np.linalg.LinAlgError) as ei:
+        gnp.cholesky(gnp.asarray(A))
+    assert "151" in str(ei.value)
+
+
+# ------------------------------------------------------------------------------ predict / loo vs reference
+def _models(gp, p, th, mp):
+    k = gp.kernel.MaternCovariance(p)
+    return {
+        "zero": gp.Model(None, k, None, th, "zero"),
+        "const": gp.Model(constant_mean, k, None, th, "linear_predictor"),
+        "lin": gp.Model(linear_mean, k, None, th, "linear_predictor"),
+        "param": gp.Model(param_mean, k, mp, th, "parameterized"),
+    }
+
+
+@pytest.mark.parametrize("tag", ["s", "m", "p3"])
+def test_predict_and_loo_vs_reference(gp, gnp, golden, tag):
+    g = golden("predict")
+    xi, zi, xt = g[f"pred_{tag}_xi"], g[f"pred_{tag}_zi"], g[f"pred_{tag}_xt"]
+    th, p, mp = g[f"pred_{tag}_theta"], int(g[f"pred_{tag}_p"]), g[f"pred_{tag}_meanparam"]
+    zs = np.max(np.abs(zi))
+    s2 = math.exp(th[0])
+    for mt, model in _models(gp, p, th, mp).items():
+        zpm, zpv, lam = model.predict(xi, zi, xt, return_lambdas=True)
+        assert isinstance(zpm, np.ndarray) and zpm.shape == (len(xt),)
+        assert np.max(np.abs(zpm - g[f"pred_{tag}_{mt}_zpm"])) < 1e-9 * zs, mt
+        assert np.max(np.abs(zpv - g[f"pred_{tag}_{mt}_zpv"])) < 1e-9 * s2, mt
+        assert rel_err(gnp.to_np(lam), g[f"pred_{tag}_{mt}_lambda"]) < 1e-7, mt
+        zpm2, zpv2 = model.predict(xi, zi, xt)   # the one-solve route (no lambda)
+        assert np.max(np.abs(zpm2 - zpm)) < 1e-10 * zs and np.max(np.abs(zpv2 - zpv)) < 1e-10 * s2
+        zl, sl, el = model.loo(xi, zi)
+        assert rel_err(gnp.to_np(zl), g[f"loo_{tag}_{mt}_zloo"]) < 1e-8, mt
+        assert rel_err(gnp.to_np(sl), g[f"loo_{tag}_{mt}_s2"]) < 1e-8, mt
+        assert rel_err(gnp.to_np(el), g[f"loo_{tag}_{mt}_eloo"]) < 1e-8, mt
+    m0 = _models(gp, p, th, mp)["zero"]
+    lam, cov = m0.kriging_predictor_with_zero_mean(gnp.asarray(xi), gnp.asarray(xt), return_type=1)
+    assert np.max(np.abs(gnp.to_np(cov) - g[f"pred_{tag}_zero_fullcov"])) < 1e-9 * s2
+    zpm, _ = m0.predict(xi, zi.reshape(-1, 1), xt)
+    assert np.max(np.abs(zpm - g[f"pred_{tag}_zero_zpm_col"])) < 1e-9 * zs
+
+
+def test_predict_generic_callable_covariance(gp, gnp, golden):
+    """a plain python closure around maternp_covariance (as every reference example writes it)"""
+    g = golden("predict")
+    xi, zi, xt, th = g["pred_s_xi"], g["pred_s_zi"], g["pred_s_xt"], g["pred_s_theta"]
+
+    def kernel(x, y, covparam, pairwise=False):
+        return gp.kernel.maternp_covariance(x, y, 2, covparam, pairwise)
+
+    model = gp.Model(constant_mean, kernel, None, th)
+    zpm, zpv = model.predict(xi, zi, xt)
+    assert np.max(np.abs(zpm - g["pred_s_const_zpm"])) < 1e-9 * np.max(np.abs(zi))
+    assert np.max(np.abs(zpv - g["pred_s_const_zpv"])) < 1e-9
+
+
+def test_predict_duplicates_clamp_and_warning(gp, gnp, golden):
+    g = golden("predict")
+    xi, zi, xt, th = g["pred_dup_xi"], g["pred_dup_zi"], g["pred_dup_xt"], g["pred_dup_theta"]
+    model = gp.Model(None, gp.kernel.MaternCovariance(2), None, th, "zero")
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        zpm, zpv = model.predict(xi, zi, xt)
+        _, zpv_raw = model.predict(xi, zi, xt, zero_neg_variances=False)
+    assert np.all(zpv >= 0.0)
+    assert np.all(zpv == np.maximum(zpv_raw, 0.0))
+    assert np.max(np.abs(zpv - g["pred_dup_zpv"])) < 1e-6      # cond ~ 1 / nugget: agreement to cond * eps
+    assert rel_err(zpm, g["pred_dup_zpm"]) < 1e-5
+
+
+def test_predict_chunked_equals_unchunked(gp, gnp):
+    from gpmp_amd.config import get_config
+
+    xi, zi = make_xz(500, 4, 77)
+    xt, _ = make_xz(1300, 4, 78)
+    th = theta_aniso(4)
+    model = gp.Model(constant_mean, gp.kernel.MaternCovariance(2), None, th)
+    cfg = get_config()
+    old = cfg.predict_chunk_bytes
+    try:
+        a = model.predict(xi, zi, xt, return_lambdas=True)
+        cfg.predict_chunk_bytes = 8 * 500 * 256  # -> chunks of 256 columns
+        b = model.predict(xi, zi, xt, return_lambdas=True)
+    finally:
+        cfg.predict_chunk_bytes = old
+    assert np.array_equal(a[0], b[0]) or np.max(np.abs(a[0] - b[0])) < 1e-12
+    assert np.max(np.abs(a[1] - b[1])) < 1e-12
+    assert rel_err(gnp.to_np(b[2]), gnp.to_np(a[2])) < 1e-12
+
+
+def test_empty_prediction_set(gp, gnp):
+    xi, zi = make_xz(50, 2, 1)
+    model = gp.Model(None, gp.kernel.MaternCovariance(2), None, theta_aniso(2), "zero")
+    zpm, zpv = model.predict(xi, zi, np.zeros((0, 2)))
+    assert zpm.shape == (0,) and zpv.shape == (0,)
+
+
+# ------------------------------------------------------------------------------ likelihoods
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_likelihoods_vs_reference(gp, gnp, golden, tag):
+    g = golden("likelihood")
+    xi, zi, p = g[f"lik_{tag}_xi"], g[f"lik_{tag}_zi"], int(g[f"lik_{tag}_p"])
+    k = gp.kernel.MaternCovariance(p)
+    mz = gp.Model(None, k, None, None, "zero")
+    mc = gp.Model(constant_mean, k, None, None, "linear_predictor")
+    ml = gp.Model(linear_mean, k, None, None, "linear_predictor")
+    mpm = gp.Model(param_mean, k, np.array([0.2, 0.5]), None, "parameterized")
+    xit, zit = gnp.asarray(xi), gnp.asarray(zi)
+    for i, t in enumerate(g[f"lik_{tag}_thetas"]):
+        def close(a, b):
+            return abs(float(a) - float(b)) < 1e-10 * max(1.0, abs(float(b)))
+        assert close(mz.negative_log_likelihood_zero_mean(t, xit, zit), g[f"lik_{tag}_nll"][i])
+        assert close(mpm.negative_log_likelihood(np.array([0.2, 0.5]), t, xit, zit), g[f"lik_{tag}_nll_param"][i])
+        assert close(mc.negative_log_restricted_likelihood(t, xit, zit), g[f"lik_{tag}_reml_const"][i])
+        assert close(ml.negative_log_restricted_likelihood(t, xit, zit), g[f"lik_{tag}_reml_lin"][i])
+        assert close(mz.norm_k_sqrd_with_zero_mean(xit, zit, t), g[f"lik_{tag}_normk0"][i])
+        assert close(mc.norm_k_sqrd(xit, zit, t), g[f"lik_{tag}_normk_const"][i])
+    a, b, c = mz.k_inverses(xit, zit, g[f"lik_{tag}_thetas"][0])
+    assert rel_err(gnp.to_np(a), g[f"lik_{tag}_kinv_ztKz"]) < 1e-9
+    assert rel_err(gnp.to_np(b), g[f"lik_{tag}_kinv_1"]) < 1e-7 and rel_err(gnp.to_np(c), g[f"lik_{tag}_kinv_z"]) < 1e-7
+    np.testing.assert_allclose(gp.kernel.anisotropic_parameters_initial_guess(mc, xit, zit), g[f"lik_{tag}_init_const"], rtol=1e-9)
+    np.testing.assert_allclose(gp.kernel.anisotropic_parameters_initial_guess_zero_mean(mz, xit, zit), g[f"lik_{tag}_init_zero"], rtol=1e-9)
+
+
+def test_non_pd_criterion_is_inf(gp, gnp, golden):
+    g = golden("likelihood")
+    mz = gp.Model(None, gp.kernel.MaternCovariance(2), None, None, "zero")
+    with pytest.raises(np.linalg.LinAlgError):
+        mz.negative_log_likelihood_zero_mean(g["lik_bad_theta"], g["lik_bad_xi"], g["lik_bad_zi"])
+    _, pre, nograd, grad = gp.kernel.make_selection_criterion_with_gradient(
+        mz, gp.kernel.negative_log_likelihood_zero_mean, g["lik_bad_xi"], g["lik_bad_zi"])
+    assert math.isinf(pre(g["lik_bad_theta"])) and math.isinf(nograd(g["lik_bad_theta"]))
+    assert np.all(grad(g["lik_bad_theta"]) == 0.0)
+
+
+# ------------------------------------------------------------------------------ gradients
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
+def test_gradients_vs_reference_autograd(gp, gnp, golden, tag):
+    g = golden("gradients")
+    xi, zi, p = g[f"grad_{tag}_xi"], g[f"grad_{tag}_zi"], int(g[f"grad_{tag}_p"])
+    k = gp.kernel.MaternCovariance(p)
+    cases = (
+        ("nll", gp.Model(None, k, None, None, "zero"), gp.kernel.negative_log_likelihood_zero_mean),
+        ("reml_const", gp.Model(constant_mean, k, None, None), gp.kernel.negative_log_restricted_likelihood),
+        ("reml_lin", gp.Model(linear_mean, k, None, None), gp.kernel.negative_log_restricted_likelihood),
+    )
+    for name, model, crit in cases:
+        _, pre, _, grad = gp.kernel.make_selection_criterion_with_gradient(model, crit, xi, zi)
+        assert grad is not None
+        for i, t in enumerate(g[f"grad_{tag}_thetas"]):
+            v = pre(t)
+            gr = grad(t)
+            assert abs(v - g[f"grad_{tag}_{name}_val"][i]) < 1e-9 * abs(v), (name, i)
+            assert rel_err(gr, g[f"grad_{tag}_{name}_grad"][i]) < 1e-7, (name, i)
+
+
+@pytest.mark.parametrize("tag", ["na", "nb"])
+def test_gradients_noisy_kernel(gp, gnp, golden, tag):
+    g = golden("gradients")
+    xi, zi, p = g[f"grad_{tag}_xi"], g[f"grad_{tag}_zi"], int(g[f"grad_{tag}_p"])
+    k = gp.kernel.MaternCovariance(p, noise=True)
+    cases = (
+        ("nll", gp.Model(None, k, None, None, "zero"), gp.kernel.negative_log_likelihood_zero_mean),
+        ("reml_const", gp.Model(constant_mean, k, None, None), gp.kernel.negative_log_restricted_likelihood),
+    )
+    for name, model, crit in cases:
+        _, pre, _, grad = gp.kernel.make_selection_criterion_with_gradient(model, crit, xi, zi)
+        for i, t in enumerate(g[f"grad_{tag}_thetas"]):
+            v, gr = pre(t), grad(t)
+            assert abs(v - g[f"grad_{tag}_{name}_val"][i]) < 1e-9 * abs(v)
+            assert rel_err(gr, g[f"grad_{tag}_{name}_grad"][i]) < 1e-7
+
+
+def test_generic_callable_has_no_analytic_gradient(gp, gnp):
+    def kernel(x, y, covparam, pairwise=False):
+        return gp.kernel.maternp_covariance(x, y, 2, covparam, pairwise)
+
+    model = gp.Model(constant_mean, kernel)
+    xi, zi = make_xz(40, 2, 5)
+    _, pre, _, grad = gp.kernel.make_selection_criterion_with_gradient(model, gp.kernel.negative_log_restricted_likelihood, xi, zi)
+    assert grad is None and math.isfinite(pre(theta_aniso(2)))   # numpy-backend behaviour: SciPy differentiates
+
+
+# ------------------------------------------------------------------------------ config 1: example02
+def test_example02_flow(gp, gnp, golden):
+    """examples/gpmp_example02_1d_interpolation.py: n = 6, Matern p = 3, constant mean, REML by SLSQP."""
+    g = golden("example02")
+    xi, zi, xt = g["ex02_xi"], g["ex02_zi"], g["ex02_xt"]
+
+    def kernel(x, y, covparam, pairwise=False):   # generic closure -> finite-difference jac, like the NumPy backend
+        return gp.kernel.maternp_covariance(x, y, 3, covparam, pairwise)
+
+    model = gp.Model(constant_mean, kernel)
+    c0 = gp.kernel.anisotropic_parameters_initial_guess(model, xi, zi)
+    np.testing.assert_allclose(c0, g["ex02_covparam0"], rtol=1e-9)
+    assert abs(float(model.negative_log_restricted_likelihood(c0, xi, zi.reshape(-1))) - float(g["ex02_reml0"])) < 1e-9
+    model, info = gp.kernel.select_parameters_with_reml(model, xi, zi, info=True)
+    reml_opt = float(model.negative_log_restricted_likelihood(model.covparam, xi, zi.reshape(-1)))
+    # optimiser path only has to agree to the optimiser tolerance (ftol 1e-6)
+    assert abs(reml_opt - float(g["ex02_reml_opt"])) < 1e-5
+    np.testing.assert_allclose(model.covparam, g["ex02_covparam"], atol=5e-3)
+    model.covparam = g["ex02_covparam"]          # same parameters -> same prediction
+    zpm, zpv = model.predict(xi, zi, xt)
+    assert np.max(np.abs(zpm - g["ex02_zpm"])) < 1e-8 and np.max(np.abs(zpv - g["ex02_zpv"])) < 1e-8
+    # analytic-gradient route reaches the same optimum
+    model2 = gp.Model(constant_mean, gp.kernel.MaternCovariance(3))
+    model2, _ = gp.kernel.select_parameters_with_reml(model2, xi, zi)
+    assert abs(float(model2.negative_log_restricted_likelihood(model2.covparam, xi, zi.reshape(-1))) - float(g["ex02_reml_opt"])) < 1e-5
+
+
+# ------------------------------------------------------------------------------ medium sizes vs the oracle
+@pytest.mark.parametrize("n,m,d", [(1500, 700, 8), (2048, 1000, 3)])
+def test_medium_size_vs_oracle(gp, gnp, n, m, d):
+    from oracle import gp_oracle as orc
+
+    xi, zi = make_xz(n, d, 100 + n)
+    xt, _ = make_xz(m, d, 200 + n)
+    th = theta_aniso(d)
+    kern = lambda x, y, t, pairwise=False: orc.maternp_covariance(x, y, 2, t, pairwise)  # noqa: E731
+    for meantype, mean_h, mean_o in (("zero", None, None), ("linear_predictor", constant_mean, np_constant_mean)):
+        model = gp.Model(mean_h, gp.kernel.MaternCovariance(2), None, th, meantype)
+        om = orc.OracleModel(mean_o, kern, None, th, meantype)
+        zpm, zpv = model.predict(xi, zi, xt)
+        ozpm, ozpv = orc.predict(om, xi, zi, xt)
+        assert np.max(np.abs(zpm - ozpm)) < 1e-8 * np.max(np.abs(zi))
+        assert np.max(np.abs(zpv - ozpv)) < 1e-8
+    mz = gp.Model(None, gp.kernel.MaternCovariance(2), None, th, "zero")
+    oz = orc.OracleModel(None, kern, None, th, "zero")
+    a, b = float(mz.negative_log_likelihood_zero_mean(th, xi, zi)), float(orc.negative_log_likelihood_zero_mean(oz, th, xi, zi))
+    assert abs(a - b) < 1e-10 * abs(b)
+    mc = gp.Model(constant_mean, gp.kernel.MaternCovariance(2), None, th)
+    oc = orc.OracleModel(np_constant_mean, kern, None, th)
+    a, b = float(mc.negative_log_restricted_likelihood(th, xi, zi)), float(orc.negative_log_restricted_likelihood(oc, th, xi, zi))
+    assert abs(a - b) < 1e-10 * abs(b)
+    v, gr = orc.reml_value_and_grad(xi, zi, np_constant_mean(xi, None), 2, th)
+    _, pre, _, grad = gp.kernel.make_selection_criterion_with_gradient(mc, gp.kernel.negative_log_restricted_likelihood, xi, zi)
+    assert abs(pre(th) - v) < 1e-10 * abs(v)
+    assert rel_err(grad(th), gr) < 1e-7
