@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X exact-GP inner loop (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One STEP = one pass of the hot path over one batch of synthetic inputs already resident in HBM:
+    Model.predict(xi, zi, xt)          Gram build -> Cholesky -> solve -> posterior mean / variance
+  + Model.negative_log_likelihood_zero_mean(theta, xi, zi)   Gram build -> Cholesky -> solve -> NLL
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): d = 8, Matern-5/2
+anisotropic, n = 32768 observations, m = 50000 prediction points per GPU, fp64.
+Multi-GPU (weak scaling): the prediction set shards over ranks (m points per rank), the observations
+are replicated and every rank factors K itself -- no collective on the data path.
+
+value = (N * m) / (max over ranks of the time of K steps / K)   [points/s].
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix peak; tools/mfma_f64_probe2.hip measures 77 (98 %)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def synth(n, m, d, rank):
+    """default_rng(1234); U[0,1]^d inputs; z = sin(2 pi x0) + sum_j x_j; rho_j = 0.5 (1 + j/d)."""
+    rng = np.random.default_rng(1234)
+    xi = rng.random((n, d))
+    zi = np.sin(2 * np.pi * xi[:, 0]) + xi[:, 1:].sum(axis=1)
+    xt = np.random.default_rng(4321 + rank).random((m, d))
+    theta = np.concatenate(([0.0], -np.log(0.5 * (1.0 + np.arange(d) / d))))
+    return xi, zi, xt, theta
+
+
+def cpu_baseline(n, m, d, threads):
+    """The oracle (NumPy/SciPy restatement of the reference's NumPy backend) timed on the host cores."""
+    from oracle import gp_oracle as orc
+
+    xi, zi, xt, theta = synth(n, m, d, 0)
+    kern = lambda x, y, t, pairwise=False: orc.maternp_covariance(x, y, 2, t, pairwise)  # noqa: E731
+    model = orc.OracleModel(None, kern, None, theta, "zero")
+    t0 = time.perf_counter()
+    orc.predict(model, xi, zi, xt)
+    orc.negative_log_likelihood_zero_mean(model, theta, xi, zi)
+    dt = time.perf_counter() - t0
+    return {"value": m / dt, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": f"oracle predict+NLL at n={n}, m={m}, d={d} (config 2 size; {dt:.1f} s), BLAS threads={threads}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=32768)
+    ap.add_argument("--m", type=int, default=50000)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=4096)
+    ap.add_argument("--cpu-m", type=int, default=10000)
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+
+    import gpmp_amd as gp
+    import gpmp_amd.num as gnp
+    from gpmp_amd import _lib
+    from gpmp_amd.kernel import MaternCovariance
+
+    lib = _lib.load()
+    n, m, d = args.n, args.m, args.d
+    xi_h, zi_h, xt_h, theta = synth(n, m, d, rank)
+    xi, zi, xt = gnp.asarray(xi_h), gnp.asarray(zi_h), gnp.asarray(xt_h)   # resident in HBM before timing
+    model = gp.Model(None, MaternCovariance(2), None, theta, "zero")
+
+    def step():
+        zpm, zpv = model.predict(xi, zi, xt, convert_in=False, convert_out=False)
+        nll = model.negative_log_likelihood_zero_mean(theta, xi, zi)
+        return zpm, zpv, nll
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    import ctypes
+
+    lib.gpmp_profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    table = (ctypes.c_double * 24)()
+    lib.gpmp_profile_end(table)
+    prof = np.array(list(table)).reshape(8, 3)
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=gnp._dev())
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    zpm, zpv, nll = out
+    assert bool(torch.isfinite(zpm).all()) and bool((zpv >= 0).all()) and math.isfinite(float(nll))
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * m / (elapsed / args.steps)
+        # ---- roofline of the dominant kernel: the NN fp64 MFMA GEMM behind the n x m triangular solve.
+        # Algorithmic flops routed through it per step: n^2 m for V = L^-1 K(xi, xt)
+        # (+ n^2 for the NLL's single right-hand side); launches and time measured with HIP events
+        # on the launch stream over the timed region.
+        steps = args.steps
+        nn_cnt, nn_ms, nn_exec = prof[1]
+        nt_cnt, nt_ms, nt_exec = prof[0]
+        alg_nn = (float(n) * n * m + float(n) * n) * steps
+        alg_nt = 2 * (float(n) ** 3 / 3.0) * steps          # two Cholesky factorisations per step
+        roof = {
+            "bound": "mfma", "kernel": "gemm_f64_kernel<AKC=1,BKC=0> (forward trsm updates)",
+            "achieved": alg_nn / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else None,
+            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": (alg_nn / (nn_ms * 1e-3) / 1e12) / FP64_MFMA_PEAK_TFLOPS if nn_ms > 0 else None,
+            "traffic": None,
+            "launches_per_step": nn_cnt / steps, "avg_launch_ms": nn_ms / max(nn_cnt, 1),
+            "algorithmic_flops_per_launch": alg_nn / max(nn_cnt, 1),
+            "executed_tflops": nn_exec / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else None,
+        }
+        gram_cnt, gram_ms, gram_bytes = prof[5]
+        extra = {
+            "potrf_gemm_nt": {"algorithmic_tflops": alg_nt / (nt_ms * 1e-3) / 1e12 if nt_ms > 0 else None,
+                              "executed_tflops": nt_exec / (nt_ms * 1e-3) / 1e12 if nt_ms > 0 else None,
+                              "ms_per_step": nt_ms / steps, "launches_per_step": nt_cnt / steps},
+            "potf2_diag_blocks": {"ms_per_step": prof[4][1] / steps, "launches_per_step": prof[4][0] / steps},
+            "gram": {"ms_per_step": gram_ms / steps, "GBps_written": gram_bytes / (gram_ms * 1e-3) / 1e9 if gram_ms > 0 else None,
+                     "frac_of_hbm_peak": (gram_bytes / (gram_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if gram_ms > 0 else None},
+            "coldots": {"ms_per_step": prof[6][1] / steps},
+            "nll": float(nll),
+        }
+        line = {
+            "metric": "fp64 predict+NLL throughput (points/s) and potrf TFLOP/s vs roofline, n=32k",
+            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"d={d} Matern-5/2 anisotropic, n={n} train, m={m} test points per GPU, fp64 "
+                                   f"predict (mean+variance) + one zero-mean NLL eval per step",
+                       "n": n, "m_per_gpu": m, "d": d, "parallelism": f"xt-sharded x{world}, K replicated"},
+            "roofline": roof,
+            "extra": extra,
+        }
+        if not args.no_cpu_baseline:
+            try:
+                from threadpoolctl import threadpool_info
+
+                threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+            except Exception:
+                threads = os.cpu_count() or 1
+            line["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_m, d, threads)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

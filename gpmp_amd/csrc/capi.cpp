@@ -1,6 +1,7 @@
 // Error plumbing and ABI version of libgpmp_hip.so.
 #include "common.h"
 #include <cstdarg>
+#include <vector>
 
 namespace gpmp {
 namespace {
@@ -17,6 +18,54 @@ int hip_fail(hipError_t e, const char* what) {
   return -1000 - (int)e;
 }
 }  // namespace gpmp
+
+namespace gpmp {
+bool g_prof_on = false;
+namespace {
+struct Rec { hipEvent_t a, b; int kind; double work; };
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t g_open[PK_COUNT];
+hipEvent_t get_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+}  // namespace
+void prof_start(int kind, hipStream_t st) {
+  hipEvent_t e = get_event();
+  (void)hipEventRecord(e, st);
+  g_open[kind] = e;
+}
+void prof_stop(int kind, hipStream_t st, double work) {
+  hipEvent_t e = get_event();
+  (void)hipEventRecord(e, st);
+  g_recs.push_back({g_open[kind], e, kind, work});
+}
+}  // namespace gpmp
+
+extern "C" int gpmp_profile_begin(void) {
+  for (auto& r : gpmp::g_recs) { gpmp::g_pool.push_back(r.a); gpmp::g_pool.push_back(r.b); }
+  gpmp::g_recs.clear();
+  gpmp::g_prof_on = true;
+  return 0;
+}
+
+extern "C" int gpmp_profile_end(double* table_host) {
+  gpmp::g_prof_on = false;
+  if (table_host == nullptr) return -1;
+  for (int i = 0; i < 3 * gpmp::PK_COUNT; ++i) table_host[i] = 0.0;
+  for (auto& r : gpmp::g_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return gpmp::hip_fail(hipGetLastError(), "hipEventSynchronize");
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return gpmp::hip_fail(hipGetLastError(), "hipEventElapsedTime");
+    table_host[3 * r.kind + 0] += 1.0;
+    table_host[3 * r.kind + 1] += (double)ms;
+    table_host[3 * r.kind + 2] += r.work;
+  }
+  for (auto& r : gpmp::g_recs) { gpmp::g_pool.push_back(r.a); gpmp::g_pool.push_back(r.b); }
+  gpmp::g_recs.clear();
+  return 0;
+}
 
 extern "C" int gpmp_hip_abi_version(void) { return 1; }
 extern "C" const char* gpmp_last_error(void) { return gpmp::g_err; }

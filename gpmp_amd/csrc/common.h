@@ -30,6 +30,19 @@ int hip_fail(hipError_t e, const char* what);
 
 inline hipStream_t as_stream(gpmp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- opt-in per-kernel timing with HIP events on the launch stream (capi.cpp) -------------------
+// Kinds index the table returned by gpmp_profile_end().
+enum ProfKind { PK_GEMM_NT = 0, PK_GEMM_NN = 1, PK_GEMM_TN = 2, PK_GEMM_TT = 3, PK_POTF2 = 4, PK_GRAM = 5,
+                PK_COLDOTS = 6, PK_GRAD = 7, PK_COUNT = 8 };
+extern bool g_prof_on;
+void prof_start(int kind, hipStream_t st);
+void prof_stop(int kind, hipStream_t st, double work);
+struct ProfScope {
+  int kind; hipStream_t st; double work; bool on;
+  ProfScope(int k, hipStream_t s, double w) : kind(k), st(s), work(w), on(g_prof_on) { if (on) prof_start(kind, st); }
+  ~ProfScope() { if (on) prof_stop(kind, st, work); }
+};
+
 // ---- GEMM (gemm_f64.hip) --------------------------------------------------------------------
 // C (M x N, row-major) = alpha * A(M x K) * B(K x N) + beta * C.
 //   a_kc != 0: A(i,l) = A[i*lda + l]   (k-contiguous)   else A(i,l) = A[l*lda + i]

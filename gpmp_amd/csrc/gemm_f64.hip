@@ -241,7 +241,13 @@ int launch_t(const GemmParams& p, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC>), dim3(p.ntiles), dim3(256), lds, st, p);
+  {
+    // executed flops of this launch (tiles actually visited, k range actually swept)
+    const double kavg = (p.kstart_row || p.kend_row) ? 0.5 * p.K : (double)p.K;
+    ProfScope ps(AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN), st,
+                 2.0 * (double)p.ntiles * BM * BN * kavg);
+    hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC>), dim3(p.ntiles), dim3(256), lds, st, p);
+  }
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -401,7 +401,11 @@ extern "C" int gpmp_matern_gram(const double* x, const double* y, int n, int m, 
   for (int k = 0; k < d; ++k) gp.invrho[k] = std::exp(theta_host[off + k]);
   fill_matern(gp.ms, p);
   dim3 grid((m + GT - 1) / GT, (n + GT - 1) / GT);
-  hipLaunchKernelGGL(gram_kernel, grid, dim3(256), 0, as_stream(stream), gp);
+  {
+    // work = algorithmic bytes written (8 per entry; lower_only writes about half)
+    ProfScope ps(PK_GRAM, as_stream(stream), 8.0 * (double)n * (double)m * (gp.lower_only ? 0.5 : 1.0));
+    hipLaunchKernelGGL(gram_kernel, grid, dim3(256), 0, as_stream(stream), gp);
+  }
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }

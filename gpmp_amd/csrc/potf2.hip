@@ -107,8 +107,11 @@ int launch(double* A, long lda, int n_total, int nblocks, double* dinv, int* inf
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(potf2_inv_kernel, dim3(nblocks), dim3(256), lds, st, A, lda, n_total, dinv, info_dev,
-                     offset, do_factor);
+  {
+    ProfScope ps(PK_POTF2, st, (double)nblocks);
+    hipLaunchKernelGGL(potf2_inv_kernel, dim3(nblocks), dim3(256), lds, st, A, lda, n_total, dinv, info_dev,
+                       offset, do_factor);
+  }
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }

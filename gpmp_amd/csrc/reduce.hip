@@ -151,6 +151,7 @@ extern "C" int gpmp_coldots(const double* V, int n, int m, long ldv, const doubl
   const int rows_per = (n + nchunks - 1) / nchunks > 0 ? (n + nchunks - 1) / nchunks : 1;
   int k0 = 0;
   bool first = true;
+  ProfScope ps(PK_COLDOTS, st, 8.0 * (double)n * (double)m);
   do {
     const int rk = (r - k0) < CD_R ? (r - k0) : CD_R;
     const int want_sq = first ? 1 : 0;

@@ -40,6 +40,14 @@ int gpmp_hip_abi_version(void);
 /* Last error text of the calling thread (HIP error string or argument message). */
 const char* gpmp_last_error(void);
 
+/* Opt-in kernel timing (HIP events recorded on the launch stream around every kernel launch of the
+ * library).  gpmp_profile_end synchronises the recorded events and fills table_host[8][3] =
+ * {launch count, total milliseconds, work} per kind: 0..3 GEMM variants NT / NN / TN / TT (work =
+ * executed flops), 4 diagonal-block kernel (work = blocks), 5 Gram kernel (work = bytes written),
+ * 6 column reductions (work = bytes read), 7 gradient trace.  Used by bench.py for `roofline`. */
+int gpmp_profile_begin(void);
+int gpmp_profile_end(double* table_host);
+
 /* ---- Matern kernels ------------------------------------------------------------------------ */
 
 /* K[i,j] = sigma2 * Matern_p( || invrho * (x_i - y_j) || )  (+ diag_add on i == j when y == NULL).
