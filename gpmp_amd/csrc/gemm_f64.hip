@@ -131,7 +131,7 @@ __device__ __forceinline__ void store_mc(double* __restrict__ S, int t, const d2
   for (int s = 0; s < 4; ++s) *reinterpret_cast<d2*>(S + (kr + 4 * s) * LDN + cp) = r[s];
 }
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, bool CACC>
 __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) double smem[];  // [2 buffers][A tile | B tile]
   int ti, tj;
@@ -148,11 +148,45 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmParams p) {
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
   const bool full_mn = p.aligned && (row0 + BM <= p.M) && (col0 + BN <= p.N);
 
+  // Accumulators start from (beta / alpha) * C (CACC), so the epilogue is a pure store: the C reads
+  // overlap the pipeline fill instead of serialising after the last MFMA.  Addressing: one uniform
+  // (SGPR) row base per accumulator row + ONE 32-bit per-lane offset shared by all 64 accesses.
+  const double alpha = p.alpha, beta = p.beta;
+  const bool full_c = (row0 + BM <= p.M) && (col0 + BN <= p.N);
+  double* __restrict__ cbase = p.C + (long)row0 * p.ldc + col0;
+  const unsigned lane_off = (unsigned)((wm + lk) * (int)p.ldc + wn + lr);
   d4 acc[4][4];
+  if constexpr (CACC) {
+    const double sc = beta / alpha;
+    if (full_c) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int r = 0; r < 4; ++r) {
+          const double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j][r] = sc * rp[lane_off + j * 16];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + wm + i * 16 + lk + 4 * r;
+          const double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int col = col0 + wn + j * 16 + lr;
+            acc[i][j][r] = (row < p.M && col < p.N) ? sc * rp[lane_off + j * 16] : 0.0;
+          }
+        }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  }
 
   d2 ra[4], rb[4];
   auto load_tiles = [&](int kt) {
@@ -210,34 +244,46 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: C = alpha * acc + beta * C
-  const double alpha = p.alpha, beta = p.beta;
-  const bool full_c = (row0 + BM <= p.M) && (col0 + BN <= p.N);
+  // ---- epilogue: C = alpha * acc  (+ beta * C when the accumulators did not start from C)
+  if (full_c) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + wm + i * 16 + lk + 4 * r;
-      double* crow = p.C + (long)row * p.ldc + col0 + wn + lr;
+      for (int r = 0; r < 4; ++r) {
+        double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = col0 + wn + j * 16 + lr;
-        if (full_c || (row < p.M && col < p.N)) {
+        for (int j = 0; j < 4; ++j) {
           double v = alpha * acc[i][j][r];
-          if (beta != 0.0) v += beta * crow[j * 16];
-          crow[j * 16] = v;
+          if constexpr (!CACC) { if (beta != 0.0) v += beta * rp[lane_off + j * 16]; }
+          rp[lane_off + j * 16] = v;
         }
       }
-    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + wm + i * 16 + lk + 4 * r;
+        double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = col0 + wn + j * 16 + lr;
+          if (row < p.M && col < p.N) {
+            double v = alpha * acc[i][j][r];
+            if constexpr (!CACC) { if (beta != 0.0) v += beta * rp[lane_off + j * 16]; }
+            rp[lane_off + j * 16] = v;
+          }
+        }
+      }
   }
 }
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, bool CACC>
 int launch_t(const GemmParams& p, hipStream_t st) {
   static bool attr_done = false;
   const size_t lds = sizeof(double) * 4 * TILE;  // 73,728 B
   if (!attr_done) {
-    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<AKC, BKC>),
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<AKC, BKC, CACC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
@@ -246,10 +292,16 @@ int launch_t(const GemmParams& p, hipStream_t st) {
     const double kavg = (p.kstart_row || p.kend_row) ? 0.5 * p.K : (double)p.K;
     ProfScope ps(AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN), st,
                  2.0 * (double)p.ntiles * BM * BN * kavg);
-    hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC>), dim3(p.ntiles), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC, CACC>), dim3(p.ntiles), dim3(256), lds, st, p);
   }
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
+}
+
+template <bool AKC, bool BKC>
+int launch_c(const GemmParams& p, hipStream_t st) {
+  if (p.beta != 0.0 && p.alpha != 0.0) return launch_t<AKC, BKC, true>(p, st);
+  return launch_t<AKC, BKC, false>(p, st);
 }
 
 }  // namespace
@@ -274,10 +326,10 @@ int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const d
   }
   p.aligned = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0) &&
               ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((ldb & 1) == 0);
-  if (a_kc && b_kc) return launch_t<true, true>(p, st);
-  if (a_kc && !b_kc) return launch_t<true, false>(p, st);
-  if (!a_kc && !b_kc) return launch_t<false, false>(p, st);
-  return launch_t<false, true>(p, st);
+  if (a_kc && b_kc) return launch_c<true, true>(p, st);
+  if (a_kc && !b_kc) return launch_c<true, false>(p, st);
+  if (!a_kc && !b_kc) return launch_c<false, false>(p, st);
+  return launch_c<false, true>(p, st);
 }
 
 }  // namespace gpmp
