@@ -2,6 +2,7 @@
 #include "common.h"
 #include <cstdarg>
 #include <vector>
+#include <cstdlib>
 
 namespace gpmp {
 namespace {
@@ -54,6 +55,9 @@ extern "C" int gpmp_profile_end(double* table_host) {
   gpmp::g_prof_on = false;
   if (table_host == nullptr) return -1;
   for (int i = 0; i < 3 * gpmp::PK_COUNT; ++i) table_host[i] = 0.0;
+  FILE* dump = nullptr;
+  if (const char* path = getenv("GPMP_PROF_DUMP")) dump = fopen(path, "w");
+  if (dump) fprintf(dump, "kind,work,ms\n");
   for (auto& r : gpmp::g_recs) {
     if (hipEventSynchronize(r.b) != hipSuccess) return gpmp::hip_fail(hipGetLastError(), "hipEventSynchronize");
     float ms = 0.f;
@@ -61,7 +65,9 @@ extern "C" int gpmp_profile_end(double* table_host) {
     table_host[3 * r.kind + 0] += 1.0;
     table_host[3 * r.kind + 1] += (double)ms;
     table_host[3 * r.kind + 2] += r.work;
+    if (dump) fprintf(dump, "%d,%.6e,%.6f\n", r.kind, r.work, ms);
   }
+  if (dump) fclose(dump);
   for (auto& r : gpmp::g_recs) { gpmp::g_pool.push_back(r.a); gpmp::g_pool.push_back(r.b); }
   gpmp::g_recs.clear();
   return 0;

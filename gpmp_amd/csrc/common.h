@@ -66,6 +66,10 @@ int launch_potf2_inv(double* A, long lda, int jb, double* dinv, int* info_dev, i
 // inv(L_kk) of every NB diagonal block of an already factored n x n lower L (one launch).
 int launch_trtri_blocks(const double* L, long ldl, int n, double* dinv, hipStream_t st);
 
+// ---- few right-hand sides (trsv.hip): in-place op(L)^-1 B, m <= 4
+int trsv_few(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int trans,
+             hipStream_t st);
+
 // ---- misc kernels (reduce.hip) -----------------------------------------------------------------
 int launch_tril(double* A, int n, long lda, hipStream_t st);
 int launch_symmetrize(double* A, int n, long lda, hipStream_t st);

@@ -26,6 +26,7 @@ constexpr int LDK = 18;    // row stride of a k-contiguous tile image
 constexpr int LDN = 144;   // row stride of an m/n-contiguous tile image
 constexpr int TILE = 2304; // doubles per operand tile image (128*18 == 16*144)
 constexpr int NXCD = 8;
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 struct GemmParams {
   const double* A;
@@ -80,6 +81,19 @@ __device__ __forceinline__ void load_kc(const double* __restrict__ G, long ld, i
                                         int k0, int kend, int t, d2 (&r)[4]) {
   const int kp = (t & 7) * 2;
   const int rr = t >> 3;
+  if constexpr (FAST) {
+    // buffer loads: uniform descriptor on the tile's first row, ONE per-lane byte offset, the four
+    // row groups and the k position go into the scalar offset -- no per-load VALU address math.
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(G + (long)idx0 * ld), 0, 0x7FFFFFFF, 0x00020000);
+    const int voff = (rr * (int)ld + kp) * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (k0 + 32 * s * (int)ld) * 8, 0);
+      r[s] = __builtin_bit_cast(d2, raw);
+    }
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int row = idx0 + rr + 32 * s;
@@ -102,6 +116,17 @@ __device__ __forceinline__ void load_mc(const double* __restrict__ G, long ld, i
                                         int k0, int kend, int t, d2 (&r)[4]) {
   const int cp = (t & 63) * 2;
   const int kr = t >> 6;
+  if constexpr (FAST) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(G + (long)k0 * ld + idx0), 0, 0x7FFFFFFF, 0x00020000);
+    const int voff = (kr * (int)ld + cp) * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (4 * s * (int)ld) * 8, 0);
+      r[s] = __builtin_bit_cast(d2, raw);
+    }
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int k = k0 + kr + 4 * s;
@@ -136,6 +161,10 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) double smem[];  // [2 buffers][A tile | B tile]
   int ti, tj;
   decode_tile(p, blockIdx.x, ti, tj);
+  // the tile coordinates are wave-uniform but come out of VALU code (sqrt in the triangular decode):
+  // pin them to SGPRs so every tile base address below is scalar
+  ti = __builtin_amdgcn_readfirstlane(ti);
+  tj = __builtin_amdgcn_readfirstlane(tj);
   const int row0 = ti * BM, col0 = tj * BN;
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
