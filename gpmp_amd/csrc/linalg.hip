@@ -148,6 +148,35 @@ inline int split_point(int n) {
   return n1;
 }
 
+// B (M x k) <- B * L^-T for a lower-triangular k x k L with diagonal-block inverses dinv (right side;
+// the panel solve of a distributed Cholesky step).  Recursive halving over 512-column leaves.
+int trsm_right(const double* L, int k, long ldl, const double* dinv, double* B, int M, long ldb, hipStream_t st) {
+  if (M <= 0 || k <= 0) return 0;
+  GemmOpts plain;
+  if (k <= LEAF_TRSM) {
+    const int nblk = (k + NB - 1) / NB;
+    for (int c = 0; c < nblk; ++c) {
+      const int c0 = c * NB, jb = imin(NB, k - c0);
+      double* Bc = B + c0;
+      int rc = launch_gemm(true, true, M, jb, jb, 1.0, Bc, ldb, dinv + (size_t)c * NB * NB, NB, 0.0, Bc, ldb, plain, st);
+      if (rc) return rc;
+      const int rest = k - (c0 + jb);
+      if (rest > 0) {
+        rc = launch_gemm(true, true, M, rest, jb, -1.0, Bc, ldb, L + (long)(c0 + jb) * ldl + c0, ldl, 1.0,
+                         B + c0 + jb, ldb, plain, st);
+        if (rc) return rc;
+      }
+    }
+    return 0;
+  }
+  const int k1 = split_point(k);
+  int rc = trsm_right(L, k1, ldl, dinv, B, M, ldb, st);
+  if (rc) return rc;
+  rc = launch_gemm(true, true, M, k - k1, k1, -1.0, B, ldb, L + (long)k1 * ldl, ldl, 1.0, B + k1, ldb, plain, st);
+  if (rc) return rc;
+  return trsm_right(L + (long)k1 * ldl + k1, k - k1, ldl, dinv + (size_t)(k1 / NB) * NB * NB, B + k1, M, ldb, st);
+}
+
 // ---- Cholesky with look-ahead --------------------------------------------------------------------
 // Right-looking over outer panels of w = 4 * NB columns.  After panel k is factored, the update of the
 // NEXT panel's columns and that panel's factorisation (latency-bound: LDS diagonal kernels, 128-wide
@@ -349,6 +378,16 @@ extern "C" int gpmp_trsm_lower(const double* L, int n, long ldl, const double* d
     return 0;
   }
   return trans ? trsm_backward(L, n, ldl, dinv, B, m, ldb, st) : trsm_forward(L, n, ldl, dinv, B, m, ldb, 0, 0, st);
+}
+
+extern "C" int gpmp_trsm_right_lower(const double* L, int k, long ldl, const double* dinv, double* B, int M, long ldb,
+                                     gpmp_stream_t stream) {
+  GPMP_ARG(L != nullptr, 1, "L is NULL");
+  GPMP_ARG(k >= 0 && ldl >= k, 3, "ldl < k");
+  GPMP_ARG(dinv != nullptr, 4, "dinv is NULL");
+  GPMP_ARG(B != nullptr, 5, "B is NULL");
+  GPMP_ARG(M >= 0 && ldb >= k, 7, "ldb < k");
+  return trsm_right(L, k, ldl, dinv, B, M, ldb, as_stream(stream));
 }
 
 extern "C" int gpmp_trtri_lower(const double* L, int n, long ldl, const double* dinv, double* T, long ldt,

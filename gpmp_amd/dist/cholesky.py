@@ -1,0 +1,346 @@
+"""2-D block-cyclic Cholesky of K + nugget over a Pr x Pc process grid, and the NLL on top of it.
+
+Layout (ScaLAPACK style): global block (I, J) of size nb lives on rank (I mod Pr, J mod Pc) at local
+block (I div Pr, J div Pc) of one dense row-major local matrix.  Because the local matrix is
+K(x[rows owned], x[cols owned]), it is built by ONE cross-covariance Gram call on two gathered point
+subsets -- no communication.
+
+Right-looking schedule per block column k (owner column cd = k mod Pc):
+  1. owner (k mod Pr, cd) factors the diagonal block (single-GPU blocked potrf, MFMA)           [local]
+  2. L_kk + its diagonal-block inverses -> broadcast down process column cd                      [RCCL]
+  3. ranks of column cd:  panel  A_Ik <- A_Ik L_kk^-T  for their block rows I > k               [local]
+  4. every process row r: panel piece broadcast along the row from (r, cd)                        [RCCL]
+  5. every process column c: the blocks J > k with J mod Pc == c are exchanged inside the column
+     (one broadcast per process row) -> the "transposed" operand of the update                    [RCCL]
+  6. every rank: A_IJ -= L_Ik L_Jk^T for its blocks I >= J > k, one GEMM per local block row       [local]
+Collectives are point-to-point-friendly broadcasts of (n - k nb) nb / Pr resp. / Pc doubles; scalars
+(log-det, quadratic form) use one all-reduce of a few doubles.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .grid import ProcessGrid
+
+
+# ------------------------------------------------------------------------------------------------
+# local compute back-ends
+# ------------------------------------------------------------------------------------------------
+class HipLocalOps:
+    """Local arithmetic through libgpmp_hip.so (the product path)."""
+
+    name = "hip"
+
+    def __init__(self):
+        from .. import _lib
+        from .. import num as gnp
+
+        self.lib, self._lib, self.gnp = _lib.load(), _lib, gnp
+        self.device = gnp._dev()
+
+    def empty(self, rows, cols):
+        return self.gnp.alloc_matrix(rows, cols)
+
+    def gram_block(self, cov, x_rows, x_cols, covparam):
+        """K(x_rows, x_cols) without the diagonal term (cross-covariance path of the kernel)."""
+        return self.gnp.as_matrix(self.gnp.asarray(cov(x_rows, x_cols, covparam)))
+
+    def potrf(self, A):
+        """In-place lower Cholesky of the square view A -> (dinv, info tensor)."""
+        g = self.gnp
+        n = A.shape[0]
+        dinv = torch.empty(max(int(self.lib.gpmp_dinv_elems(n)), 1), dtype=torch.float64, device=self.device)
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._lib.check(self.lib.gpmp_potrf_lower_async(g._ptr(A), n, g._ld(A), g._ptr(dinv), g._ptr(info), g._stream()),
+                        "gpmp_potrf_lower_async")
+        return dinv, info
+
+    def diag_inverses(self, L):
+        g = self.gnp
+        n = L.shape[0]
+        dinv = torch.empty(max(int(self.lib.gpmp_dinv_elems(n)), 1), dtype=torch.float64, device=self.device)
+        self._lib.check(self.lib.gpmp_trtri_diag_blocks(g._ptr(L), n, g._ld(L), g._ptr(dinv), g._stream()), "gpmp_trtri_diag_blocks")
+        return dinv
+
+    def trsm_right(self, L, dinv, B):
+        """B <- B L^-T in place (B: M x k view)."""
+        g = self.gnp
+        if B.shape[0] == 0:
+            return
+        self._lib.check(self.lib.gpmp_trsm_right_lower(g._ptr(L), L.shape[0], g._ld(L), g._ptr(dinv), g._ptr(B), B.shape[0],
+                                                       g._ld(B), g._stream()), "gpmp_trsm_right_lower")
+
+    def gemm_nt_sub(self, C, A, B):
+        """C -= A B^T  (C: M x N view, A: M x K, B: N x K)."""
+        g = self.gnp
+        M, N, K = C.shape[0], C.shape[1], A.shape[1]
+        if M == 0 or N == 0:
+            return
+        self._lib.check(self.lib.gpmp_dgemm(0, 1, M, N, K, -1.0, g._ptr(A), g._ld(A), g._ptr(B), g._ld(B), 1.0, g._ptr(C),
+                                            g._ld(C), 0, g._stream()), "gpmp_dgemm")
+
+    def solve_lower_vec(self, L, dinv, v):
+        """L^-1 v for a small diagonal block (vector)."""
+        g = self.gnp
+        x = g.as_matrix(v.reshape(-1, 1), copy=True)
+        self._lib.check(self.lib.gpmp_trsm_lower(g._ptr(L), L.shape[0], g._ld(L), g._ptr(dinv), g._ptr(x), 1, g._ld(x), 0, None,
+                                                 g._stream()), "gpmp_trsm_lower")
+        return x.reshape(-1)
+
+    def matvec(self, A, v):
+        """A v through the library GEMM (A: M x K view)."""
+        g = self.gnp
+        M, K = A.shape
+        out = g.alloc_matrix(M, 1)
+        if M == 0:
+            return out.reshape(-1)
+        vm = g.as_matrix(v.reshape(-1, 1), copy=True)
+        self._lib.check(self.lib.gpmp_dgemm(0, 0, M, 1, K, 1.0, g._ptr(A), g._ld(A), g._ptr(vm), g._ld(vm), 0.0, g._ptr(out),
+                                            g._ld(out), 0, g._stream()), "gpmp_dgemm")
+        return out.reshape(-1)
+
+    def sum_log_diag(self, L):
+        return float(torch.log(torch.diagonal(L)).sum().item())
+
+    def asarray(self, a):
+        return self.gnp.asarray(a)
+
+
+# ------------------------------------------------------------------------------------------------
+def _comm_tensor(t: torch.Tensor, backend: str) -> torch.Tensor:
+    """Contiguous tensor on the device the communication backend wants."""
+    if backend == "nccl":
+        return t.contiguous()
+    return t.detach().to("cpu").contiguous()
+
+
+class BlockCyclicCholesky:
+    """K = L L^T with K 2-D block-cyclic over ``grid``; keeps the local factor for NLL evaluations."""
+
+    def __init__(self, grid: ProcessGrid, n: int, nb: int = 1024, ops=None):
+        if nb % 128 != 0:
+            raise ValueError("block size must be a multiple of 128 (the GEMM tile)")
+        self.grid, self.n, self.nb = grid, n, nb
+        self.ops = ops if ops is not None else HipLocalOps()
+        self.backend = dist.get_backend(grid.world_group)
+        self.nblocks = (n + nb - 1) // nb
+        self.row_blocks = grid.local_row_blocks(self.nblocks)
+        self.col_blocks = grid.local_col_blocks(self.nblocks)
+        self.roff = self._offsets(self.row_blocks)
+        self.coff = self._offsets(self.col_blocks)
+        self.A = None            # local matrix (rows owned x cols owned)
+        self.info = 0
+        self.diag_cache = {}     # k -> (L_kk contiguous, dinv) on ranks of the owning process column
+        self.bytes_received = 0
+
+    # ---- index helpers
+    def bs(self, I: int) -> int:
+        return min(self.nb, self.n - I * self.nb)
+
+    def _offsets(self, blocks: List[int]):
+        off, acc = [], 0
+        for I in blocks:
+            off.append(acc)
+            acc += self.bs(I)
+        off.append(acc)
+        return off
+
+    def local_rows(self):
+        return self.roff[-1]
+
+    def local_cols(self):
+        return self.coff[-1]
+
+    def global_row_index(self):
+        return np.concatenate([np.arange(I * self.nb, I * self.nb + self.bs(I)) for I in self.row_blocks]) if self.row_blocks else np.zeros(0, dtype=np.int64)
+
+    def global_col_index(self):
+        return np.concatenate([np.arange(J * self.nb, J * self.nb + self.bs(J)) for J in self.col_blocks]) if self.col_blocks else np.zeros(0, dtype=np.int64)
+
+    # ---- build
+    def build_local_gram(self, cov, x, covparam, diag_add: float):
+        """Local part of K(x, x) + diag_add I: one cross-covariance call on the owned row / column points."""
+        ops = self.ops
+        x = ops.asarray(x)
+        ri, ci = self.global_row_index(), self.global_col_index()
+        xr = x[torch.as_tensor(ri, device=x.device)] if len(ri) else x[:0]
+        xc = x[torch.as_tensor(ci, device=x.device)] if len(ci) else x[:0]
+        if len(ri) == 0 or len(ci) == 0:
+            self.A = ops.empty(len(ri), len(ci))
+            return self.A
+        A = ops.gram_block(cov, xr.contiguous(), xc.contiguous(), covparam)
+        # nugget / noise on the global diagonal entries this rank owns
+        for li, I in enumerate(self.row_blocks):
+            if I in self.col_blocks:
+                lj = self.col_blocks.index(I)
+                blk = A[self.roff[li]:self.roff[li + 1], self.coff[lj]:self.coff[lj + 1]]
+                torch.diagonal(blk).add_(diag_add)
+        self.A = A
+        return A
+
+    def set_local(self, A_local: torch.Tensor):
+        self.A = A_local
+
+    # ---- communication helpers
+    def _bcast(self, t: torch.Tensor, src_rank: int, group) -> torch.Tensor:
+        """Broadcast ``t`` (already allocated with the right shape on every participant)."""
+        ct = _comm_tensor(t, self.backend)
+        dist.broadcast(ct, src=src_rank, group=group)
+        if dist.get_rank(self.grid.world_group) != src_rank:
+            self.bytes_received += ct.numel() * 8
+        if ct.data_ptr() != t.data_ptr():
+            t.copy_(ct)
+        return t
+
+    # ---- factorisation
+    def factor(self):
+        g, ops, nb = self.grid, self.ops, self.nb
+        A = self.A
+        for k in range(self.nblocks):
+            rd, cd = g.owner_row(k), g.owner_col(k)
+            bk = self.bs(k)
+            in_col = g.c == cd
+            # local block indices of the first owned row / col block strictly after k
+            i0 = next((i for i, I in enumerate(self.row_blocks) if I > k), len(self.row_blocks))
+            j0 = next((j for j, J in enumerate(self.col_blocks) if J > k), len(self.col_blocks))
+            Mr = self.roff[-1] - self.roff[i0]
+
+            # 1-2. diagonal block: factor on the owner, broadcast (L_kk, dinv) down process column cd
+            if in_col:
+                Lkk = ops.empty(bk, bk)
+                ndinv = ((bk + 127) // 128) * 128 * 128
+                dinv = torch.empty(ndinv, dtype=torch.float64, device=Lkk.device)
+                info_t = torch.zeros(1, dtype=torch.float64, device=Lkk.device)
+                if g.r == rd:
+                    li, lj = self.row_blocks.index(k), self.col_blocks.index(k)
+                    D = A[self.roff[li]:self.roff[li + 1], self.coff[lj]:self.coff[lj + 1]]
+                    dv, info = ops.potrf(D)
+                    dinv.copy_(dv[:ndinv])
+                    Lkk.copy_(D)
+                    info_t[0] = float(int(info.item()))
+                src = g.rank_of(rd, cd)
+                if g.pr > 1:
+                    self._bcast(Lkk, src, g.col_group)
+                    self._bcast(dinv, src, g.col_group)
+                    self._bcast(info_t, src, g.col_group)
+                if int(info_t.item()) != 0 and self.info == 0:
+                    self.info = k * nb + int(info_t.item())
+                self.diag_cache[k] = (Lkk, dinv)
+
+            # 3. panel solve on the owning process column
+            panel = ops.empty(Mr, bk)     # this process row's panel piece (rows of blocks I > k, I mod Pr == r)
+            if in_col and Mr > 0:
+                lj = self.col_blocks.index(k)
+                P = A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]]
+                ops.trsm_right(Lkk, dinv, P)
+                panel.copy_(P)
+            # 4. broadcast along the process row
+            if g.pc > 1 and Mr > 0:
+                self._bcast(panel, g.rank_of(g.r, cd), g.row_group)
+
+            # 5. column operand: blocks J > k with J mod Pc == c, gathered inside the process column
+            my_cols = self.col_blocks[j0:]
+            Nc = self.coff[-1] - self.coff[j0]
+            if Nc > 0:
+                colop = ops.empty(Nc, bk)
+                for rp in range(g.pr):
+                    # blocks held by process row rp (I mod Pr == rp, I > k) that this column needs
+                    blocks = [J for J in my_cols if J % g.pr == rp]
+                    if not blocks:
+                        continue
+                    rows = sum(self.bs(J) for J in blocks)
+                    piece = ops.empty(rows, bk)
+                    if g.r == rp:
+                        off = 0
+                        for J in blocks:
+                            li = self.row_blocks.index(J)
+                            src_rows = panel[self.roff[li] - self.roff[i0]: self.roff[li + 1] - self.roff[i0]]
+                            piece[off:off + self.bs(J)].copy_(src_rows)
+                            off += self.bs(J)
+                    if g.pr > 1:
+                        self._bcast(piece, g.rank_of(rp, g.c), g.col_group)
+                    off = 0
+                    for J in blocks:
+                        lj = self.col_blocks.index(J)
+                        colop[self.coff[lj] - self.coff[j0]: self.coff[lj + 1] - self.coff[j0]].copy_(piece[off:off + self.bs(J)])
+                        off += self.bs(J)
+
+                # 6. trailing update of the local blocks, one GEMM per local block row (staircase)
+                for li in range(i0, len(self.row_blocks)):
+                    I = self.row_blocks[li]
+                    # last local column block with J <= I
+                    jmax = max((j for j, J in enumerate(self.col_blocks) if J <= I and J > k), default=-1)
+                    if jmax < j0:
+                        continue
+                    C = A[self.roff[li]:self.roff[li + 1], self.coff[j0]:self.coff[jmax + 1]]
+                    Ai = panel[self.roff[li] - self.roff[i0]: self.roff[li + 1] - self.roff[i0]]
+                    Bj = colop[: self.coff[jmax + 1] - self.coff[j0]]
+                    ops.gemm_nt_sub(C, Ai, Bj)
+        # agree on info
+        it = torch.tensor([float(self.info if self.info else 0)], dtype=torch.float64)
+        it = it.to("cuda") if self.backend == "nccl" else it
+        if self.info == 0:
+            it[0] = float("inf")
+        dist.all_reduce(it, op=dist.ReduceOp.MIN, group=g.world_group)
+        self.info = 0 if math.isinf(float(it.item())) else int(it.item())
+        return self.info
+
+    # ---- scalars
+    def logdet(self) -> float:
+        """2 sum_i log L_ii, all-reduced."""
+        g, ops = self.grid, self.ops
+        s = 0.0
+        for k in range(self.nblocks):
+            if g.r == g.owner_row(k) and g.c == g.owner_col(k):
+                s += ops.sum_log_diag(self.diag_cache[k][0])
+        t = torch.tensor([2.0 * s], dtype=torch.float64)
+        t = t.to("cuda") if self.backend == "nccl" else t
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=g.world_group)
+        return float(t.item())
+
+    def solve_lower_vector(self, z):
+        """w = L^-1 z for a replicated vector z (n,): block forward substitution with one broadcast and
+        one all-reduce of the update per block column."""
+        g, ops, nb = self.grid, self.ops, self.nb
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        w = torch.as_tensor(np.asarray(z, dtype=np.float64)).to(dev).clone()
+        for k in range(self.nblocks):
+            rd, cd = g.owner_row(k), g.owner_col(k)
+            bk = self.bs(k)
+            k0 = k * nb
+            wk = w[k0:k0 + bk].clone()
+            if g.r == rd and g.c == cd:
+                Lkk, dinv = self.diag_cache[k]
+                wk = ops.solve_lower_vec(Lkk, dinv, ops.asarray(w[k0:k0 + bk]) if hasattr(ops, "asarray") else w[k0:k0 + bk]).to(dev)
+            wk = wk.contiguous()
+            dist.broadcast(wk, src=g.rank_of(rd, cd), group=g.world_group)
+            w[k0:k0 + bk] = wk
+            rest = self.n - (k0 + bk)
+            if rest <= 0:
+                continue
+            delta = torch.zeros(rest, dtype=torch.float64, device=dev)
+            if g.c == cd:
+                i0 = next((i for i, I in enumerate(self.row_blocks) if I > k), len(self.row_blocks))
+                if i0 < len(self.row_blocks):
+                    lj = self.col_blocks.index(k)
+                    P = self.A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]]
+                    upd = ops.matvec(P, ops.asarray(wk)).to(dev)
+                    for li in range(i0, len(self.row_blocks)):
+                        I = self.row_blocks[li]
+                        a, b = self.roff[li] - self.roff[i0], self.roff[li + 1] - self.roff[i0]
+                        delta[I * nb - (k0 + bk): I * nb - (k0 + bk) + (b - a)] = upd[a:b]
+            dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=g.world_group)
+            w[k0 + bk:] -= delta
+        return w
+
+    def negative_log_likelihood(self, z) -> float:
+        """1/2 (n ln 2pi + ln|K| + z^T K^-1 z) -- gpmp/core/likelihood.py:18-52 on the distributed factor."""
+        if self.info:
+            return math.inf
+        w = self.solve_lower_vector(z)
+        return 0.5 * (self.n * math.log(2.0 * math.pi) + self.logdet() + float((w * w).sum().item()))

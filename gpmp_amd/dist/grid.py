@@ -1,0 +1,51 @@
+"""Pr x Pc process grid and the block-cyclic index maps (ScaLAPACK conventions, row-major ranks)."""
+import torch.distributed as dist
+
+
+class ProcessGrid:
+    def __init__(self, pr: int, pc: int, group=None):
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if pr * pc != self.world:
+            raise ValueError(f"process grid {pr}x{pc} does not match world size {self.world}")
+        self.pr, self.pc = pr, pc
+        self.r, self.c = divmod(self.rank, pc)
+        # one communicator per process row and per process column (every rank creates all of them)
+        self.row_groups = [dist.new_group([rr * pc + cc for cc in range(pc)]) for rr in range(pr)]
+        self.col_groups = [dist.new_group([rr * pc + cc for rr in range(pr)]) for cc in range(pc)]
+        self.world_group = group
+
+    @staticmethod
+    def default_shape(world: int):
+        """2 x 4 for 8 GPUs; otherwise the most square Pr <= Pc factorisation."""
+        pr = 1
+        for cand in range(1, int(world ** 0.5) + 1):
+            if world % cand == 0:
+                pr = cand
+        return pr, world // pr
+
+    def rank_of(self, r: int, c: int) -> int:
+        return r * self.pc + c
+
+    @property
+    def row_group(self):
+        return self.row_groups[self.r]
+
+    @property
+    def col_group(self):
+        return self.col_groups[self.c]
+
+    # ---- block-cyclic maps: global block index -> (owner coordinate, local block index)
+    def owner_row(self, I: int) -> int:
+        return I % self.pr
+
+    def owner_col(self, J: int) -> int:
+        return J % self.pc
+
+    def local_row_blocks(self, nblocks: int, r=None):
+        r = self.r if r is None else r
+        return list(range(r, nblocks, self.pr))
+
+    def local_col_blocks(self, nblocks: int, c=None):
+        c = self.c if c is None else c
+        return list(range(c, nblocks, self.pc))

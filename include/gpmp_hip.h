@@ -91,6 +91,12 @@ int gpmp_potrf_lower_async(double* A, int n, long lda, double* dinv, int* info_d
 int gpmp_trsm_lower(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb,
                     int trans, double* scratch, gpmp_stream_t stream);
 
+/* B <- B L^-T for an M x k row-major B and a k x k lower-triangular L (right-side solve: the panel step
+ * A21 <- A21 inv(L11)^T of a blocked / distributed Cholesky).  dinv as produced by gpmp_potrf_lower_async
+ * or gpmp_trtri_diag_blocks for L. */
+int gpmp_trsm_right_lower(const double* L, int k, long ldl, const double* dinv, double* B, int M, long ldb,
+                          gpmp_stream_t stream);
+
 /* inv(L_kk) for every diagonal block of a given lower-triangular L (no factorisation). */
 int gpmp_trtri_diag_blocks(const double* L, int n, long ldl, double* dinv, gpmp_stream_t stream);
 

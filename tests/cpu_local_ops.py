@@ -1,0 +1,44 @@
+"""CPU stand-in for gpmp_amd.dist's LocalOps (torch-CPU / LAPACK arithmetic) -- TEST INFRASTRUCTURE.
+
+Lets the block-cyclic schedule (ownership maps, panel broadcasts, staircase updates) run under gloo
+on a machine without GPUs.  The product path uses gpmp_amd.dist.HipLocalOps."""
+import numpy as np
+import torch
+
+
+class CpuLocalOps:
+    name = "cpu-test"
+
+    def empty(self, rows, cols):
+        return torch.zeros((rows, cols), dtype=torch.float64)
+
+    def asarray(self, a):
+        return torch.as_tensor(np.asarray(a, dtype=np.float64)) if not isinstance(a, torch.Tensor) else a.to(torch.float64)
+
+    def gram_block(self, cov, x_rows, x_cols, covparam):
+        return torch.as_tensor(np.ascontiguousarray(cov(x_rows.numpy(), x_cols.numpy(), covparam)))
+
+    def potrf(self, A):
+        info = torch.zeros(1, dtype=torch.int32)
+        L, inf = torch.linalg.cholesky_ex(torch.tril(A) + torch.tril(A, -1).T)
+        info[0] = int(inf)
+        A.copy_(torch.tril(L))
+        n = A.shape[0]
+        return torch.zeros(((n + 127) // 128) * 128 * 128, dtype=torch.float64), info
+
+    def trsm_right(self, L, dinv, B):
+        if B.shape[0]:
+            B.copy_(torch.linalg.solve_triangular(torch.tril(L), B.T.contiguous(), upper=False).T)
+
+    def gemm_nt_sub(self, C, A, B):
+        if C.numel():
+            C.sub_(A @ B.T)
+
+    def solve_lower_vec(self, L, dinv, v):
+        return torch.linalg.solve_triangular(torch.tril(L), v.reshape(-1, 1), upper=False).reshape(-1)
+
+    def matvec(self, A, v):
+        return A @ v
+
+    def sum_log_diag(self, L):
+        return float(torch.log(torch.diagonal(L)).sum())

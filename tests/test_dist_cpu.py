@@ -1,0 +1,166 @@
+"""Multi-process (gloo, CPU) tests of the N > 1 paths: xt-sharded prediction and the 2-D block-cyclic
+Cholesky / NLL schedule.  The local arithmetic is a torch-CPU stand-in (tests/cpu_local_ops.py); what is
+tested is the distributed host logic that the GPU path shares verbatim."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import gp_oracle as orc
+from tests.helpers import make_xz, theta_aniso
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _cov(x, y, t, pairwise=False):
+    return orc.maternp_covariance_it(np.asarray(x), np.asarray(y), 2, t, pairwise)
+
+
+def _chol_worker(rank, world, port, pr, pc, n, nb, out):
+    _init(rank, world, port)
+    try:
+        from gpmp_amd.dist import BlockCyclicCholesky, ProcessGrid
+        from tests.cpu_local_ops import CpuLocalOps
+
+        x, z = make_xz(n, 3, 7)
+        th = theta_aniso(3, scale=0.4)
+        nugget = 1e-6
+        grid = ProcessGrid(pr, pc)
+        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=CpuLocalOps())
+        ch.build_local_gram(_cov, x, th, nugget)
+        info = ch.factor()
+        nll = ch.negative_log_likelihood(z)
+        # reassemble the factor on rank 0 for comparison
+        ri, ci = ch.global_row_index(), ch.global_col_index()
+        payload = (ri, ci, ch.A.numpy().copy(), info, nll, ch.bytes_received)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, payload)
+        if rank == 0:
+            L = np.zeros((n, n))
+            for (r_i, c_i, a, _, _, _) in gathered:
+                if len(r_i) and len(c_i):
+                    L[np.ix_(r_i, c_i)] = a
+            np.save(out, np.tril(L))
+            np.save(out + ".meta.npy", np.array([info, nll, sum(g[5] for g in gathered)], dtype=np.float64))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pr,pc,n,nb", [(1, 2, 700, 128), (2, 1, 700, 128), (2, 2, 1000, 128), (2, 2, 1100, 256), (1, 4, 900, 128)])
+def test_block_cyclic_cholesky_and_nll(tmp_path, pr, pc, n, nb):
+    world = pr * pc
+    out = str(tmp_path / "L.npy")
+    mp.spawn(_chol_worker, args=(world, _free_port(), pr, pc, n, nb, out), nprocs=world, join=True)
+    L = np.load(out)
+    info, nll, recv = np.load(out + ".meta.npy")
+    x, z = make_xz(n, 3, 7)
+    th = theta_aniso(3, scale=0.4)
+    K = orc.maternp_covariance_it(x, x, 2, th) + 1e-6 * np.eye(n)
+    Lref = np.linalg.cholesky(K)
+    assert info == 0
+    assert np.max(np.abs(L - Lref)) / np.max(np.abs(Lref)) < 1e-9
+    w = np.linalg.solve(Lref, z)
+    ref_nll = 0.5 * (n * math.log(2 * math.pi) + 2 * np.sum(np.log(np.diag(Lref))) + w @ w)
+    assert abs(nll - ref_nll) < 1e-9 * abs(ref_nll)
+    assert recv > 0   # panels really travelled
+
+
+def _nonpd_worker(rank, world, port, out):
+    _init(rank, world, port)
+    try:
+        from gpmp_amd.dist import BlockCyclicCholesky, ProcessGrid
+        from tests.cpu_local_ops import CpuLocalOps
+
+        n = 512
+        grid = ProcessGrid(1, 2)
+        ch = BlockCyclicCholesky(grid, n, nb=128, ops=CpuLocalOps())
+        A = np.eye(n)
+        A[300, 300] = -1.0
+        ch.set_local(torch.as_tensor(A[np.ix_(ch.global_row_index(), ch.global_col_index())].copy()))
+        info = ch.factor()
+        nll = ch.negative_log_likelihood(np.ones(n))
+        if rank == 0:
+            np.save(out, np.array([info, nll]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_block_cyclic_not_positive_definite(tmp_path):
+    out = str(tmp_path / "r.npy")
+    mp.spawn(_nonpd_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    info, nll = np.load(out)
+    assert info == 301 and math.isinf(nll)      # LAPACK-style 1-based leading minor; criterion -> +inf
+
+
+class _OracleBackedModel:
+    """predict() with the reference semantics, computed by the CPU oracle (stand-in for gpmp_amd.Model)."""
+
+    def __init__(self, th):
+        self.m = orc.OracleModel(None, lambda x, y, t, pairwise=False: orc.maternp_covariance(x, y, 2, t, pairwise), None, th, "zero")
+
+    def predict(self, xi, zi, xt):
+        if xt.shape[0] == 0:
+            return np.zeros(0), np.zeros(0)
+        return orc.predict(self.m, xi, zi, xt)
+
+
+def _predict_worker(rank, world, port, m, out):
+    _init(rank, world, port)
+    try:
+        from gpmp_amd.dist import sharded_predict, shard_bounds
+
+        xi, zi = make_xz(200, 3, 1)
+        xt, _ = make_xz(m, 3, 2)
+        zpm, zpv, (lo, hi) = sharded_predict(_OracleBackedModel(theta_aniso(3)), xi, zi, xt)
+        assert (lo, hi) == shard_bounds(m, world, rank)
+        if rank == world - 1:
+            np.save(out, np.stack([zpm, zpv]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,m", [(2, 101), (3, 7), (2, 1)])
+def test_sharded_predict_matches_single_process(tmp_path, world, m):
+    out = str(tmp_path / "p.npy")
+    mp.spawn(_predict_worker, args=(world, _free_port(), m, out), nprocs=world, join=True)
+    got = np.load(out)
+    xi, zi = make_xz(200, 3, 1)
+    xt, _ = make_xz(m, 3, 2)
+    ref = _OracleBackedModel(theta_aniso(3)).predict(xi, zi, xt)
+    np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(got[1], ref[1], rtol=0, atol=1e-12)
+
+
+def test_shard_bounds_cover_and_balance():
+    from gpmp_amd.dist import shard_bounds
+
+    for m in (0, 1, 7, 50000, 50001):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(m, world, r) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == m
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_grid_shapes():
+    from gpmp_amd.dist import ProcessGrid
+
+    assert ProcessGrid.default_shape(8) == (2, 4)
+    assert ProcessGrid.default_shape(4) == (2, 2)
+    assert ProcessGrid.default_shape(2) == (1, 2)
+    assert ProcessGrid.default_shape(1) == (1, 1)

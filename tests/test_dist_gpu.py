@@ -1,0 +1,76 @@
+"""GPU tests of the distributed layer with the real local arithmetic (HipLocalOps through the C ABI).
+Ranks share the single test GPU and talk over gloo (RCCL needs one GPU per rank); the schedule and the
+kernels are the ones the 8-GPU run uses."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gp_oracle as orc
+from tests.helpers import make_xz, theta_aniso
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, pr, pc, n, nb, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gpmp_amd.num as gnp
+        from gpmp_amd.dist import BlockCyclicCholesky, HipLocalOps, ProcessGrid
+        from gpmp_amd.kernel import MaternCovariance
+
+        x, z = make_xz(n, 4, 11)
+        th = theta_aniso(4, scale=0.5)
+        cov = MaternCovariance(2)
+        nugget = 10.0 * math.exp(th[0]) * gnp.eps
+        grid = ProcessGrid(pr, pc)
+        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=HipLocalOps())
+        ch.build_local_gram(cov, x, th, nugget)
+        info = ch.factor()
+        nll = ch.negative_log_likelihood(z)
+        payload = (ch.global_row_index(), ch.global_col_index(), gnp.to_np(ch.A).copy(), info, nll)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, payload)
+        if rank == 0:
+            L = np.zeros((n, n))
+            for (r_i, c_i, a, _, _) in gathered:
+                if len(r_i) and len(c_i):
+                    L[np.ix_(r_i, c_i)] = a
+            np.save(out, np.tril(L))
+            np.save(out + ".meta.npy", np.array([info, nll], dtype=np.float64))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pr,pc,n,nb", [(1, 1, 1500, 512), (1, 2, 1500, 256), (2, 2, 2000, 256)])
+def test_block_cyclic_cholesky_hip(tmp_path, pr, pc, n, nb):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+
+    world = pr * pc
+    out = str(tmp_path / "L.npy")
+    mp.spawn(_worker, args=(world, _free_port(), pr, pc, n, nb, out), nprocs=world, join=True)
+    L = np.load(out)
+    info, nll = np.load(out + ".meta.npy")
+    x, z = make_xz(n, 4, 11)
+    th = theta_aniso(4, scale=0.5)
+    K = orc.maternp_covariance(x, None, 2, th)
+    Lref = np.linalg.cholesky(K)
+    assert info == 0
+    assert np.max(np.abs(L @ L.T - K)) / np.max(np.abs(K)) < 1e-13
+    om = orc.OracleModel(None, lambda a, b, t, pairwise=False: orc.maternp_covariance(a, b, 2, t, pairwise), None, th, "zero")
+    ref = float(orc.negative_log_likelihood_zero_mean(om, th, x, z))
+    assert abs(nll - ref) < 1e-8 * abs(ref)
