@@ -40,6 +40,25 @@ def synth(n, m, d, rank):
     return xi, zi, xt, theta
 
 
+def pmc_traffic_per_launch(kernel_substr):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r1/bench_v2_pmc_{fetch,write}_size_by_kernel.csv; FETCH_SIZE / WRITE_SIZE are in KB and, on gfx950,
+    FETCH_SIZE reports half of a wide streaming read -- MI355X_MICROARCH.md, HBM section).  None if absent."""
+    import csv
+
+    tot = 0.0
+    n_disp = None
+    for name, factor in (("fetch", 2.0), ("write", 1.0)):
+        path = os.path.join(ROOT, "profiles", "r1", f"bench_v2_pmc_{name}_size_by_kernel.csv")
+        if not os.path.exists(path):
+            return None
+        for row in csv.DictReader(open(path)):
+            if kernel_substr in row["kernel"]:
+                tot += factor * 1024.0 * float(row["per_dispatch_KB_raw"])
+                n_disp = int(row["dispatches"])
+    return tot if n_disp else None
+
+
 def cpu_baseline(n, m, d, threads):
     """The oracle (NumPy/SciPy restatement of the reference's NumPy backend) timed on the host cores."""
     from oracle import gp_oracle as orc
@@ -122,6 +141,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- outside the timed region: the Cholesky alone (BASELINE metric also quotes potrf TFLOP/s)
+    potrf_ms = None
+    if rank == 0:
+        cov = model.covariance
+
+        def _timed(fn, reps=2):
+            best = float("inf")
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t_)
+            return best
+
+        t_gram = _timed(lambda: cov.gram_lower(xi, theta))
+        t_both = _timed(lambda: gnp.cholesky_factor(cov.gram_lower(xi, theta), overwrite=True))
+        potrf_ms = 1e3 * (t_both - t_gram)
+
     zpm, zpv, nll = out
     assert bool(torch.isfinite(zpm).all()) and bool((zpv >= 0).all()) and math.isfinite(float(nll))
 
@@ -142,17 +180,21 @@ def main():
             "achieved": alg_nn / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else None,
             "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": (alg_nn / (nn_ms * 1e-3) / 1e12) / FP64_MFMA_PEAK_TFLOPS if nn_ms > 0 else None,
-            "traffic": None,
+            "traffic": pmc_traffic_per_launch("gemm_f64_kernel<true, false, true>") if (n, m) == (32768, 50000) else None,
+            "traffic_note": "bytes per launch at the fabric side of L2 (Infinity-Cache hits included), from the committed "
+                            "PMC passes in profiles/r1/ (FETCH_SIZE x2 + WRITE_SIZE); MFMA-bound kernel, 36 flop per such byte",
             "launches_per_step": nn_cnt / steps, "avg_launch_ms": nn_ms / max(nn_cnt, 1),
             "algorithmic_flops_per_launch": alg_nn / max(nn_cnt, 1),
             "executed_tflops": nn_exec / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else None,
         }
         gram_cnt, gram_ms, gram_bytes = prof[5]
         extra = {
-            "potrf_gemm_nt": {"algorithmic_tflops": alg_nt / (nt_ms * 1e-3) / 1e12 if nt_ms > 0 else None,
-                              "executed_tflops": nt_exec / (nt_ms * 1e-3) / 1e12 if nt_ms > 0 else None,
-                              "ms_per_step": nt_ms / steps, "launches_per_step": nt_cnt / steps},
-            "potf2_diag_blocks": {"ms_per_step": prof[4][1] / steps, "launches_per_step": prof[4][0] / steps},
+            "potrf": {"n": n, "ms": potrf_ms, "tflops": (float(n) ** 3 / 3.0) / (potrf_ms * 1e-3) / 1e12,
+                      "frac_of_fp64_mfma_peak": (float(n) ** 3 / 3.0) / (potrf_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                      "note": "whole factorisation (diagonal blocks + panels + trailing updates), wall time outside the timed region"},
+            "potrf_gemm_nt_events": {"sum_of_spans_ms_per_step": nt_ms / steps, "launches_per_step": nt_cnt / steps,
+                                     "note": "look-ahead overlaps panel and trailing kernels on two streams: spans are not additive"},
+            "potf2_diag_blocks": {"sum_of_spans_ms_per_step": prof[4][1] / steps, "launches_per_step": prof[4][0] / steps},
             "gram": {"ms_per_step": gram_ms / steps, "GBps_written": gram_bytes / (gram_ms * 1e-3) / 1e9 if gram_ms > 0 else None,
                      "frac_of_hbm_peak": (gram_bytes / (gram_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if gram_ms > 0 else None},
             "coldots": {"ms_per_step": prof[6][1] / steps},

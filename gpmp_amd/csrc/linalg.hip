@@ -354,29 +354,6 @@ extern "C" int gpmp_trsm_lower(const double* L, int n, long ldl, const double* d
     dinv = scratch;
   }
   if (m <= 4) return trsv_few(L, n, ldl, dinv, B, m, ldb, trans, st);   // HBM-bound fused sweep
-  if (m >= 4096 && n > OUTER_BLOCKS * NB) {
-    // Columns are independent: solve the two halves on two streams so the latency-bound diagonal-block
-    // steps of one half overlap the large GEMM updates of the other.
-    if (g_la.helper == nullptr) {
-      int lo = 0, hi = 0;
-      GPMP_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      GPMP_HIP_TRY(hipStreamCreateWithPriority(&g_la.helper, hipStreamNonBlocking, hi));
-    }
-    hipStream_t s1 = g_la.helper;
-    g_la.used = 0;
-    const int m0 = ((m / 2 + NB - 1) / NB) * NB;
-    hipEvent_t e0 = g_la.next(), e1 = g_la.next();
-    GPMP_HIP_TRY(hipEventRecord(e0, st));
-    GPMP_HIP_TRY(hipStreamWaitEvent(s1, e0, 0));
-    int rc = trans ? trsm_backward(L, n, ldl, dinv, B + m0, m - m0, ldb, s1)
-                   : trsm_forward(L, n, ldl, dinv, B + m0, m - m0, ldb, 0, 0, s1);
-    if (rc) return rc;
-    GPMP_HIP_TRY(hipEventRecord(e1, s1));
-    rc = trans ? trsm_backward(L, n, ldl, dinv, B, m0, ldb, st) : trsm_forward(L, n, ldl, dinv, B, m0, ldb, 0, 0, st);
-    if (rc) return rc;
-    GPMP_HIP_TRY(hipStreamWaitEvent(st, e1, 0));
-    return 0;
-  }
   return trans ? trsm_backward(L, n, ldl, dinv, B, m, ldb, st) : trsm_forward(L, n, ldl, dinv, B, m, ldb, 0, 0, st);
 }
 
