@@ -54,6 +54,8 @@ struct GemmOpts {
   int lower_only = 0;
   int kstart_row = 0;
   int kend_row = 0;
+  int kstart_col = 0;       // B(l, j) = 0 for l < j - kstart_col_off (B lower triangular after an offset)
+  int kstart_col_off = 0;
 };
 int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, long lda,
                 const double* B, long ldb, double beta, double* C, long ldc, const GemmOpts& o,

@@ -36,6 +36,7 @@ struct GemmParams {
   int M, N, K;
   double alpha, beta;
   int lower_only, kstart_row, kend_row;
+  int kstart_col, kstart_col_off;   // k loop of tile column j starts at max(0, col0(j) - off)
   int tiles_m, tiles_n, ntiles;
   int aligned;  // 16-byte loads allowed on A and B
 };
@@ -47,7 +48,9 @@ __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& t
   const int q = nwg / NXCD, r = nwg % NXCD;
   const int xcd = bid % NXCD;
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  const int v = base + bid / NXCD;
+  // tiles of unequal cost (triangular k ranges) are dealt round-robin instead: a contiguous chunk per
+  // XCD would hand one XCD all the long tiles (measured on lauum: 29 -> 50+ TFLOP/s)
+  const int v = (p.kstart_row | p.kend_row | p.kstart_col) ? bid : base + bid / NXCD;
   if (p.lower_only) {
     const int tn = p.tiles_n < p.tiles_m ? p.tiles_n : p.tiles_m;
     const int t1 = tn * (tn + 1) / 2;
@@ -172,6 +175,10 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmParams p) {
   const int lr = lane & 15, lk = lane >> 4;
 
   int kbeg = p.kstart_row ? row0 : 0;
+  if (p.kstart_col) {
+    const int kb = (col0 - p.kstart_col_off) & ~(BK - 1);
+    if (kb > kbeg) kbeg = kb;
+  }
   int kend = p.K;
   if (p.kend_row && row0 + BM < kend) kend = row0 + BM;
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
@@ -318,7 +325,7 @@ int launch_t(const GemmParams& p, hipStream_t st) {
   }
   {
     // executed flops of this launch (tiles actually visited, k range actually swept)
-    const double kavg = (p.kstart_row || p.kend_row) ? 0.5 * p.K : (double)p.K;
+    const double kavg = (p.kstart_row || p.kend_row || p.kstart_col) ? 0.5 * p.K : (double)p.K;
     ProfScope ps(AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN), st,
                  2.0 * (double)p.ntiles * BM * BN * kavg);
     hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC, CACC>), dim3(p.ntiles), dim3(256), lds, st, p);
@@ -345,6 +352,7 @@ int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const d
   p.M = M; p.N = N; p.K = K;
   p.alpha = alpha; p.beta = beta;
   p.lower_only = o.lower_only; p.kstart_row = o.kstart_row; p.kend_row = o.kend_row;
+  p.kstart_col = o.kstart_col; p.kstart_col_off = o.kstart_col_off;
   p.tiles_m = (M + BM - 1) / BM;
   p.tiles_n = (N + BN - 1) / BN;
   if (o.lower_only) {

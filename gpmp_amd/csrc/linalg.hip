@@ -288,8 +288,10 @@ int trsm_forward(const double* L, int n, long ldl, const double* dinv, double* B
   int rc = trsm_forward(L, n1, ldl, dinv, B, m, ldb, tri, tri_off, st);
   if (rc) return rc;
   GemmOpts plain;
-  // B2 -= L21 * X1 ; with tri, X1 is non-zero only in its first tri_off + n1 columns
+  // B2 -= L21 * X1 ; with tri, X1 is non-zero only in its first tri_off + n1 columns and X1[l][c] = 0 for
+  // l < c - tri_off (lower triangular after the dense tri_off columns): column tiles skip those k.
   const int ncol = tri ? imin(m, tri_off + n1) : m;
+  if (tri) { plain.kstart_col = 1; plain.kstart_col_off = tri_off; }
   rc = launch_gemm(true, false, n - n1, ncol, n1, -1.0, L + (long)n1 * ldl, ldl, B, ldb, 1.0, B + (long)n1 * ldb, ldb,
                    plain, st);
   if (rc) return rc;

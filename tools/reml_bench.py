@@ -52,3 +52,23 @@ t0 = time.perf_counter()
 r = minimize(f, theta0, jac=grad, method="L-BFGS-B", options=dict(maxfun=a.evals, maxcor=20, ftol=1e-6, gtol=1e-5, maxls=40))
 torch.cuda.synchronize()
 print(f"  L-BFGS-B (maxfun={a.evals}): {len(hist)} evals in {time.perf_counter()-t0:.2f} s, criterion {hist[0]:.4f} -> {r.fun:.4f}, status: {r.message}")
+
+# ---- breakdown of one gradient evaluation
+from gpmp_amd.core import gradients as G
+from gpmp_amd.core.linalg import covariance_factor, MeanSpace
+def tm(fn, reps=3):
+    fn(); torch.cuda.synchronize(); best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize(); s = time.perf_counter(); r = fn(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - s)
+    return best * 1e3, r
+th = thetas[0]
+t, F = tm(lambda: covariance_factor(model, xi_t, th)); print(f"  gram_lower + potrf: {t:.1f} ms")
+if a.criterion == "reml":
+    P = constant_mean(xi_t, None)
+    t, ms = tm(lambda: MeanSpace(F, zi_t, P)); print(f"  MeanSpace (L^-1 [z,P], Gram of W): {t:.1f} ms")
+    t, X = tm(lambda: F.solve_lower(ms.W, trans=True)); print(f"  L^-T W (2 cols): {t:.1f} ms")
+t, T = tm(lambda: F.inverse_factor()); print(f"  trtri: {t:.1f} ms")
+t, Kinv = tm(lambda: F.inverse_lower(T)); print(f"  lauum: {t:.1f} ms")
+alpha = F.solve(zi_t).reshape(-1, 1)
+t, g = tm(lambda: G._grad_trace(model.covariance, Kinv, xi_t, th, alpha, alpha)); print(f"  grad_trace (r=1): {t:.1f} ms  ({4*n*n/t/1e9:.2f} TB/s of K^-1 lower read)")
+t, _ = tm(lambda: F.logdet()); print(f"  logdet: {t:.2f} ms")
