@@ -16,6 +16,7 @@
 //      C/D register r of lane l: row = (l >> 4) + 4 r, col = l & 15.
 //  * blockIdx -> tile map is XCD aware: each XCD (own L2) gets a contiguous run of tiles.
 #include "common.h"
+#include <cstdlib>
 
 namespace gpmp {
 
@@ -314,21 +315,198 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmParams p) {
   }
 }
 
+// ================================================================================================
+// v2 main loop: operands go HBM -> LDS directly (buffer_load ... lds, no staging registers, no
+// ds_write), into UNPADDED images whose bank conflicts are removed by an XOR swizzle applied on the
+// per-lane SOURCE offset and on the fragment reads (the LDS-DMA destination is lane-linear):
+//   k-contiguous operand  [128 rows][16 k]:   16-byte slot s of row r holds k pair  s ^ ((r >> 1) & 7)
+//   m/n-contiguous operand [16 k][128 cols]:  16-byte slot s of k-row k holds column pair  s ^ ((k & 1) << 3)
+// The barrier of each k-tile sits between k-steps 2 and 3: after it the fragments of the NEXT tile's
+// k-steps 0,1 are fetched from LDS while the 16 MFMAs of k-step 3 (fragments already in registers)
+// keep the matrix pipe busy, so no ds_read latency is exposed after the barrier.
+// Full tiles only (M, N multiples of 128, k range a multiple of 16, 16-byte aligned operands).
+constexpr int V2_TILE = 2048;   // doubles per operand image (unpadded)
+
+template <bool KC>
+__device__ __forceinline__ int v2_frag_addr(int idx, int k) {
+  if constexpr (KC) return idx * 16 + 2 * ((k >> 1) ^ ((idx >> 1) & 7)) + (k & 1);
+  else return k * 128 + 2 * ((idx >> 1) ^ ((k & 1) << 3)) + (idx & 1);
+}
+
+template <bool AKC, bool BKC, bool CACC>
+__global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // [2 buffers][A image | B image] = 64 KB
+  int ti, tj;
+  decode_tile(p, blockIdx.x, ti, tj);
+  ti = __builtin_amdgcn_readfirstlane(ti);
+  tj = __builtin_amdgcn_readfirstlane(tj);
+  const int row0 = ti * BM, col0 = tj * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int lr = lane & 15, lk = lane >> 4;
+
+  int kbeg = p.kstart_row ? row0 : 0;
+  if (p.kstart_col) {
+    const int kb = (col0 - p.kstart_col_off) & ~(BK - 1);
+    if (kb > kbeg) kbeg = kb;
+  }
+  int kend = p.K;
+  if (p.kend_row && row0 + BM < kend) kend = row0 + BM;
+  const int nk = kend > kbeg ? (kend - kbeg) / BK : 0;
+
+  // ---- accumulators (start from (beta/alpha) C, see v1)
+  const double alpha = p.alpha, beta = p.beta;
+  double* __restrict__ cbase = p.C + (long)row0 * p.ldc + col0;
+  const unsigned lane_off = (unsigned)((wm + lk) * (int)p.ldc + wn + lr);
+  d4 acc[4][4];
+  if constexpr (CACC) {
+    const double sc = beta / alpha;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j][r] = sc * rp[lane_off + j * 16];
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  }
+
+  // ---- per-lane source offsets (bytes), two variants each (they depend on s & 1 only)
+  int voffA[2], voffB[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if constexpr (AKC) voffA[h] = ((lane >> 3) * (int)p.lda + 2 * ((lane & 7) ^ ((h * 4 + (lane >> 4)) & 7))) * 8;
+    else voffA[h] = 2 * (lane ^ (h << 3)) * 8;
+    if constexpr (BKC) voffB[h] = ((lane >> 3) * (int)p.ldb + 2 * ((lane & 7) ^ ((h * 4 + (lane >> 4)) & 7))) * 8;
+    else voffB[h] = 2 * (lane ^ (h << 3)) * 8;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  auto issue = [&](int kt, int buf) {
+    const int k0 = kbeg + kt * BK;
+    double* sa = smem + buf * 2 * V2_TILE;
+    double* sb = sa + V2_TILE;
+    if constexpr (AKC) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.A + (long)row0 * p.lda), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sa + (wave * 32 + s * 8) * 16), 16, voffA[s & 1],
+                                                 ((wave * 32 + s * 8) * (int)p.lda + k0) * 8, 0, 0);
+    } else {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.A + (long)k0 * p.lda + row0), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sa + (wave * 4 + s) * 128), 16, voffA[s & 1],
+                                                 ((wave * 4 + s) * (int)p.lda) * 8, 0, 0);
+    }
+    if constexpr (BKC) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.B + (long)col0 * p.ldb), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sb + (wave * 32 + s * 8) * 16), 16, voffB[s & 1],
+                                                 ((wave * 32 + s * 8) * (int)p.ldb + k0) * 8, 0, 0);
+    } else {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.B + (long)k0 * p.ldb + col0), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sb + (wave * 4 + s) * 128), 16, voffB[s & 1],
+                                                 ((wave * 4 + s) * (int)p.ldb) * 8, 0, 0);
+    }
+  };
+
+  double fa[4][4], fb[4][4];   // [k-step][fragment], statically indexed after unrolling
+  auto read_frags = [&](int ks, int buf) {
+    const double* sa = smem + buf * 2 * V2_TILE;
+    const double* sb = sa + V2_TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[ks][i] = sa[v2_frag_addr<AKC>(wm + i * 16 + lr, ks * 4 + lk)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[ks][j] = sb[v2_frag_addr<BKC>(wn + j * 16 + lr, ks * 4 + lk)];
+  };
+  auto mfma_step = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+  };
+
+  if (nk > 0) {
+    issue(0, 0);
+    __syncthreads();
+    read_frags(0, 0);
+    read_frags(1, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const bool more = kt + 1 < nk;
+      if (more) issue(kt + 1, cur ^ 1);
+      // at most three k-steps of fragments are live at any point (48 VGPRs)
+      read_frags(2, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(3, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(1);
+      mfma_step(2);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();   // next tile landed (vmcnt(0) of every wave) and buffer `cur` is free for tile kt+2
+      if (more) {
+        read_frags(0, cur ^ 1);
+        read_frags(1, cur ^ 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(3);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double v = alpha * acc[i][j][r];
+        if constexpr (!CACC) { if (beta != 0.0) v += beta * rp[lane_off + j * 16]; }
+        rp[lane_off + j * 16] = v;
+      }
+    }
+}
+
 template <bool AKC, bool BKC, bool CACC>
 int launch_t(const GemmParams& p, hipStream_t st) {
   static bool attr_done = false;
-  const size_t lds = sizeof(double) * 4 * TILE;  // 73,728 B
+  const size_t lds = sizeof(double) * 4 * TILE;        // v1: 73,728 B
+  const size_t lds2 = sizeof(double) * 4 * V2_TILE;    // v2: 65,536 B
   if (!attr_done) {
     GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<AKC, BKC, CACC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_v2<AKC, BKC, CACC>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     attr_done = true;
   }
+  static int use_v2 = -1;
+  if (use_v2 < 0) { const char* e = getenv("GPMP_GEMM_V2"); use_v2 = e ? atoi(e) : 1; }
+  // v2 (LDS-direct loads) handles full, aligned tiles only
+  // (v2 wins from K = 512 up: 94 % vs 88-92 % of peak at K = 4096; below that its longer fill costs more)
+  const bool v2ok = use_v2 && p.K >= 512 && p.aligned && (p.M % BM == 0) && (p.N % BN == 0) && (p.K % BK == 0) && p.K > 0 &&
+                    (p.lda % 2 == 0) && (p.ldb % 2 == 0) && (p.ldc >= p.N) &&
+                    ((long)BM * p.lda * 8 + (long)p.K * 8 < 0x7FFFFFFFL) && ((long)BN * p.ldb * 8 + (long)p.K * 8 < 0x7FFFFFFFL);
   {
     // executed flops of this launch (tiles actually visited, k range actually swept)
     const double kavg = (p.kstart_row || p.kend_row || p.kstart_col) ? 0.5 * p.K : (double)p.K;
     ProfScope ps(AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN), st,
                  2.0 * (double)p.ntiles * BM * BN * kavg);
-    hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC, CACC>), dim3(p.ntiles), dim3(256), lds, st, p);
+    if (v2ok) hipLaunchKernelGGL((gemm_f64_kernel_v2<AKC, BKC, CACC>), dim3(p.ntiles), dim3(256), lds2, st, p);
+    else hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC, CACC>), dim3(p.ntiles), dim3(256), lds, st, p);
   }
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
@@ -342,9 +520,9 @@ int launch_c(const GemmParams& p, hipStream_t st) {
 
 }  // namespace
 
-int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, long lda,
-                const double* B, long ldb, double beta, double* C, long ldc, const GemmOpts& o,
-                hipStream_t st) {
+static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, long lda,
+                           const double* B, long ldb, double beta, double* C, long ldc, const GemmOpts& o,
+                           hipStream_t st) {
   if (M <= 0 || N <= 0) return 0;
   GemmParams p;
   p.A = A; p.B = B; p.C = C;
@@ -367,6 +545,33 @@ int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const d
   if (a_kc && !b_kc) return launch_c<true, false>(p, st);
   if (!a_kc && !b_kc) return launch_c<false, false>(p, st);
   return launch_c<false, true>(p, st);
+}
+
+int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, long lda,
+                const double* B, long ldb, double beta, double* C, long ldc, const GemmOpts& o,
+                hipStream_t st) {
+  if (M <= 0 || N <= 0) return 0;
+  // The LDS-direct kernel takes full tiles only: peel a ragged last tile column / row off a large
+  // rectangular product so that everything else runs on it (e.g. m = 50000 prediction points).
+  const bool plain = !o.lower_only && !o.kstart_row && !o.kend_row && !o.kstart_col;
+  const int Nr = N % BN, Mr = M % BM;
+  if (plain && (Nr || Mr) && (K % BK == 0) && K >= 512 && (M >= 4 * BM || N >= 4 * BN) && C != A && C != B) {
+    const int Mf = M - Mr, Nf = N - Nr;
+    int rc = 0;
+    if (Mf > 0 && Nf > 0) rc = launch_gemm_one(a_kc, b_kc, Mf, Nf, K, alpha, A, lda, B, ldb, beta, C, ldc, o, st);
+    if (rc) return rc;
+    if (Nr > 0) {  // last columns, all rows
+      const double* Bn = b_kc ? B + (long)Nf * ldb : B + Nf;
+      rc = launch_gemm_one(a_kc, b_kc, M, Nr, K, alpha, A, lda, Bn, ldb, beta, C + Nf, ldc, o, st);
+      if (rc) return rc;
+    }
+    if (Mr > 0 && Nf > 0) {  // last rows, full-tile columns
+      const double* Am = a_kc ? A + (long)Mf * lda : A + Mf;
+      rc = launch_gemm_one(a_kc, b_kc, Mr, Nf, K, alpha, Am, lda, B, ldb, beta, C + (long)Mf * ldc, ldc, o, st);
+    }
+    return rc;
+  }
+  return launch_gemm_one(a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, o, st);
 }
 
 }  // namespace gpmp

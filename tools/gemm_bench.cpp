@@ -44,5 +44,6 @@ int main(int argc, char** argv) {
   if (which < 0 || which == 6) run("square TN K=4096", 1, 0, 8192, 8192, 4096, 0, 0.0, reps);
   if (which < 0 || which == 7) run("small NT L2-resident K=4096", 0, 1, 2048, 2048, 4096, 0, 0.0, reps);
   if (which < 0 || which == 8) run("panel scale N=128 K=128", 0, 1, 32640, 128, 128, 0, 0.0, reps);
+  if (which == 20) { for (int K : {128, 256, 512, 1024, 2048, 4096}) { run("NN beta=1 K sweep", 0, 0, 16384, 16384, K, 0, 1.0, reps); run("NN beta=0 K sweep", 0, 0, 16384, 16384, K, 0, 0.0, reps); } }
   return 0;
 }
