@@ -10,6 +10,7 @@
 // (gpmp/num/numpy_backend.py:465-469) and diag_Kinv_from_chol (gpmp/core/linalg.py:17-46).
 #include "common.h"
 #include <vector>
+#include <cstdlib>
 
 namespace gpmp {
 namespace {
@@ -197,29 +198,37 @@ struct LookAhead {
 };
 LookAhead g_la;
 
-int factor_panel(double* A, int n, long lda, double* dinv, int* info_dev, int ob, hipStream_t st) {
-  // panel = diagonal blocks ob .. ob+3: potf2 + panel scaling + rank-128 updates inside the panel
-  const int nblk = (n + NB - 1) / NB;
-  const int oe = imin(ob + OUTER_BLOCKS, nblk);
-  const int out_end = imin(oe * NB, n);
+// Factor the panel of columns [p0, p1) (p0, p1 multiples of NB; rows p0 .. n): diagonal blocks in LDS,
+// panel scaling, rank-128 updates inside 512-column sub-panels and rank-512 updates between them.
+int factor_panel(double* A, int n, long lda, double* dinv, int* info_dev, int p0, int p1, hipStream_t st) {
   GemmOpts lower, plain;
   lower.lower_only = 1;
-  for (int c = ob; c < oe; ++c) {
-    const int c0 = c * NB;
-    const int jb = imin(NB, n - c0);
-    double* dc = dinv + (size_t)c * NB * NB;
-    int rc = launch_potf2_inv(A + (long)c0 * lda + c0, lda, jb, dc, info_dev, c0, st);
-    if (rc) return rc;
-    const int r1 = c0 + jb;
-    const int mrem = n - r1;
-    if (mrem <= 0) break;
-    double* A21 = A + (long)r1 * lda + c0;
-    rc = launch_gemm(true, true, mrem, jb, jb, 1.0, A21, lda, dc, NB, 0.0, A21, lda, plain, st);
-    if (rc) return rc;
-    const int ncols_in = out_end - r1;
-    if (ncols_in > 0) {
-      rc = launch_gemm(true, true, mrem, ncols_in, jb, -1.0, A21, lda, A21, lda, 1.0, A + (long)r1 * lda + r1, lda,
-                       lower, st);
+  const int sub = OUTER_BLOCKS * NB;
+  for (int s0 = p0; s0 < p1; s0 += sub) {
+    const int s1 = imin(s0 + sub, p1);   // sub-panel [s0, s1)
+    for (int c0 = s0; c0 < s1; c0 += NB) {
+      const int jb = imin(NB, n - c0);
+      double* dc = dinv + (size_t)(c0 / NB) * NB * NB;
+      int rc = launch_potf2_inv(A + (long)c0 * lda + c0, lda, jb, dc, info_dev, c0, st);
+      if (rc) return rc;
+      const int r1 = c0 + jb;
+      const int mrem = n - r1;
+      if (mrem <= 0) return 0;
+      double* A21 = A + (long)r1 * lda + c0;
+      rc = launch_gemm(true, true, mrem, jb, jb, 1.0, A21, lda, dc, NB, 0.0, A21, lda, plain, st);
+      if (rc) return rc;
+      const int ncols_in = imin(s1, n) - r1;
+      if (ncols_in > 0) {
+        rc = launch_gemm(true, true, mrem, ncols_in, jb, -1.0, A21, lda, A21, lda, 1.0, A + (long)r1 * lda + r1, lda,
+                         lower, st);
+        if (rc) return rc;
+      }
+    }
+    const int rest_cols = imin(p1, n) - s1;   // remaining columns of this (wide) panel
+    if (rest_cols > 0) {
+      // A[s1:, s1:p1] -= A[s1:, s0:s1] A[s1:p1, s0:s1]^T
+      int rc = launch_gemm(true, true, n - s1, rest_cols, s1 - s0, -1.0, A + (long)s1 * lda + s0, lda,
+                           A + (long)s1 * lda + s0, lda, 1.0, A + (long)s1 * lda + s1, lda, lower, st);
       if (rc) return rc;
     }
   }
@@ -227,8 +236,18 @@ int factor_panel(double* A, int n, long lda, double* dinv, int* info_dev, int ob
 }
 
 int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hipStream_t s0) {
-  const int w = OUTER_BLOCKS * NB;
-  const int np = (n + w - 1) / w;
+  // panel boundaries: 1024-wide panels while the trailing matrix is large (rank-1024 updates run at
+  // ~89 % of the MFMA peak against ~84 % for rank-512, and the longer panel still hides behind them),
+  // 512-wide afterwards (shorter latency-bound tail)
+  static int wide_thresh = -1;
+  if (wide_thresh < 0) { const char* e = getenv("GPMP_POTRF_WIDE_ABOVE"); wide_thresh = e ? atoi(e) : 12288; }
+  std::vector<int> pb;
+  for (int p = 0; p < n;) {
+    pb.push_back(p);
+    p += (n - p > wide_thresh) ? 2 * OUTER_BLOCKS * NB : OUTER_BLOCKS * NB;
+  }
+  pb.push_back(n);
+  const int np = (int)pb.size() - 1;
   if (g_la.helper == nullptr) {
     int lo = 0, hi = 0;
     GPMP_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -242,21 +261,20 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   hipEvent_t e = g_la.next();
   GPMP_HIP_TRY(hipEventRecord(e, s0));
   GPMP_HIP_TRY(hipStreamWaitEvent(s1, e, 0));
-  int rc = factor_panel(A, n, lda, dinv, info_dev, 0, s1);
+  int rc = factor_panel(A, n, lda, dinv, info_dev, pb[0], pb[1], s1);
   if (rc) return rc;
   hipEvent_t e_f = g_la.next();                 // panel k factored (on s1)
   GPMP_HIP_TRY(hipEventRecord(e_f, s1));
   hipEvent_t e_u2 = nullptr;                    // trailing update k-1 finished (on s0)
   for (int k = 0; k + 1 < np; ++k) {
-    const int p0 = k * w;                       // panel k columns [p0, p1)
-    const int p1 = p0 + w;                      // next panel columns [p1, p2)
-    const int p2 = imin(p1 + w, n);
+    const int p0 = pb[k], p1 = pb[k + 1], p2 = pb[k + 2];   // panel k = [p0, p1), next panel = [p1, p2)
+    const int w = p1 - p0;
     // -- helper: update next panel's columns with P_k, then factor it
     if (e_u2) GPMP_HIP_TRY(hipStreamWaitEvent(s1, e_u2, 0));
     rc = launch_gemm(true, true, n - p1, p2 - p1, w, -1.0, A + (long)p1 * lda + p0, lda, A + (long)p1 * lda + p0, lda,
                      1.0, A + (long)p1 * lda + p1, lda, lower, s1);
     if (rc) return rc;
-    rc = factor_panel(A, n, lda, dinv, info_dev, (k + 1) * OUTER_BLOCKS, s1);
+    rc = factor_panel(A, n, lda, dinv, info_dev, p1, p2, s1);
     if (rc) return rc;
     hipEvent_t e_f_next = g_la.next();
     GPMP_HIP_TRY(hipEventRecord(e_f_next, s1));
