@@ -1,33 +1,41 @@
 // Diagonal-block kernel of the blocked Cholesky: factor one NB x NB (128 x 128) block and produce
-// the inverse of its triangular factor, entirely in LDS, by ONE workgroup of 8 waves.
+// the inverse of its triangular factor, by ONE workgroup of 8 waves, in 89 KB of LDS.
 //
-// The block is handled as 8 x 8 sub-blocks of 16 x 16 (the v_mfma_f64_16x16x4_f64 tile):
+// Why 89 KB: this kernel sits on the critical path of the look-ahead factorisation and runs while the
+// trailing-update GEMM fills the chip with two 64 KB workgroups per CU.  A 149 KB version (full
+// 128 x 130 image) had to wait for BOTH GEMM workgroups of one CU to retire together (measured: ~600 us
+// queueing for a 57 us kernel); 89 KB fits next to ONE resident GEMM workgroup (160 - 64 = 96 KB free).
+//
+// The block is handled as 8 x 8 sub-blocks of 16 x 16 (the v_mfma_f64_16x16x4_f64 tile).  Only the
+// 36 sub-blocks on/below the diagonal are stored, packed, each as an unpadded 16 x 16 image whose bank
+// conflicts are removed by an XOR swizzle of the column index (col ^ 2*((row>>1)&7)).
 //   phase A  for each of the 8 block columns j
-//     A1  wave 0 factors the 16 x 16 diagonal block in registers (one row per lane, pivots and
-//         column entries broadcast with v_readlane; 1/sqrt by v_rsq_f64 + Newton, no division)
-//     A2  panel rows below: X L_jj^T = A_panel by forward substitution, one row per lane
+//     A1  wave 0 factors the 16 x 16 diagonal block in registers (one row per lane, pivots and column
+//         entries broadcast with v_readlane; 1/sqrt by v_rsq_f64 + Newton, no division)
+//     A2  panel rows below: X L_jj^T = A_panel by forward substitution, one row per thread
 //     A3  trailing update A_ik -= L_ij L_kj^T on the MFMA pipe, one 16 x 16 block per wave at a time
-//   phase B  inverses of the 8 diagonal 16 x 16 factors, one per wave, in registers
-//   phase C  T = L^-1 by block forward substitution on MFMA:  T_ij = -T_ii sum_k L_ik T_kj ; the MFMA
-//            result layout (row = (lane>>4) + 4 r) IS the B-operand layout of the next MFMA, so the
-//            product with T_ii needs no LDS round trip.  T is kept transposed in the upper triangle.
-//   phase D  L -> global (lower triangle), T -> dinv (NB x NB row-major, zero above the diagonal)
-//
-// LDS image: S[128][130] doubles (row stride 130 makes the MFMA fragment reads conflict free),
-// dg[128] = 1 / L_ii, Td[8][16][18] = diagonal inverse blocks.  149 KB of the CU's 160 KB.
-//
-// The inverse is what turns every panel solve of the blocked algorithms into an MFMA GEMM
-// (X = A21 * inv(L11)^T), see linalg.hip.
+//   phase B  inverses of the 8 diagonal 16 x 16 factors, one per wave, in registers -> Td (LDS)
+//   phase C  T = L^-1 by block forward substitution, wave w owns block COLUMN w of T and keeps it in
+//            registers: T_iw = -T_ii sum_k L_ik T_kw.  The MFMA result layout (row = (lane>>4) + 4 r) IS
+//            the B-operand layout of the next MFMA, so neither the running sum nor T_kw ever touch LDS.
+//   phase D  L -> global (lower triangle); T -> dinv (NB x NB row-major, zero above the diagonal)
 #include "common.h"
 
 namespace gpmp {
 namespace {
 
-constexpr int LD = NB + 2;       // 130
 constexpr int SB = 16;           // sub-block edge
 constexpr int NSB = NB / SB;     // 8
-constexpr int TD_LD = 18;
+constexpr int NPACK = NSB * (NSB + 1) / 2;   // 36 stored sub-blocks
 constexpr int THREADS = 512;
+
+// packed offset of element (r, c) of the 128 x 128 block; requires (r >> 4) >= (c >> 4)
+__device__ __forceinline__ int pidx(int r, int c) {
+  const int bi = r >> 4, bk = c >> 4, rr = r & 15, cc = c & 15;
+  return ((bi * (bi + 1) / 2 + bk) << 8) + rr * 16 + (cc ^ (((rr >> 1) & 7) << 1));
+}
+// offset inside one 16 x 16 swizzled image
+__device__ __forceinline__ int sidx(int rr, int cc) { return rr * 16 + (cc ^ (((rr >> 1) & 7) << 1)); }
 
 __device__ __forceinline__ double bcast_lane(double x, int src) {
   int lo = __double2loint(x), hi = __double2hiint(x);
@@ -53,32 +61,33 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
   offset += blockIdx.x * NB;
   const int jb = (n_total - (int)blockIdx.x * NB) < NB ? (n_total - (int)blockIdx.x * NB) : NB;
 
-  extern __shared__ __attribute__((aligned(16))) double S[];   // [NB][LD]
-  double* dg = S + NB * LD;                                    // [NB]     1 / L_ii
-  double* Td = dg + NB;                                        // [NSB][SB][TD_LD]
+  extern __shared__ __attribute__((aligned(16))) double S[];   // [NPACK][16][16] packed lower block triangle
+  double* Td = S + NPACK * 256;                                // [NSB][16][16] diagonal inverse blocks
+  double* dg = Td + NSB * 256;                                 // [NB] 1 / L_ii
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lr = lane & 15, lk = lane >> 4;
 
-  // ---- load: lower triangle of the jb x jb block, identity padding, zeros above the diagonal
+  // ---- load: lower triangle of the jb x jb block, identity padding, zeros elsewhere
   for (int idx = t; idx < NB * NB; idx += THREADS) {
     const int i = idx >> 7, j = idx & (NB - 1);
+    if ((i >> 4) < (j >> 4)) continue;   // sub-block above the diagonal: not stored
     double v = (i == j) ? 1.0 : 0.0;
     if (i < jb && j <= i) v = A[(long)i * lda + j];
-    S[i * LD + j] = v;
+    S[pidx(i, j)] = v;
   }
   __syncthreads();
 
   if (do_factor) {
     for (int j = 0; j < NSB; ++j) {
       const int j0 = j * SB;
-      // ---- A1: diagonal 16 x 16 block, wave 0, row (j0 + lane) in registers of lane < 16
+      double* Djj = S + ((j * (j + 1) / 2 + j) << 8);   // diagonal sub-block image
+      // ---- A1: diagonal 16 x 16 block, wave 0, row (lane & 15) in registers
       if (wave == 0) {
         double a[SB];
-        const int row = j0 + (lane & 15);
 #pragma unroll
-        for (int c = 0; c < SB; ++c) a[c] = S[row * LD + j0 + c];
+        for (int c = 0; c < SB; ++c) a[c] = Djj[sidx(lr, c)];
 #pragma unroll
         for (int c = 0; c < SB; ++c) {
           double d = bcast_lane(a[c], c);
@@ -99,8 +108,7 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
         }
         if (lane < SB) {
 #pragma unroll
-          for (int c = 0; c < SB; ++c)
-            if (c <= lane) S[row * LD + j0 + c] = a[c];
+          for (int c = 0; c < SB; ++c) Djj[sidx(lr, c)] = (c <= lane) ? a[c] : 0.0;
         }
       }
       __syncthreads();
@@ -110,16 +118,16 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
         if (row < NB) {
           double x[SB];
 #pragma unroll
-          for (int c = 0; c < SB; ++c) x[c] = S[row * LD + j0 + c];
+          for (int c = 0; c < SB; ++c) x[c] = S[pidx(row, j0 + c)];
 #pragma unroll
           for (int c = 0; c < SB; ++c) {
             double s = x[c];
 #pragma unroll
-            for (int k = 0; k < c; ++k) s = fma(-x[k], S[(j0 + c) * LD + j0 + k], s);
+            for (int k = 0; k < c; ++k) s = fma(-x[k], Djj[sidx(c, k)], s);
             x[c] = s * dg[j0 + c];
           }
 #pragma unroll
-          for (int c = 0; c < SB; ++c) S[row * LD + j0 + c] = x[c];
+          for (int c = 0; c < SB; ++c) S[pidx(row, j0 + c)] = x[c];
         }
       }
       __syncthreads();
@@ -131,18 +139,21 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
           int bi = 0, acc_cnt = 0;
           while (acc_cnt + bi + 1 <= b) { acc_cnt += bi + 1; ++bi; }
           const int bk = b - acc_cnt;
-          const int i0 = (j + 1 + bi) * SB, k0 = (j + 1 + bk) * SB;
+          const int gi = j + 1 + bi, gk = j + 1 + bk;                       // global sub-block indices, gi >= gk
+          double* Cik = S + ((gi * (gi + 1) / 2 + gk) << 8);
+          const double* Lij = S + ((gi * (gi + 1) / 2 + j) << 8);
+          const double* Lkj = S + ((gk * (gk + 1) / 2 + j) << 8);
           d4 acc;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = S[(i0 + lk + 4 * r) * LD + k0 + lr];
+          for (int r = 0; r < 4; ++r) acc[r] = Cik[sidx(lk + 4 * r, lr)];
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const double af = -S[(i0 + lr) * LD + j0 + 4 * s + lk];   // -L_ij[row][k]
-            const double bf = S[(k0 + lr) * LD + j0 + 4 * s + lk];    // L_kj[col][k] = (L_kj^T)[k][col]
+            const double af = -Lij[sidx(lr, 4 * s + lk)];   // -L_ij[row][k]
+            const double bf = Lkj[sidx(lr, 4 * s + lk)];    // L_kj[col][k] = (L_kj^T)[k][col]
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) S[(i0 + lk + 4 * r) * LD + k0 + lr] = acc[r];
+          for (int r = 0; r < 4; ++r) Cik[sidx(lk + 4 * r, lr)] = acc[r];
         }
       }
       __syncthreads();
@@ -150,84 +161,91 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
     // factor back to global memory (lower triangle only)
     for (int idx = t; idx < NB * NB; idx += THREADS) {
       const int i = idx >> 7, j = idx & (NB - 1);
-      if (i < jb && j <= i) A[(long)i * lda + j] = S[i * LD + j];
+      if (i < jb && j <= i) A[(long)i * lda + j] = S[pidx(i, j)];
     }
   } else {
-    if (t < NB) dg[t] = 1.0 / S[t * LD + t];
+    if (t < NB) dg[t] = 1.0 / S[pidx(t, t)];
     __syncthreads();
   }
 
   // ---- phase B: T_ww = L_ww^-1 for the 8 diagonal 16 x 16 blocks, wave w, column (lane & 15) per lane
   {
-    const int w0 = wave * SB;
+    const double* Dww = S + ((wave * (wave + 1) / 2 + wave) << 8);
     double tc[SB];
     const int c = lane & 15;
 #pragma unroll
     for (int i = 0; i < SB; ++i) {
       double s = 0.0;
 #pragma unroll
-      for (int k = 0; k < i; ++k) s = fma(S[(w0 + i) * LD + w0 + k], tc[k], s);
-      const double ri = dg[w0 + i];
+      for (int k = 0; k < i; ++k) s = fma(Dww[sidx(i, k)], tc[k], s);
+      const double ri = dg[wave * SB + i];
       tc[i] = (c == i) ? ri : -ri * s;   // lanes with c > i get exactly 0 (all their t_k are 0)
     }
     if (lane < SB) {
 #pragma unroll
-      for (int i = 0; i < SB; ++i) Td[(wave * SB + i) * TD_LD + c] = tc[i];
+      for (int i = 0; i < SB; ++i) Td[(wave << 8) + sidx(i, c)] = tc[i];
     }
   }
   __syncthreads();
 
-  // ---- phase C: off-diagonal blocks of T by block rows;  T_ij = -T_ii * sum_{k=j}^{i-1} L_ik T_kj.
-  // T_kj (k > j) is stored transposed in the upper triangle: T[r][c] at S[c][r].
-  for (int bi = 1; bi < NSB; ++bi) {
-    const int i0 = bi * SB;
-    for (int bj = wave; bj < bi; bj += THREADS / 64) {
-      const int c0 = bj * SB;
-      d4 acc = {0.0, 0.0, 0.0, 0.0};
-      // k = bj term: B operand is the diagonal inverse block T_jj (from Td)
+  // ---- phase C + D: wave w computes block column w of T = L^-1, keeps it in registers, streams it out.
+  {
+    const int bj = wave;
+    d4 tcol[NSB];                 // tcol[i] = T_{i,bj} (MFMA C layout), i > bj
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double af = S[(i0 + lr) * LD + c0 + 4 * s + lk];                 // L_ij[row][k]
-        const double bf = Td[(bj * SB + 4 * s + lk) * TD_LD + lr];             // T_jj[k][col]
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
-      }
-      for (int bk = bj + 1; bk < bi; ++bk) {
-        const int k0 = bk * SB;
+    for (int bi = 1; bi < NSB; ++bi) {
+      if (bi > bj) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        // k = bj term: B operand is the diagonal inverse block T_jj (from Td)
+        {
+          const double* Lij = S + ((bi * (bi + 1) / 2 + bj) << 8);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const double af = Lij[sidx(lr, 4 * s + lk)];                    // L_ij[row][k]
+            const double bf = Td[(bj << 8) + sidx(4 * s + lk, lr)];         // T_jj[k][col]
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int bk = 1; bk < NSB; ++bk) {
+          if (bk > bj && bk < bi) {
+            const double* Lik = S + ((bi * (bi + 1) / 2 + bk) << 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const double af = Lik[sidx(lr, 4 * s + lk)];                  // L_ik[row][k]
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, tcol[bk][s], acc, 0, 0, 0);   // B = T_kj registers
+            }
+          }
+        }
+        // multiply by -T_ii: acc register r is exactly the B fragment of k-step r
+        d4 res = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const double af = S[(i0 + lr) * LD + k0 + 4 * s + lk];               // L_ik[row][k]
-          const double bf = S[(c0 + lr) * LD + k0 + 4 * s + lk];               // T_kj[k][col] = S[c0+col][k0+k]
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+          const double af = -Td[(bi << 8) + sidx(lr, 4 * s + lk)];          // -T_ii[row][k]
+          res = __builtin_amdgcn_mfma_f64_16x16x4f64(af, acc[s], res, 0, 0, 0);
         }
+        tcol[bi] = res;
       }
-      // multiply by -T_ii: acc register r is exactly the B fragment of k-step r
-      d4 res = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double af = -Td[(bi * SB + lr) * TD_LD + 4 * s + lk];            // -T_ii[row][k]
-        res = __builtin_amdgcn_mfma_f64_16x16x4f64(af, acc[s], res, 0, 0, 0);
-      }
-      // store T_ij transposed into the upper triangle: T_ij[row][col] -> S[c0 + col][i0 + row]
-#pragma unroll
-      for (int r = 0; r < 4; ++r) S[(c0 + lr) * LD + i0 + lk + 4 * r] = res[r];
     }
-    __syncthreads();
-  }
-
-  // ---- phase D: inverse to global memory (row-major NB x NB, zeros above the diagonal)
-  for (int idx = t; idx < NB * NB; idx += THREADS) {
-    const int i = idx >> 7, c = idx & (NB - 1);
-    double v = 0.0;
-    if ((i >> 4) == (c >> 4)) v = Td[i * TD_LD + (c & 15)];   // diagonal block (zeros above its diagonal)
-    else if (c < i) v = S[c * LD + i];
-    dinv[idx] = v;
+    // phase D: block column bj of dinv (row-major NB x NB): zeros above, Td on the diagonal, tcol below
+#pragma unroll
+    for (int bi = 0; bi < NSB; ++bi) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = bi * SB + lk + 4 * r, col = bj * SB + lr;
+        double v = 0.0;
+        if (bi == bj) v = Td[(bj << 8) + sidx(lk + 4 * r, lr)];
+        else if (bi > bj) v = tcol[bi][r];
+        dinv[row * NB + col] = v;
+      }
+    }
   }
 }
 
 int launch(double* A, long lda, int n_total, int nblocks, double* dinv, int* info_dev, int offset,
            int do_factor, hipStream_t st) {
   static bool attr_done = false;
-  const size_t lds = sizeof(double) * (NB * LD + NB + NSB * SB * TD_LD);
+  const size_t lds = sizeof(double) * (NPACK * 256 + NSB * 256 + NB);   // 91,136 B
   if (!attr_done) {
     GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
