@@ -33,7 +33,8 @@ inline hipStream_t as_stream(gpmp_stream_t s) { return reinterpret_cast<hipStrea
 // ---- opt-in per-kernel timing with HIP events on the launch stream (capi.cpp) -------------------
 // Kinds index the table returned by gpmp_profile_end().
 enum ProfKind { PK_GEMM_NT = 0, PK_GEMM_NN = 1, PK_GEMM_TN = 2, PK_GEMM_TT = 3, PK_POTF2 = 4, PK_GRAM = 5,
-                PK_COLDOTS = 6, PK_GRAD = 7, PK_COUNT = 8 };
+                PK_COLDOTS = 6, PK_GRAD = 7, PK_GEMM2_NT = 8, PK_GEMM2_NN = 9, PK_GEMM2_TN = 10, PK_GEMM2_TT = 11,
+                PK_COUNT = 12 };
 extern bool g_prof_on;
 void prof_start(int kind, hipStream_t st);
 void prof_stop(int kind, hipStream_t st, double work);

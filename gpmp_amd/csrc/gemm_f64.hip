@@ -503,7 +503,7 @@ int launch_t(const GemmParams& p, hipStream_t st) {
   {
     // executed flops of this launch (tiles actually visited, k range actually swept)
     const double kavg = (p.kstart_row || p.kend_row || p.kstart_col) ? 0.5 * p.K : (double)p.K;
-    ProfScope ps(AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN), st,
+    ProfScope ps((AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN)) + (v2ok ? 8 : 0), st,
                  2.0 * (double)p.ntiles * BM * BN * kavg);
     if (v2ok) hipLaunchKernelGGL((gemm_f64_kernel_v2<AKC, BKC, CACC>), dim3(p.ntiles), dim3(256), lds2, st, p);
     else hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC, CACC>), dim3(p.ntiles), dim3(256), lds, st, p);

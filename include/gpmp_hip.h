@@ -41,10 +41,11 @@ int gpmp_hip_abi_version(void);
 const char* gpmp_last_error(void);
 
 /* Opt-in kernel timing (HIP events recorded on the launch stream around every kernel launch of the
- * library).  gpmp_profile_end synchronises the recorded events and fills table_host[8][3] =
- * {launch count, total milliseconds, work} per kind: 0..3 GEMM variants NT / NN / TN / TT (work =
- * executed flops), 4 diagonal-block kernel (work = blocks), 5 Gram kernel (work = bytes written),
- * 6 column reductions (work = bytes read), 7 gradient trace.  Used by bench.py for `roofline`. */
+ * library).  gpmp_profile_end synchronises the recorded events and fills table_host[12][3] =
+ * {launch count, total milliseconds, work} per kind: 0..3 GEMM (register-staged kernel) NT / NN / TN / TT
+ * (work = executed flops), 4 diagonal-block kernel (work = blocks), 5 Gram kernel (work = bytes written),
+ * 6 column reductions (work = bytes read), 7 gradient trace, 8..11 GEMM (LDS-direct kernel
+ * gemm_f64_kernel_v2) NT / NN / TN / TT.  Used by bench.py for `roofline`. */
 int gpmp_profile_begin(void);
 int gpmp_profile_end(double* table_host);
 
