@@ -79,9 +79,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=32768)
-    ap.add_argument("--m", type=int, default=50000)
-    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--size-n", dest="n", type=int, default=32768)
+    ap.add_argument("--size-m", dest="m", type=int, default=50000)
+    ap.add_argument("--dim-d", dest="d", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=4096)
     ap.add_argument("--cpu-m", type=int, default=10000)
@@ -92,10 +92,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    torch.cuda.set_device(local_rank)
+    dist_on = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # launched by torch.distributed.run
+    if dist_on:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
@@ -117,7 +118,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -136,7 +137,7 @@ def main():
     lib.gpmp_profile_end(table)
     prof = np.array(list(table)).reshape(12, 3)
 
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=gnp._dev())
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -224,7 +225,7 @@ def main():
                 threads = os.cpu_count() or 1
             line["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_m, d, threads)
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

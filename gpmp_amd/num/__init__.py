@@ -69,8 +69,18 @@ def _is_linalg_exception(exc: Exception) -> bool:
 # ---------------------------------------------------------------------------------------------
 # array plumbing (torch is the container)
 # ---------------------------------------------------------------------------------------------
+_device_bound = False
+
+
 def _dev():
-    return get_device()
+    """Device of this process; the first call makes it the current HIP device (the library's helper stream,
+    events and kernel attributes are created on the current device)."""
+    global _device_bound
+    d = get_device()
+    if not _device_bound and d.type == "cuda":
+        torch.cuda.set_device(d)
+        _device_bound = True
+    return d
 
 
 def _stream():
