@@ -139,6 +139,148 @@ __global__ void __launch_bounds__(256) gram_kernel(GramParams p) {
   }
 }
 
+// ---- fp64 helpers tuned for this kernel (VALU-bound: fp64 exp + sqrt dominate the per-entry cost) ----
+// exp(-x) for x >= 0: k = rint(x log2 e), r = k ln2 - x in [-0.347, 0.347], degree-12 Taylor (remainder
+// 0.347^13 / 13! = 1.7e-16), scale by 2^-k.  < 1 ulp of libm on the tested range; exact 1 at x = 0.
+__device__ __forceinline__ double exp_neg(double x) {
+  const double kf = rint(x * 1.4426950408889634);
+  double r = fma(kf, 6.93147180369123816490e-01, -x);
+  r = fma(kf, 1.90821492927058770002e-10, r);
+  double p = 2.08767569878680989792e-09;            // 1/12!
+  p = fma(p, r, 2.50521083854417187751e-08);        // 1/11!
+  p = fma(p, r, 2.75573192239858906526e-07);
+  p = fma(p, r, 2.75573192239858906526e-06);
+  p = fma(p, r, 2.48015873015873015873e-05);
+  p = fma(p, r, 1.98412698412698412698e-04);
+  p = fma(p, r, 1.38888888888888888889e-03);
+  p = fma(p, r, 8.33333333333333333333e-03);
+  p = fma(p, r, 4.16666666666666666667e-02);
+  p = fma(p, r, 1.66666666666666666667e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const int k = (kf > 1100.0) ? 1100 : (int)kf;     // exp(-x) underflows to 0 well before
+  return ldexp(p, -k);
+}
+// sqrt(a) for a >= 0 from the hardware 1/sqrt estimate + one coupled Newton step + a residual correction.
+__device__ __forceinline__ double sqrt_pos(double a) {
+  const double y0 = __builtin_amdgcn_rsq(a);
+  double g = a * y0, h = 0.5 * y0;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double d = fma(-g, g, a);
+  g = fma(d, h, g);
+  return (a > 0.0) ? g : 0.0;    // a == 0: rsq = inf -> NaN above
+}
+
+template <int P>
+__device__ __forceinline__ double matern_fast(const MaternSpec& ms, double h) {
+  const double t = 2.0 * ms.c * h;
+  double poly;
+  if constexpr (P >= 0) {
+    poly = ms.q[P];
+#pragma unroll
+    for (int k = P - 1; k >= 0; --k) poly = poly * t + ms.q[k];
+  } else {
+    poly = ms.q[ms.p];
+    for (int k = ms.p - 1; k >= 0; --k) poly = poly * t + ms.q[k];
+  }
+  return exp_neg(ms.c * h) * poly;
+}
+
+// 128 x 64 output tile per 256-thread workgroup, 8 x 4 outputs per thread.
+template <int P>
+__global__ void __launch_bounds__(256) gram_kernel_v2(GramParams p) {
+  __shared__ __attribute__((aligned(16))) double xs[DC][128];
+  __shared__ __attribute__((aligned(16))) double ys[DC][GT];
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  const int row0 = ti * 128, col0 = tj * GT;
+  if (p.lower_only && col0 > row0 + 127) return;
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  const double* __restrict__ yp = p.same ? p.x : p.y;
+
+  double acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+
+  for (int k0 = 0; k0 < p.d; k0 += DC) {
+    if (k0) __syncthreads();
+    const int kc = (p.d - k0) < DC ? (p.d - k0) : DC;
+    // stage 128 rows of x and 64 rows of y (kc dims), scaled by 1/rho; consecutive threads walk k first
+    // (global reads contiguous along k), LDS stores scatter over rows
+    for (int idx = t; idx < 128 * kc; idx += 256) {
+      const int r = idx / kc, k = idx - r * kc;
+      xs[k][r] = (row0 + r < p.n) ? p.invrho[k0 + k] * p.x[(long)(row0 + r) * p.d + k0 + k] : 0.0;
+    }
+    for (int idx = t; idx < GT * kc; idx += 256) {
+      const int r = idx / kc, k = idx - r * kc;
+      ys[k][r] = (col0 + r < p.m) ? p.invrho[k0 + k] * yp[(long)(col0 + r) * p.d + k0 + k] : 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < kc; ++k) {
+      const d4 xa0 = *reinterpret_cast<const d4*>(&xs[k][ty * 8]);
+      const d4 xa1 = *reinterpret_cast<const d4*>(&xs[k][ty * 8 + 4]);
+      // this thread's columns: {2tx, 2tx+1, 32+2tx, 32+2tx+1} -> each 16-byte store below is contiguous
+      // with its 15 neighbours (256 B = two full 128-B lines per row and instruction)
+      const d2 y0 = *reinterpret_cast<const d2*>(&ys[k][2 * tx]);
+      const d2 y1 = *reinterpret_cast<const d2*>(&ys[k][32 + 2 * tx]);
+      const double yb[4] = {y0[0], y0[1], y1[0], y1[1]};
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double d0 = xa0[a] - yb[b], d1 = xa1[a] - yb[b];
+          acc[a][b] = fma(d0, d0, acc[a][b]);
+          acc[a + 4][b] = fma(d1, d1, acc[a + 4][b]);
+        }
+    }
+  }
+
+  const bool full = p.aligned && (row0 + 128 <= p.n) && (col0 + GT <= p.m);
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int row = row0 + ty * 8 + a;
+    double v[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = col0 + (b >> 1) * 32 + 2 * tx + (b & 1);
+      const double h = sqrt_pos(acc[a][b]);
+      double val = h;
+      if (p.mode == 0) {
+        val = p.sigma2 * matern_fast<P>(p.ms, h);
+        if (p.same && row == col) val += p.diag_add;
+      }
+      v[b] = val;
+    }
+    double* out = p.K + (long)row * p.ldk + col0 + 2 * tx;
+    if (full) {
+      *reinterpret_cast<d2*>(out) = (d2){v[0], v[1]};
+      *reinterpret_cast<d2*>(out + 32) = (d2){v[2], v[3]};
+    } else if (row < p.n) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int cc = (b >> 1) * 32 + 2 * tx + (b & 1);
+        if (col0 + cc < p.m) p.K[(long)row * p.ldk + col0 + cc] = v[b];
+      }
+    }
+  }
+}
+
+static int launch_gram(const GramParams& gp, hipStream_t st) {
+  dim3 grid((gp.m + GT - 1) / GT, (gp.n + 127) / 128);
+  switch (gp.mode == 0 ? gp.ms.p : 0) {
+    case 0: hipLaunchKernelGGL(gram_kernel_v2<0>, grid, dim3(256), 0, st, gp); break;
+    case 1: hipLaunchKernelGGL(gram_kernel_v2<1>, grid, dim3(256), 0, st, gp); break;
+    case 2: hipLaunchKernelGGL(gram_kernel_v2<2>, grid, dim3(256), 0, st, gp); break;
+    case 3: hipLaunchKernelGGL(gram_kernel_v2<3>, grid, dim3(256), 0, st, gp); break;
+    default: hipLaunchKernelGGL(gram_kernel_v2<-1>, grid, dim3(256), 0, st, gp); break;
+  }
+  return 0;
+}
+
 struct PairParams {
   const double* x;
   const double* y;
@@ -400,11 +542,10 @@ extern "C" int gpmp_matern_gram(const double* x, const double* y, int n, int m, 
   const int off = noise ? 2 : 1;
   for (int k = 0; k < d; ++k) gp.invrho[k] = std::exp(theta_host[off + k]);
   fill_matern(gp.ms, p);
-  dim3 grid((m + GT - 1) / GT, (n + GT - 1) / GT);
   {
     // work = algorithmic bytes written (8 per entry; lower_only writes about half)
     ProfScope ps(PK_GRAM, as_stream(stream), 8.0 * (double)n * (double)m * (gp.lower_only ? 0.5 : 1.0));
-    hipLaunchKernelGGL(gram_kernel, grid, dim3(256), 0, as_stream(stream), gp);
+    launch_gram(gp, as_stream(stream));
   }
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
@@ -425,8 +566,7 @@ extern "C" int gpmp_scaled_distance(const double* x, const double* y, int n, int
   gp.mode = 1; gp.sigma2 = 1.0; gp.diag_add = 0.0;
   for (int k = 0; k < d; ++k) gp.invrho[k] = std::exp(loginvrho_host[k]);
   fill_matern(gp.ms, 0);
-  dim3 grid((m + GT - 1) / GT, (n + GT - 1) / GT);
-  hipLaunchKernelGGL(gram_kernel, grid, dim3(256), 0, as_stream(stream), gp);
+  launch_gram(gp, as_stream(stream));
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -32,6 +32,7 @@ def timed(fn, reps=a.reps):
 t, K = timed(lambda: cov.gram_lower(xi, theta)); print(f"gram_lower n={n}: {t*1e3:8.2f} ms  {8*n*n/2/t/1e12:.2f} TB/s written")
 t, Kf = timed(lambda: cov(xi, None, theta)); print(f"gram_full  n={n}: {t*1e3:8.2f} ms  {8*n*n/t/1e12:.2f} TB/s written")
 t, Kit = timed(lambda: cov(xi, xt, theta)); print(f"gram_it n={n} m={m}: {t*1e3:8.2f} ms  {8*n*m/t/1e12:.2f} TB/s written")
+t, Dm = timed(lambda: gnp.scaled_distance(theta[1:], xi, xt)); print(f"scaled_distance n={n} m={m}: {t*1e3:8.2f} ms  {8*n*m/t/1e12:.2f} TB/s written"); del Dm
 def fac():
     Kc = cov.gram_lower(xi, theta)
     return gnp.cholesky_factor(Kc, overwrite=True)
