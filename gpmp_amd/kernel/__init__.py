@@ -16,7 +16,23 @@ from .parameter_selection import (
     negative_log_restricted_likelihood,
     select_parameters_with_criterion,
     select_parameters_with_reml,
+    select_parameters_with_remap,
+    select_parameters_with_remap_gaussian_logsigma2_and_logrho_prior,
+    select_parameters_with_remap_with_power_laws_prior,
 )
+from .prior_helpers import compute_logrho_min_from_xi
+from .priors import (
+    log_prior_gaussian_logsigma2,
+    log_prior_jeffreys_variance,
+    log_prior_logrho_barrier_linear,
+    log_prior_power_law,
+    neg_log_restricted_posterior_logsigma2_and_logrho_prior,
+    neg_log_restricted_posterior_logsigma2_prior,
+    neg_log_restricted_posterior_power_laws_prior,
+    neg_log_restricted_posterior_with_logrho_prior,
+    neglog_f_logrho,
+)
+from . import prior_defaults
 
 __all__ = [
     "MaternCovariance", "matern32_kernel", "maternp_kernel", "maternp_covariance",
@@ -24,5 +40,10 @@ __all__ = [
     "anisotropic_parameters_initial_guess", "anisotropic_parameters_initial_guess_zero_mean",
     "negative_log_likelihood_zero_mean", "negative_log_likelihood", "negative_log_restricted_likelihood",
     "make_selection_criterion_with_gradient", "autoselect_parameters",
-    "select_parameters_with_criterion", "select_parameters_with_reml",
+    "select_parameters_with_criterion", "select_parameters_with_reml", "select_parameters_with_remap",
+    "select_parameters_with_remap_gaussian_logsigma2_and_logrho_prior", "select_parameters_with_remap_with_power_laws_prior",
+    "compute_logrho_min_from_xi", "log_prior_gaussian_logsigma2", "log_prior_jeffreys_variance",
+    "log_prior_logrho_barrier_linear", "log_prior_power_law", "neglog_f_logrho",
+    "neg_log_restricted_posterior_logsigma2_and_logrho_prior", "neg_log_restricted_posterior_logsigma2_prior",
+    "neg_log_restricted_posterior_power_laws_prior", "neg_log_restricted_posterior_with_logrho_prior", "prior_defaults",
 ]

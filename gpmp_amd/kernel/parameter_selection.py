@@ -13,6 +13,8 @@ from scipy.optimize import minimize
 from .. import num as gnp
 from .init import anisotropic_parameters_initial_guess
 from .matern import MaternCovariance
+from .prior_helpers import resolve_covparam0_prior_and_init, resolve_logsigma2_logrho_prior_args
+from . import priors as _priors
 
 
 # criteria with the reference's call signatures (parameter_selection.py re-exports of core.likelihood)
@@ -32,6 +34,10 @@ def _analytic_for(model, selection_criterion, parameterized_mean):
     if parameterized_mean or not isinstance(model.covariance, MaternCovariance):
         return None
     from ..core import gradients as _gradients  # deferred: core imports kernel.matern
+
+    factory = getattr(selection_criterion, "_gpmp_analytic_factory", None)
+    if factory is not None:          # REML + host-side priors (REMAP): analytic REML gradient + prior gradient
+        return factory(model)
 
     if selection_criterion is negative_log_likelihood_zero_mean:
         return _gradients.MLZeroMeanAnalytic(model)
@@ -166,4 +172,86 @@ def select_parameters_with_reml(model, xi=None, zi=None, dataloader=None, covpar
     return select_parameters_with_criterion(model, negative_log_restricted_likelihood, xi=xi, zi=zi, dataloader=dataloader,
                                             covparam0=covparam0, info=info, verbosity=verbosity, bounds=bounds,
                                             bounds_auto=bounds_auto, bounds_delta=bounds_delta, method=method,
+                                            method_options=method_options)
+
+
+# ------------------------------------------------------------------------------------------------
+# REMAP: REML regularised by priors (gpmp/kernel/parameter_selection.py:867-1483).  The priors are O(d)
+# scalar terms on the host; value and gradient of the REML part come from the HIP path.
+# ------------------------------------------------------------------------------------------------
+class _RemapAnalytic:
+    """REML analytic value/gradient + (value, gradient) of a host-side negative log-prior."""
+
+    def __init__(self, model, neg_log_prior, grad_neg_log_prior):
+        from ..core import gradients as _gradients
+
+        self.reml = _gradients.REMLAnalytic(model)
+        self.nlp, self.gnlp = neg_log_prior, grad_neg_log_prior
+
+    def value_and_state(self, covparam, xi, zi):
+        prior = float(self.nlp(covparam))
+        if not np.isfinite(prior):
+            raise np.linalg.LinAlgError("prior support violated (treated like a singular matrix: criterion = +inf)")
+        value, state = self.reml.value_and_state(covparam, xi, zi)
+        return value + prior, (state, np.array(covparam, dtype=np.float64))
+
+    def gradient_from_state(self, state):
+        reml_state, covparam = state
+        return self.reml.gradient_from_state(reml_state) + self.gnlp(covparam)
+
+
+def select_parameters_with_remap_gaussian_logsigma2_and_logrho_prior(
+        model, xi=None, zi=None, dataloader=None, covparam0=None, info=False, verbosity=0, *, covparam0_prior=None,
+        prior_gamma=None, prior_sigma2_coverage=None, prior_rho_min_range_factor=None, prior_logrho_min=None,
+        prior_log_sigma2_0=None, prior_logrho_0=None, prior_alpha=None, covparam0_init=None, bounds=None,
+        bounds_auto=True, bounds_delta=10.0, method="SLSQP", method_options=None):
+    """gpmp/kernel/parameter_selection.py:1301-1483: REML - log p(log sigma^2) - log p(log rho)."""
+    covparam0_prior, covparam0_init = resolve_covparam0_prior_and_init(
+        model, xi=xi, zi=zi, dataloader=dataloader, covparam0=covparam0, covparam0_prior=covparam0_prior,
+        covparam0_init=covparam0_init)
+    (prior_gamma, prior_sigma2_coverage, prior_alpha, prior_rho_min_range_factor, prior_log_sigma2_0, prior_logrho_0,
+     prior_logrho_min) = resolve_logsigma2_logrho_prior_args(
+        covparam0_prior=covparam0_prior, xi=xi, dataloader=dataloader, prior_gamma=prior_gamma,
+        prior_sigma2_coverage=prior_sigma2_coverage, prior_alpha=prior_alpha,
+        prior_rho_min_range_factor=prior_rho_min_range_factor, prior_log_sigma2_0=prior_log_sigma2_0,
+        prior_logrho_0=prior_logrho_0, prior_logrho_min=prior_logrho_min)
+
+    def criterion(m, covparam, x, z):
+        return _priors.neg_log_restricted_posterior_logsigma2_and_logrho_prior(
+            m, covparam, x, z, log_sigma2_0=prior_log_sigma2_0, gamma=prior_gamma, sigma2_coverage=prior_sigma2_coverage,
+            logrho_min=prior_logrho_min, logrho_0=prior_logrho_0, alpha=prior_alpha)
+
+    def neg_log_prior(covparam):
+        return -(_priors.log_prior_gaussian_logsigma2(covparam, prior_log_sigma2_0, gamma=prior_gamma,
+                                                      sigma2_coverage=prior_sigma2_coverage)
+                 + _priors.log_prior_logrho_barrier_linear(covparam, logrho_min=prior_logrho_min, logrho_0=prior_logrho_0,
+                                                           alpha=prior_alpha))
+
+    def grad_neg_log_prior(covparam):
+        return (_priors.grad_neg_log_prior_gaussian_logsigma2(covparam, prior_log_sigma2_0, gamma=prior_gamma,
+                                                              sigma2_coverage=prior_sigma2_coverage)
+                + _priors.grad_neg_log_prior_logrho_barrier_linear(covparam, prior_logrho_min, prior_logrho_0,
+                                                                   alpha=prior_alpha))
+
+    criterion._gpmp_analytic_factory = lambda m: _RemapAnalytic(m, neg_log_prior, grad_neg_log_prior)
+    return select_parameters_with_criterion(model, criterion, xi=xi, zi=zi, dataloader=dataloader, covparam0=covparam0_init,
+                                            info=info, verbosity=verbosity, bounds=bounds, bounds_auto=bounds_auto,
+                                            bounds_delta=bounds_delta, method=method, method_options=method_options)
+
+
+def select_parameters_with_remap(model, xi=None, zi=None, dataloader=None, covparam0=None, covparam0_init=None, info=False,
+                                 verbosity=0, **kwargs):
+    """gpmp/kernel/parameter_selection.py:867-965: alias of the Gaussian-log-sigma2 + log-rho procedure."""
+    return select_parameters_with_remap_gaussian_logsigma2_and_logrho_prior(
+        model, xi=xi, zi=zi, dataloader=dataloader, covparam0=covparam0, covparam0_init=covparam0_init, info=info,
+        verbosity=verbosity, **kwargs)
+
+
+def select_parameters_with_remap_with_power_laws_prior(model, xi=None, zi=None, dataloader=None, covparam0=None, info=False,
+                                                       verbosity=0, *, bounds=None, bounds_auto=True, bounds_delta=10.0,
+                                                       method="SLSQP", method_options=None):
+    """gpmp/kernel/parameter_selection.py:969-1030 (finite-difference jacobian, as with the NumPy backend)."""
+    return select_parameters_with_criterion(model, _priors.neg_log_restricted_posterior_power_laws_prior, xi=xi, zi=zi,
+                                            dataloader=dataloader, covparam0=covparam0, info=info, verbosity=verbosity,
+                                            bounds=bounds, bounds_auto=bounds_auto, bounds_delta=bounds_delta, method=method,
                                             method_options=method_options)

@@ -217,8 +217,45 @@ def gen_example02(out):
     out["ex02_nevals"] = np.array(len(info["history_criterion"]))
 
 
+def gen_remap(out):
+    """REMAP (REML + priors): priors, data-driven bounds, criterion values, and one full selection run."""
+    from gpmp.kernel import priors as rp
+    from gpmp.kernel.prior_helpers import resolve_logsigma2_logrho_prior_args
+
+    rng = np.random.default_rng(51)
+    for tag, (n, d), p in (("a", (60, 2), 2), ("b", (150, 5), 2)):
+        xi, zi = make_xz(n, d, 52)
+        out[f"remap_{tag}_xi"], out[f"remap_{tag}_zi"], out[f"remap_{tag}_p"] = xi, zi, np.array(p)
+        model = gp.core.Model(constant_mean, make_kernel(p))
+        out[f"remap_{tag}_logrho_min"] = gp.kernel.compute_logrho_min_from_xi(xi)
+        c0 = gp.kernel.anisotropic_parameters_initial_guess(model, xi, zi)
+        out[f"remap_{tag}_covparam0"] = c0
+        args = resolve_logsigma2_logrho_prior_args(covparam0_prior=c0, xi=xi)
+        gamma, cov, alpha, rfac, ls20, lr0, lrmin = args
+        out[f"remap_{tag}_prior_scalars"] = np.array([gamma, cov, alpha, rfac, float(ls20)])
+        out[f"remap_{tag}_logrho_0"], out[f"remap_{tag}_logrho_min_resolved"] = np.asarray(lr0), np.asarray(lrmin)
+        thetas = np.stack([c0 + 0.3 * rng.standard_normal(d + 1) for _ in range(4)])
+        out[f"remap_{tag}_thetas"] = thetas
+        out[f"remap_{tag}_lp_sigma2"] = np.array([rp.log_prior_gaussian_logsigma2(t, ls20) for t in thetas])
+        out[f"remap_{tag}_lp_logrho"] = np.array([rp.log_prior_logrho_barrier_linear(t, lrmin, lr0) for t in thetas])
+        out[f"remap_{tag}_lp_power"] = np.array([rp.log_prior_power_law(t) for t in thetas])
+        out[f"remap_{tag}_crit"] = np.array([
+            rp.neg_log_restricted_posterior_logsigma2_and_logrho_prior(model, t, xi, zi, log_sigma2_0=ls20, logrho_min=lrmin, logrho_0=lr0)
+            for t in thetas])
+        # barrier: a length-scale below its lower bound -> +inf
+        tb = c0.copy()
+        tb[1] = -(lrmin[0] - 0.5)
+        out[f"remap_{tag}_theta_barrier"] = tb
+        out[f"remap_{tag}_crit_barrier"] = np.array(
+            rp.neg_log_restricted_posterior_logsigma2_and_logrho_prior(model, tb, xi, zi, log_sigma2_0=ls20, logrho_min=lrmin, logrho_0=lr0))
+        model, info = gp.kernel.select_parameters_with_remap(model, xi, zi, info=True)
+        out[f"remap_{tag}_covparam_opt"] = np.asarray(model.covparam)
+        out[f"remap_{tag}_crit_opt"] = np.array(
+            rp.neg_log_restricted_posterior_logsigma2_and_logrho_prior(model, model.covparam, xi, zi, log_sigma2_0=ls20, logrho_min=lrmin, logrho_0=lr0))
+
+
 def numpy_pass():
-    for name, fn in (("matern", gen_matern), ("predict", gen_predict), ("likelihood", gen_likelihood), ("example02", gen_example02)):
+    for name, fn in (("matern", gen_matern), ("predict", gen_predict), ("likelihood", gen_likelihood), ("example02", gen_example02), ("remap", gen_remap)):
         out = {}
         fn(out)
         path = os.path.join(HERE, f"ref_{name}.npz")
@@ -275,6 +312,27 @@ def torch_pass():
                 vals.append(float(pre(tt)))
                 grads.append(tonp(grad(tt)))
             out[f"grad_{tag}_{name}_val"], out[f"grad_{tag}_{name}_grad"] = np.array(vals), np.stack(grads)
+    # REMAP criterion gradient (autograd through REML + priors) at the thetas of ref_remap.npz
+    from gpmp.kernel import priors as rp
+
+    g = np.load(os.path.join(HERE, "ref_remap.npz"))
+    for tag in ("a", "b"):
+        xi, zi, p = g[f"remap_{tag}_xi"], g[f"remap_{tag}_zi"], int(g[f"remap_{tag}_p"])
+        model = gp.core.Model(constant_mean, make_kernel(p))
+        ls20 = float(g[f"remap_{tag}_prior_scalars"][4])
+        lrmin = torch.as_tensor(g[f"remap_{tag}_logrho_min_resolved"])
+        lr0 = torch.as_tensor(g[f"remap_{tag}_logrho_0"])
+
+        def crit(m, covparam, x, z):
+            return rp.neg_log_restricted_posterior_logsigma2_and_logrho_prior(m, covparam, x, z, log_sigma2_0=ls20, logrho_min=lrmin, logrho_0=lr0)
+
+        _, pre, _, grad = gp.kernel.make_selection_criterion_with_gradient(model, crit, xi, zi)
+        vals, grads = [], []
+        for t in g[f"remap_{tag}_thetas"]:
+            tt = torch.as_tensor(t, dtype=torch.float64)
+            vals.append(float(pre(tt)))
+            grads.append(tonp(grad(tt)))
+        out[f"grad_remap_{tag}_val"], out[f"grad_remap_{tag}_grad"] = np.array(vals), np.stack(grads)
     path = os.path.join(HERE, "ref_gradients.npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

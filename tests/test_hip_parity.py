@@ -425,3 +425,39 @@ def test_medium_size_vs_oracle(gp, gnp, n, m, d):
     _, pre, _, grad = gp.kernel.make_selection_criterion_with_gradient(mc, gp.kernel.negative_log_restricted_likelihood, xi, zi)
     assert abs(pre(th) - v) < 1e-10 * abs(v)
     assert rel_err(grad(th), gr) < 1e-7
+
+
+# ------------------------------------------------------------------------------ REMAP (REML + priors)
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_remap_criterion_gradient_and_selection(gp, gnp, golden, tag):
+    g, gg = golden("remap"), golden("gradients")
+    xi, zi, p = g[f"remap_{tag}_xi"], g[f"remap_{tag}_zi"], int(g[f"remap_{tag}_p"])
+    ls20 = float(g[f"remap_{tag}_prior_scalars"][4])
+    lr0, lrmin = g[f"remap_{tag}_logrho_0"], g[f"remap_{tag}_logrho_min_resolved"]
+    model = gp.Model(constant_mean, gp.kernel.MaternCovariance(p))
+    crit = gp.kernel.neg_log_restricted_posterior_logsigma2_and_logrho_prior
+    for i, t in enumerate(g[f"remap_{tag}_thetas"]):
+        v = float(crit(model, t, xi, zi, log_sigma2_0=ls20, logrho_min=lrmin, logrho_0=lr0))
+        assert abs(v - g[f"remap_{tag}_crit"][i]) < 1e-10 * max(1.0, abs(v))
+    assert math.isinf(float(crit(model, g[f"remap_{tag}_theta_barrier"], xi, zi, log_sigma2_0=ls20, logrho_min=lrmin, logrho_0=lr0)))
+    np.testing.assert_allclose(gp.kernel.anisotropic_parameters_initial_guess(model, xi, zi), g[f"remap_{tag}_covparam0"], rtol=1e-9)
+    # the full selection run: same optimum to the optimiser tolerance, with the analytic jacobian
+    model, info = gp.kernel.select_parameters_with_remap(model, xi, zi, info=True)
+    v_opt = float(crit(model, model.covparam, xi, zi, log_sigma2_0=ls20, logrho_min=lrmin, logrho_0=lr0))
+    # (the reference run uses SciPy finite differences and stops at ftol 1e-6; the analytic jacobian may go a
+    # little further down the same flat valley: require agreement to 1e-3 relative and "not worse")
+    ref_opt = float(g[f"remap_{tag}_crit_opt"])
+    assert abs(v_opt - ref_opt) < 1e-3 * max(1.0, abs(v_opt))
+    assert v_opt <= ref_opt + 1e-5 * abs(ref_opt)
+    np.testing.assert_allclose(model.covparam, g[f"remap_{tag}_covparam_opt"], atol=0.25)
+    # analytic gradient of the REMAP criterion against the reference's autograd
+    from gpmp_amd.kernel.parameter_selection import _RemapAnalytic
+    from gpmp_amd.kernel import priors
+
+    nlp = lambda c: -(priors.log_prior_gaussian_logsigma2(c, ls20) + priors.log_prior_logrho_barrier_linear(c, lrmin, lr0))  # noqa: E731
+    gnl = lambda c: priors.grad_neg_log_prior_gaussian_logsigma2(c, ls20) + priors.grad_neg_log_prior_logrho_barrier_linear(c, lrmin, lr0)  # noqa: E731
+    ana = _RemapAnalytic(gp.Model(constant_mean, gp.kernel.MaternCovariance(p)), nlp, gnl)
+    for i, t in enumerate(g[f"remap_{tag}_thetas"]):
+        v, st = ana.value_and_state(t, gnp.asarray(xi), gnp.asarray(zi))
+        assert abs(v - gg[f"grad_remap_{tag}_val"][i]) < 1e-9 * max(1.0, abs(v))
+        assert rel_err(ana.gradient_from_state(st), gg[f"grad_remap_{tag}_grad"][i]) < 1e-7
