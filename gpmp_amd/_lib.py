@@ -25,6 +25,7 @@ SIGNATURES = {
     "gpmp_matern_pairwise": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P]),
     "gpmp_scaled_distance": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_long, _P]),
     "gpmp_maternp_kernel": (c_int, [_P, c_long, c_int, _P, _P]),
+    "gpmp_matern_gram_deriv": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _P, c_long, _P]),
     "gpmp_dinv_elems": (c_size_t, [c_int]),
     "gpmp_potrf_lower_async": (c_int, [_P, c_int, c_long, _P, _P, _P]),
     "gpmp_trsm_lower": (c_int, [_P, c_int, c_long, _P, _P, c_int, c_long, c_int, _P, _P]),

@@ -3,12 +3,13 @@
 Same constructor, attributes and method signatures as the reference ``Model`` for
 ``predict`` / ``loo`` / ``negative_log_likelihood*`` / ``negative_log_restricted_likelihood`` /
 ``norm_k_sqrd*`` / ``k_inverses`` and the kriging predictors; the arithmetic runs in libgpmp_hip.so.
-Out of scope here: Fisher information and sample paths.
+Also carried: Fisher information (analytic covariance derivatives) and sample paths by
+the Cholesky route; ``fisher_information_torch`` (autograd Hessian) has no counterpart here.
 """
 import warnings
 
 from .. import num as gnp
-from . import kriging, likelihood, linalg, loo, utils
+from . import fisher, kriging, likelihood, linalg, loo, sample_paths, utils
 
 
 class Model:
@@ -96,3 +97,21 @@ class Model:
     def norm_k_sqrd(self, xi, zi, covparam):
         xi, zi, _ = utils.ensure_shapes_and_type(xi=xi, zi=zi)
         return linalg.norm_k_sqrd(self, xi, zi, covparam)
+
+    # ------------------------------------------------------------------ Fisher information (gpmp/core/model.py:509-571)
+    def fisher_information(self, xi, covparam=None, epsilon=1e-3):
+        return fisher.fisher_information(self, xi, covparam=covparam, epsilon=epsilon)
+
+    def fisher_information_cpd(self, xi, covparam=None, epsilon=1e-3):
+        return fisher.fisher_information_cpd(self, xi, covparam=covparam, epsilon=epsilon)
+
+    # ------------------------------------------------------------------ sample paths (gpmp/core/model.py:576-696)
+    def sample_paths(self, xt, nb_paths, method="chol", check_result=True):
+        return sample_paths.sample_paths(self, xt, nb_paths, method=method, check_result=check_result)
+
+    def conditional_sample_paths(self, ztsim, xi_ind, zi, xt_ind, lambda_t, convert_out=True):
+        return sample_paths.conditional_sample_paths(self, ztsim, xi_ind, zi, xt_ind, lambda_t, convert_out=convert_out)
+
+    def conditional_sample_paths_parameterized_mean(self, ztsim, xi, xi_ind, zi, xt, xt_ind, lambda_t, convert_out=True):
+        return sample_paths.conditional_sample_paths_parameterized_mean(self, ztsim, xi, xi_ind, zi, xt, xt_ind, lambda_t,
+                                                                        convert_out=convert_out)

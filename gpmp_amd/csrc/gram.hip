@@ -497,6 +497,43 @@ __global__ void grad_finalize_kernel(const double* __restrict__ partial, int nbl
   if (k >= 1 && k <= d) g[(noise ? 1 : 0) + k] = sigma2 * tot[k];
 }
 
+// dK/dtheta_j as a dense matrix (Fisher information, diagnostics): one entry per thread.
+//   jparam = 0: d/d log sigma^2 = sigma2 * Kc (+ nugget on the diagonal when it scales with sigma2)
+//   jparam = noise_index: sigma_noise^2 * I
+//   otherwise: d/d log(1/rho_j) = sigma2 * (K'(h)/h) * (invrho_j (x_ij - x_kj))^2
+struct DerivParams {
+  const double* x;
+  double* out;
+  long ld;
+  int n, d, jdim, kind;          // kind 0: log sigma2, 1: noise, 2: length-scale jdim
+  double sigma2, diag_val;
+  double invrho[GPMP_MAX_DIM];
+  MaternSpec ms;
+};
+
+__global__ void gram_deriv_kernel(DerivParams p) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (k >= p.n) return;
+  double v = 0.0;
+  if (p.kind == 1) {
+    v = (i == k) ? p.diag_val : 0.0;
+  } else {
+    double s = 0.0, dj = 0.0;
+    for (int c = 0; c < p.d; ++c) {
+      const double df = p.invrho[c] * (p.x[(long)i * p.d + c] - p.x[(long)k * p.d + c]);
+      s = fma(df, df, s);
+      if (c == p.jdim) dj = df * df;
+    }
+    const double h = sqrt(s);
+    double kval;
+    const double dk = matern_dk_over_h(p.ms, h, kval);
+    if (p.kind == 0) v = p.sigma2 * kval + ((i == k) ? p.diag_val : 0.0);
+    else v = p.sigma2 * dk * dj;
+  }
+  p.out[(long)i * p.ld + k] = v;
+}
+
 // ---- host-side helpers -------------------------------------------------------------------------
 int fill_matern(MaternSpec& ms, int p) {
   if (p < 0 || p > GPMP_MAX_P) return -1;
@@ -667,6 +704,31 @@ extern "C" int gpmp_matern_grad_trace(const double* Kinv, long ldk, const double
   const double noise_var = noise ? std::exp(theta_host[1]) : 0.0;
   hipLaunchKernelGGL(grad_finalize_kernel, dim3(1), dim3(128), 0, st, ws, nblocks, dt + 2, d, noise,
                      gp.sigma2, nugget_scale, noise_var, g_dev);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gpmp_matern_gram_deriv(const double* x, int n, int d, int p, const double* theta_host, int noise,
+                                      int jparam, double* out, long ld, gpmp_stream_t stream) {
+  GPMP_ARG(x != nullptr, 1, "x is NULL");
+  GPMP_ARG(n >= 1 && n <= 65535, 2, "n outside [1, 65535] (diagnostic-sized problems)");
+  GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 3, "d outside [1, GPMP_MAX_DIM]");
+  GPMP_ARG(p >= 0 && p <= GPMP_MAX_P, 4, "p outside [0, GPMP_MAX_P]");
+  GPMP_ARG(theta_host != nullptr, 5, "theta is NULL");
+  const int off = noise ? 2 : 1;
+  GPMP_ARG(jparam >= 0 && jparam < off + d, 7, "jparam outside the parameter vector");
+  GPMP_ARG(out != nullptr && ld >= n, 8, "out is NULL or ld < n");
+  DerivParams dp;
+  dp.x = x; dp.out = out; dp.ld = ld; dp.n = n; dp.d = d;
+  dp.sigma2 = std::exp(theta_host[0]);
+  for (int k = 0; k < d; ++k) dp.invrho[k] = std::exp(theta_host[off + k]);
+  fill_matern(dp.ms, p);
+  const double eps = 2.220446049250313e-16;
+  dp.jdim = -1;
+  if (jparam == 0) { dp.kind = 0; dp.diag_val = noise ? 0.0 : 10.0 * dp.sigma2 * eps; }
+  else if (noise && jparam == 1) { dp.kind = 1; dp.diag_val = std::exp(theta_host[1]); }
+  else { dp.kind = 2; dp.jdim = jparam - off; dp.diag_val = 0.0; }
+  hipLaunchKernelGGL(gram_deriv_kernel, dim3((n + 255) / 256, n), dim3(256), 0, as_stream(stream), dp);
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -73,6 +73,12 @@ int gpmp_scaled_distance(const double* x, const double* y, int n, int m, int d,
 /* Matern_p(h) elementwise on a device vector -- maternp_kernel (matern.py:32-64). */
 int gpmp_maternp_kernel(const double* h, long count, int p, double* out, gpmp_stream_t stream);
 
+/* out (n x n) = dK/dtheta_jparam for the covariance of gpmp_matern_gram (ii path): dense derivative
+ * matrices for the Fisher information I_ij = 1/2 tr(K^-1 dK_i K^-1 dK_j) (gpmp/core/fisher.py:18-78, which
+ * differentiates the covariance by 5-point finite differences).  Diagnostic-sized n (<= 65535). */
+int gpmp_matern_gram_deriv(const double* x, int n, int d, int p, const double* theta_host, int noise,
+                           int jparam, double* out, long ld, gpmp_stream_t stream);
+
 /* ---- Cholesky and triangular solves ---------------------------------------------------------- */
 
 /* Number of doubles of the diagonal-block-inverse workspace for an n x n factorisation. */

@@ -254,8 +254,38 @@ def gen_remap(out):
             rp.neg_log_restricted_posterior_logsigma2_and_logrho_prior(model, model.covparam, xi, zi, log_sigma2_0=ls20, logrho_min=lrmin, logrho_0=lr0))
 
 
+def gen_fisher_paths(out):
+    """Fisher information (finite-difference covariance derivatives in the reference) and conditioning of sample paths."""
+    for tag, (n, d), p in (("a", (40, 2), 2), ("b", (70, 3), 1)):
+        xi, zi = make_xz(n, d, 61)
+        th = theta_aniso(d, sigma2=0.7)
+        out[f"fish_{tag}_xi"], out[f"fish_{tag}_theta"], out[f"fish_{tag}_p"] = xi, th, np.array(p)
+        mz = gp.core.Model(None, make_kernel(p), None, th, "zero")
+        mc = gp.core.Model(constant_mean, make_kernel(p), None, th, "linear_predictor")
+        out[f"fish_{tag}_I"] = mz.fisher_information(xi)
+        out[f"fish_{tag}_I_cpd"] = mc.fisher_information_cpd(xi)
+    # conditional sample paths: deterministic given (ztsim, lambda_t)
+    rng = np.random.default_rng(62)
+    xi, zi = make_xz(30, 2, 63)
+    xt, _ = make_xz(50, 2, 64)
+    th = theta_aniso(2)
+    model = gp.core.Model(constant_mean, make_kernel(2), None, th)
+    _, _, lam = model.predict(xi, zi, xt, return_lambdas=True)
+    xtsim = np.vstack((xi, xt))
+    ztsim = rng.standard_normal((80, 5))
+    xi_ind, xt_ind = np.arange(30), np.arange(30, 80)
+    out["paths_xi"], out["paths_zi"], out["paths_xt"], out["paths_theta"] = xi, zi, xt, th
+    out["paths_ztsim"], out["paths_lambda"] = ztsim, lam
+    out["paths_cond"] = model.conditional_sample_paths(ztsim, xi_ind, zi, xt_ind, lam)
+    mp = np.array([0.3, -0.7])
+    mpm = gp.core.Model(param_mean, make_kernel(2), mp, th, "parameterized")
+    _, _, lam2 = mpm.predict(xi, zi, xt, return_lambdas=True)
+    out["paths_lambda_param"] = lam2
+    out["paths_cond_param"] = mpm.conditional_sample_paths_parameterized_mean(ztsim, xi, xi_ind, zi, xt, xt_ind, lam2)
+
+
 def numpy_pass():
-    for name, fn in (("matern", gen_matern), ("predict", gen_predict), ("likelihood", gen_likelihood), ("example02", gen_example02), ("remap", gen_remap)):
+    for name, fn in (("matern", gen_matern), ("predict", gen_predict), ("likelihood", gen_likelihood), ("example02", gen_example02), ("remap", gen_remap), ("fisher_paths", gen_fisher_paths)):
         out = {}
         fn(out)
         path = os.path.join(HERE, f"ref_{name}.npz")

@@ -461,3 +461,45 @@ def test_remap_criterion_gradient_and_selection(gp, gnp, golden, tag):
         v, st = ana.value_and_state(t, gnp.asarray(xi), gnp.asarray(zi))
         assert abs(v - gg[f"grad_remap_{tag}_val"][i]) < 1e-9 * max(1.0, abs(v))
         assert rel_err(ana.gradient_from_state(st), gg[f"grad_remap_{tag}_grad"][i]) < 1e-7
+
+
+# ------------------------------------------------------------------------------ Fisher information, sample paths
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_fisher_information_vs_reference(gp, gnp, golden, tag):
+    g = golden("fisher_paths")
+    xi, th, p = g[f"fish_{tag}_xi"], g[f"fish_{tag}_theta"], int(g[f"fish_{tag}_p"])
+    mz = gp.Model(None, gp.kernel.MaternCovariance(p), None, th, "zero")
+    mc = gp.Model(constant_mean, gp.kernel.MaternCovariance(p), None, th)
+    # the reference differentiates the covariance by 5-point finite differences (eps = 1e-3): agreement to ~1e-7
+    assert rel_err(mz.fisher_information(xi), g[f"fish_{tag}_I"]) < 1e-6
+    assert rel_err(mc.fisher_information_cpd(xi), g[f"fish_{tag}_I_cpd"]) < 1e-6
+    # generic callable -> same finite differences as the reference
+    def kernel(x, y, covparam, pairwise=False):
+        return gp.kernel.maternp_covariance(x, y, p, covparam, pairwise)
+    mg = gp.Model(None, kernel, None, th, "zero")
+    assert rel_err(mg.fisher_information(xi), g[f"fish_{tag}_I"]) < 1e-6
+    I = mz.fisher_information(xi)
+    assert np.allclose(I, I.T) and np.all(np.linalg.eigvalsh(I) > 0)
+
+
+def test_sample_paths(gp, gnp, golden):
+    g = golden("fisher_paths")
+    xi, zi, xt, th = g["paths_xi"], g["paths_zi"], g["paths_xt"], g["paths_theta"]
+    model = gp.Model(constant_mean, gp.kernel.MaternCovariance(2), None, th)
+    xi_ind, xt_ind = np.arange(30), np.arange(30, 80)
+    cond = model.conditional_sample_paths(g["paths_ztsim"], xi_ind, zi, xt_ind, g["paths_lambda"])
+    assert rel_err(cond, g["paths_cond"]) < 1e-12
+    mpm = gp.Model(param_mean, gp.kernel.MaternCovariance(2), g["pred_s_meanparam"] if "pred_s_meanparam" in g.files else np.array([0.3, -0.7]), th, "parameterized")
+    cond2 = mpm.conditional_sample_paths_parameterized_mean(g["paths_ztsim"], gnp.asarray(xi), xi_ind, zi, gnp.asarray(xt), xt_ind, g["paths_lambda_param"])
+    assert rel_err(cond2, g["paths_cond_param"]) < 1e-12
+    # unconditional paths: C W with the backend's generator; check the factor identity and the moments
+    gnp.set_seed(123)
+    xs = gnp.asarray(np.vstack((xi, xt)))
+    Z = gnp.to_np(model.sample_paths(xs, 2000))
+    K = gnp.to_np(model.covariance(xs, xs, th))
+    emp = Z @ Z.T / Z.shape[1]
+    assert Z.shape == (80, 2000) and np.max(np.abs(emp - K)) < 0.15 * np.max(np.abs(K))
+    # conditioning interpolates the data
+    lam = g["paths_lambda"]
+    full = model.conditional_sample_paths(Z[:, :3], xi_ind, zi, np.arange(80), np.hstack((np.eye(30), lam)))
+    assert np.max(np.abs(full[:30] - zi[:, None])) < 1e-9
