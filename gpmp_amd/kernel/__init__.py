@@ -7,7 +7,11 @@ from .matern import (
     maternp_covariance_it,
     maternp_kernel,
 )
-from .init import anisotropic_parameters_initial_guess, anisotropic_parameters_initial_guess_zero_mean
+from .init import (
+    anisotropic_parameters_initial_guess,
+    anisotropic_parameters_initial_guess_constant_mean,
+    anisotropic_parameters_initial_guess_zero_mean,
+)
 from .parameter_selection import (
     autoselect_parameters,
     make_selection_criterion_with_gradient,
@@ -19,6 +23,11 @@ from .parameter_selection import (
     select_parameters_with_remap,
     select_parameters_with_remap_gaussian_logsigma2_and_logrho_prior,
     select_parameters_with_remap_with_power_laws_prior,
+    select_parameters_with_ml_constant_mean,
+    update_parameters_with_criterion,
+    update_parameters_with_ml_constant_mean,
+    update_parameters_with_reml,
+    update_parameters_with_remap,
 )
 from .prior_helpers import compute_logrho_min_from_xi
 from .priors import (
@@ -46,4 +55,7 @@ __all__ = [
     "log_prior_logrho_barrier_linear", "log_prior_power_law", "neglog_f_logrho",
     "neg_log_restricted_posterior_logsigma2_and_logrho_prior", "neg_log_restricted_posterior_logsigma2_prior",
     "neg_log_restricted_posterior_power_laws_prior", "neg_log_restricted_posterior_with_logrho_prior", "prior_defaults",
+    "anisotropic_parameters_initial_guess_constant_mean", "select_parameters_with_ml_constant_mean",
+    "update_parameters_with_criterion", "update_parameters_with_ml_constant_mean", "update_parameters_with_reml",
+    "update_parameters_with_remap",
 ]

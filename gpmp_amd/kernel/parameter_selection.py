@@ -11,7 +11,7 @@ import numpy as np
 from scipy.optimize import minimize
 
 from .. import num as gnp
-from .init import anisotropic_parameters_initial_guess
+from .init import anisotropic_parameters_initial_guess, anisotropic_parameters_initial_guess_constant_mean
 from .matern import MaternCovariance
 from .prior_helpers import resolve_covparam0_prior_and_init, resolve_logsigma2_logrho_prior_args
 from . import priors as _priors
@@ -255,3 +255,57 @@ def select_parameters_with_remap_with_power_laws_prior(model, xi=None, zi=None, 
                                             dataloader=dataloader, covparam0=covparam0, info=info, verbosity=verbosity,
                                             bounds=bounds, bounds_auto=bounds_auto, bounds_delta=bounds_delta, method=method,
                                             method_options=method_options)
+
+
+# ------------------------------------------------------------------------------------------------
+# update_* procedures (start from the model's current parameters) and ML with a constant mean
+# ------------------------------------------------------------------------------------------------
+def update_parameters_with_criterion(model, criterion, xi=None, zi=None, dataloader=None, parameterized_mean=False,
+                                     meanparam_len=1, info=False, verbosity=0, **kw):
+    """gpmp/kernel/parameter_selection.py:440-507: re-optimise starting at model.meanparam / model.covparam."""
+    if model.covparam is None:
+        raise ValueError("model.covparam must be set before an update; use select_parameters_with_criterion first.")
+    return select_parameters_with_criterion(model, criterion, xi=xi, zi=zi, dataloader=dataloader,
+                                            meanparam0=model.meanparam if parameterized_mean else None,
+                                            covparam0=model.covparam, parameterized_mean=parameterized_mean,
+                                            meanparam_len=meanparam_len, info=info, verbosity=verbosity, **kw)
+
+
+def update_parameters_with_reml(model, xi=None, zi=None, dataloader=None, info=False, verbosity=0, **kw):
+    """gpmp/kernel/parameter_selection.py:811-864."""
+    return update_parameters_with_criterion(model, negative_log_restricted_likelihood, xi=xi, zi=zi, dataloader=dataloader,
+                                            info=info, verbosity=verbosity, **kw)
+
+
+def update_parameters_with_remap(model, xi=None, zi=None, dataloader=None, covparam0=None, covparam0_prior=None,
+                                 covparam0_init=None, info=False, verbosity=0, **kw):
+    """gpmp/kernel/parameter_selection.py:922-965,1486-1577: prior anchored at covparam0_prior (default: the model's
+    current parameters), optimiser started at covparam0_init (default: the model's current parameters)."""
+    cur = model.covparam
+    if covparam0_prior is None:
+        covparam0_prior = covparam0 if covparam0 is not None else cur
+    if covparam0_init is None:
+        covparam0_init = covparam0 if covparam0 is not None else cur
+    return select_parameters_with_remap_gaussian_logsigma2_and_logrho_prior(
+        model, xi=xi, zi=zi, dataloader=dataloader, covparam0_prior=covparam0_prior, covparam0_init=covparam0_init, info=info,
+        verbosity=verbosity, **kw)
+
+
+def select_parameters_with_ml_constant_mean(model, xi=None, zi=None, dataloader=None, meanparam0=None, covparam0=None,
+                                            info=False, verbosity=0, *, bounds=None, bounds_auto=True, bounds_delta=10.0,
+                                            method="SLSQP", method_options=None):
+    """gpmp/kernel/parameter_selection.py:583-680: ML over [constant mean, covparam] (meantype 'parameterized')."""
+    if meanparam0 is None or covparam0 is None:
+        m0, c0 = anisotropic_parameters_initial_guess_constant_mean(model, xi, zi, dataloader)
+        meanparam0 = m0 if meanparam0 is None else meanparam0
+        covparam0 = c0 if covparam0 is None else covparam0
+    return select_parameters_with_criterion(model, negative_log_likelihood, xi=xi, zi=zi, dataloader=dataloader,
+                                            meanparam0=meanparam0, covparam0=covparam0, parameterized_mean=True, meanparam_len=1,
+                                            info=info, verbosity=verbosity, bounds=bounds, bounds_auto=bounds_auto,
+                                            bounds_delta=bounds_delta, method=method, method_options=method_options)
+
+
+def update_parameters_with_ml_constant_mean(model, xi=None, zi=None, dataloader=None, info=False, verbosity=0, **kw):
+    """gpmp/kernel/parameter_selection.py:683-744."""
+    return select_parameters_with_ml_constant_mean(model, xi=xi, zi=zi, dataloader=dataloader, meanparam0=model.meanparam,
+                                                   covparam0=model.covparam, info=info, verbosity=verbosity, **kw)

@@ -206,6 +206,22 @@ def reshape(x, shape):
     return torch.reshape(x, shape)
 
 
+def sort(x, axis=-1):
+    return torch.sort(x, dim=axis).values
+
+
+def diff(x, n=1, axis=-1):
+    return torch.diff(x, n=n, dim=axis)
+
+
+def var(x, axis=None):
+    return torch.var(x, unbiased=False) if axis is None else torch.var(x, dim=axis, unbiased=False)
+
+
+def mean(x, axis=None):
+    return torch.mean(x) if axis is None else torch.mean(x, dim=axis)
+
+
 def gammaln(x):
     return torch.lgamma(asarray(x).to(torch.float64))
 
@@ -401,6 +417,31 @@ def cholesky_inv(A):
 
 
 inv = cholesky_inv
+
+
+def logdet(A):
+    """numpy_backend.py:449-456 for symmetric positive definite A: 2 sum log L_ii (raises if not PD)."""
+    try:
+        return cholesky_factor(A).logdet()
+    except HipLinAlgError as exc:
+        raise ValueError("Matrix is not positive definite (or has non-positive determinant).") from exc
+
+
+def solve(A, B, overwrite_a=True, overwrite_b=True, assume_a="gen", sym_pos=False):
+    """scipy.linalg.solve as used on the path: SPD systems go through the HIP Cholesky; small general / symmetric
+    indefinite systems (the q x q blocks of the mean-space algebra) are plumbing-sized torch solves."""
+    A, B = asarray(A), asarray(B)
+    if assume_a == "pos" or sym_pos:
+        return cholesky_factor(A).solve(B)
+    return torch.linalg.solve(A, B)
+
+
+def qr(A, mode="reduced"):
+    return torch.linalg.qr(asarray(A), mode=mode)
+
+
+def svd(A, full_matrices=True, hermitian=True):
+    return torch.linalg.svd(asarray(A), full_matrices=full_matrices)
 
 
 def matmul(A, B):

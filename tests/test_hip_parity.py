@@ -503,3 +503,37 @@ def test_sample_paths(gp, gnp, golden):
     lam = g["paths_lambda"]
     full = model.conditional_sample_paths(Z[:, :3], xi_ind, zi, np.arange(80), np.hstack((np.eye(30), lam)))
     assert np.max(np.abs(full[:30] - zi[:, None])) < 1e-9
+
+
+def test_update_procedures_and_ml_constant_mean(gp, gnp):
+    from oracle import gp_oracle as orc
+
+    xi, zi = make_xz(80, 2, 91)
+    zi = zi + 1.5
+    cov = gp.kernel.MaternCovariance(2)
+    model = gp.Model(constant_mean, cov)
+    model, _ = gp.kernel.select_parameters_with_reml(model, xi, zi)
+    v0 = float(model.negative_log_restricted_likelihood(model.covparam, xi, zi))
+    model, _ = gp.kernel.update_parameters_with_reml(model, xi, zi)
+    assert float(model.negative_log_restricted_likelihood(model.covparam, xi, zi)) <= v0 + 1e-6
+    model, _ = gp.kernel.update_parameters_with_remap(model, xi, zi)
+    assert np.all(np.isfinite(model.covparam))
+    # ML with a parameterized constant mean: criterion value equals the oracle's at the optimum found
+    def cmean(x, param):
+        return param[0] * gnp.ones((x.shape[0], 1))
+    mp = gp.Model(cmean, cov, None, None, "parameterized")
+    m0, c0 = gp.kernel.anisotropic_parameters_initial_guess_constant_mean(mp, xi, zi)
+    assert abs(m0[0] - np.mean(zi)) < 1.0
+    mp, info = gp.kernel.select_parameters_with_ml_constant_mean(mp, xi, zi, info=True)
+    om = orc.OracleModel(lambda x, prm: prm[0] * np.ones((x.shape[0], 1)), lambda a, b, t, pairwise=False: orc.maternp_covariance(a, b, 2, t, pairwise),
+                         np.asarray(mp.meanparam), np.asarray(mp.covparam), "parameterized")
+    a = float(mp.negative_log_likelihood(mp.meanparam, mp.covparam, xi, zi))
+    b = float(orc.negative_log_likelihood(om, np.asarray(mp.meanparam), np.asarray(mp.covparam), xi, zi))
+    # (noise-free data: the ML optimum sits at long length-scales, cond(K) ~ 1e9; agreement to cond * eps)
+    assert abs(a - b) < 1e-6 * max(1.0, abs(b))
+    assert a <= float(mp.negative_log_likelihood(m0, c0, xi, zi)) + 1e-9
+    # gnp helpers
+    K = gnp.asarray(orc.maternp_covariance(xi, None, 2, theta_aniso(2)) + 1e-3 * np.eye(len(xi)))   # well conditioned
+    assert abs(gnp.logdet(K) - np.linalg.slogdet(gnp.to_np(K))[1]) < 1e-9
+    rhs = gnp.asarray(zi)
+    assert rel_err(gnp.to_np(gnp.solve(K, rhs, assume_a="pos")), np.linalg.solve(gnp.to_np(K), zi)) < 1e-8
