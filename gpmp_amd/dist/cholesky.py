@@ -12,7 +12,8 @@ Right-looking schedule per block column k (owner column cd = k mod Pc):
   4. every process row r: panel piece broadcast along the row from (r, cd)                        [RCCL]
   5. every process column c: the blocks J > k with J mod Pc == c are exchanged inside the column
      (one broadcast per process row) -> the "transposed" operand of the update                    [RCCL]
-  6. every rank: A_IJ -= L_Ik L_Jk^T for its blocks I >= J > k, one GEMM per local block row       [local]
+  6. every rank: A_IJ -= L_Ik L_Jk^T for its blocks I >= J > k, a staircase of GEMMs over groups of
+     4 local block rows                                                                              [local]
 Collectives are point-to-point-friendly broadcasts of (n - k nb) nb / Pr resp. / Pc doubles; scalars
 (log-det, quadratic form) use one all-reduce of a few doubles.
 """
@@ -270,15 +271,17 @@ class BlockCyclicCholesky:
                         colop[self.coff[lj] - self.coff[j0]: self.coff[lj + 1] - self.coff[j0]].copy_(piece[off:off + self.bs(J)])
                         off += self.bs(J)
 
-                # 6. trailing update of the local blocks, one GEMM per local block row (staircase)
-                for li in range(i0, len(self.row_blocks)):
-                    I = self.row_blocks[li]
-                    # last local column block with J <= I
-                    jmax = max((j for j, J in enumerate(self.col_blocks) if J <= I and J > k), default=-1)
+                # 6. trailing update of the local blocks: staircase of GEMMs over groups of up to 4 local block rows
+                #    (the few blocks above the diagonal that a group also touches are never read)
+                G = 4
+                for lg in range(i0, len(self.row_blocks), G):
+                    le = min(lg + G, len(self.row_blocks))
+                    I_last = self.row_blocks[le - 1]
+                    jmax = max((j for j, J in enumerate(self.col_blocks) if J <= I_last and J > k), default=-1)
                     if jmax < j0:
                         continue
-                    C = A[self.roff[li]:self.roff[li + 1], self.coff[j0]:self.coff[jmax + 1]]
-                    Ai = panel[self.roff[li] - self.roff[i0]: self.roff[li + 1] - self.roff[i0]]
+                    C = A[self.roff[lg]:self.roff[le], self.coff[j0]:self.coff[jmax + 1]]
+                    Ai = panel[self.roff[lg] - self.roff[i0]: self.roff[le] - self.roff[i0]]
                     Bj = colop[: self.coff[jmax + 1] - self.coff[j0]]
                     ops.gemm_nt_sub(C, Ai, Bj)
         # agree on info

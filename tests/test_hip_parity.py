@@ -537,3 +537,48 @@ def test_update_procedures_and_ml_constant_mean(gp, gnp):
     assert abs(gnp.logdet(K) - np.linalg.slogdet(gnp.to_np(K))[1]) < 1e-9
     rhs = gnp.asarray(zi)
     assert rel_err(gnp.to_np(gnp.solve(K, rhs, assume_a="pos")), np.linalg.solve(gnp.to_np(K), zi)) < 1e-8
+
+
+# ------------------------------------------------------------------------------ randomized shapes
+def test_randomized_shapes_cholesky_solve_predict(gp, gnp):
+    """ragged sizes around every tile / panel boundary (128, 512, 1024, look-ahead threshold) vs LAPACK"""
+    from oracle import gp_oracle as orc
+
+    rng = np.random.default_rng(2026)
+    sizes = [2, 3, 17, 129, 255, 257, 511, 513, 1023, 1025, 1100, 1537, 2049, 2300]
+    for n in sizes:
+        d = int(rng.integers(1, 6))
+        m = int(rng.integers(1, 700))
+        x = rng.random((n, d))
+        z = rng.standard_normal(n)
+        th = theta_aniso(d, scale=0.3)
+        K = orc.maternp_covariance(x, None, 2, th) + 1e-4 * np.eye(n)
+        B = rng.standard_normal((n, m))
+        X, L = gnp.cholesky_solve(gnp.asarray(K), gnp.asarray(B))
+        assert rel_err(gnp.to_np(L) @ gnp.to_np(L).T, K) < 1e-13, n
+        assert rel_err(K @ gnp.to_np(X), B) < 1e-9, n
+        xv, _ = gnp.cholesky_solve(gnp.asarray(K), gnp.asarray(z))
+        assert rel_err(K @ gnp.to_np(xv), z) < 1e-9, n
+        T = gnp.to_np(gnp.cholesky_inv(gnp.asarray(K)))
+        assert rel_err(T @ K, np.eye(n)) < 1e-8, n
+
+
+def test_predict_many_shapes_vs_oracle(gp, gnp):
+    from oracle import gp_oracle as orc
+
+    rng = np.random.default_rng(7)
+    for n, m, d, p in [(5, 1, 1, 0), (130, 257, 2, 1), (600, 129, 3, 2), (1030, 50, 7, 3), (700, 1300, 4, 4), (300, 40, 2, 6)]:
+        xi, zi = make_xz(n, d, n)
+        xt = rng.random((m, d))
+        th = theta_aniso(d, sigma2=1.3, scale=0.6)
+        kern = lambda a, b, t, pairwise=False, p=p: orc.maternp_covariance(a, b, p, t, pairwise)  # noqa: E731
+        for meantype, mean_h, mean_o in (("zero", None, None), ("linear_predictor", linear_mean, np_linear_mean)):
+            if meantype == "linear_predictor" and n <= d + 1:
+                continue
+            model = gp.Model(mean_h, gp.kernel.MaternCovariance(p), None, th, meantype)
+            om = orc.OracleModel(mean_o, kern, None, th, meantype)
+            zpm, zpv = model.predict(xi, zi, xt)
+            ozpm, ozpv = orc.predict(om, xi, zi, xt)
+            scale = max(1.0, np.max(np.abs(zi)))
+            assert np.max(np.abs(zpm - ozpm)) < 1e-7 * scale, (n, m, d, p, meantype)
+            assert np.max(np.abs(zpv - ozpv)) < 1e-7 * math.exp(th[0]), (n, m, d, p, meantype)
