@@ -65,80 +65,6 @@ __device__ __forceinline__ double matern_dispatch(const MaternSpec& ms, double h
   }
 }
 
-__global__ void __launch_bounds__(256) gram_kernel(GramParams p) {
-  __shared__ __attribute__((aligned(16))) double xs[DC][GT];
-  __shared__ __attribute__((aligned(16))) double ys[DC][GT];
-  const int tj = blockIdx.x, ti = blockIdx.y;
-  if (p.lower_only && tj > ti) return;
-  const int row0 = ti * GT, col0 = tj * GT;
-  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
-  const double* __restrict__ yp = p.same ? p.x : p.y;
-
-  double acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-
-  for (int k0 = 0; k0 < p.d; k0 += DC) {
-    if (k0) __syncthreads();
-    // stage 64 rows x 16 dims of x and y, scaled by 1/rho (numpy_backend.py:433-435)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = t + 256 * e;       // 0..1023
-      const int r = idx / DC, k = idx % DC;
-      double vx = 0.0, vy = 0.0;
-      if (k0 + k < p.d) {
-        const double ir = p.invrho[k0 + k];
-        if (row0 + r < p.n) vx = ir * p.x[(long)(row0 + r) * p.d + k0 + k];
-        if (col0 + r < p.m) vy = ir * yp[(long)(col0 + r) * p.d + k0 + k];
-      }
-      xs[k][r] = vx;
-      ys[k][r] = vy;
-    }
-    __syncthreads();
-    const int kmax = (p.d - k0) < DC ? (p.d - k0) : DC;
-    for (int k = 0; k < kmax; ++k) {
-      const d4 xa = *reinterpret_cast<const d4*>(&xs[k][ty * 4]);
-      const d4 yb = *reinterpret_cast<const d4*>(&ys[k][tx * 4]);
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const double df = xa[a] - yb[b];
-          acc[a][b] = fma(df, df, acc[a][b]);
-        }
-    }
-  }
-
-  const bool full = p.aligned && (row0 + GT <= p.n) && (col0 + GT <= p.m);
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int row = row0 + ty * 4 + a;
-    double v[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int col = col0 + tx * 4 + b;
-      const double h = sqrt(acc[a][b]);
-      double val = h;
-      if (p.mode == 0) {
-        val = p.sigma2 * matern_dispatch(p.ms, h);
-        if (p.same && row == col) val += p.diag_add;
-      }
-      v[b] = val;
-    }
-    double* out = p.K + (long)row * p.ldk + col0 + tx * 4;
-    if (full) {
-      *reinterpret_cast<d2*>(out) = (d2){v[0], v[1]};
-      *reinterpret_cast<d2*>(out + 2) = (d2){v[2], v[3]};
-    } else if (row < p.n) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        if (col0 + tx * 4 + b < p.m) out[b] = v[b];
-    }
-  }
-}
-
 // ---- fp64 helpers tuned for this kernel (VALU-bound: fp64 exp + sqrt dominate the per-entry cost) ----
 // exp(-x) for x >= 0: k = rint(x log2 e), r = k ln2 - x in [-0.347, 0.347], degree-12 Taylor (remainder
 // 0.347^13 / 13! = 1.7e-16), scale by 2^-k.  < 1 ulp of libm on the tested range; exact 1 at x = 0.
