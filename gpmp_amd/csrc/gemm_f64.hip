@@ -40,6 +40,9 @@ struct GemmParams {
   int kstart_col, kstart_col_off;   // k loop of tile column j starts at max(0, col0(j) - off)
   int tiles_m, tiles_n, ntiles;
   int aligned;  // 16-byte loads allowed on A and B
+  int cspread;  // v2: read C inside the first 16 k-tiles instead of up front
+  int stagger;  // v2: desynchronise the first round (see GemmOpts::stagger)
+  int tile_skip;
 };
 
 __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& ti, int& tj) {
@@ -51,7 +54,7 @@ __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& t
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   // tiles of unequal cost (triangular k ranges) are dealt round-robin instead: a contiguous chunk per
   // XCD would hand one XCD all the long tiles (measured on lauum: 29 -> 50+ TFLOP/s)
-  const int v = (p.kstart_row | p.kend_row | p.kstart_col) ? bid : base + bid / NXCD;
+  const int v = ((p.kstart_row | p.kend_row | p.kstart_col) ? bid : base + bid / NXCD) + p.tile_skip;
   if (p.lower_only) {
     const int tn = p.tiles_n < p.tiles_m ? p.tiles_n : p.tiles_m;
     const int t1 = tn * (tn + 1) / 2;
@@ -356,12 +359,26 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
   if (p.kend_row && row0 + BM < kend) kend = row0 + BM;
   const int nk = kend > kbeg ? (kend - kbeg) / BK : 0;
 
+  // Workgroups of one launch otherwise finish in lock-step rounds, and a latency-critical kernel on another
+  // (high-priority) stream then waits up to a whole tile time for a free slot.  Spreading the start of every
+  // second first-round workgroup over one tile time keeps completions -- free slots -- coming continuously;
+  // the co-resident workgroup runs alone meanwhile, so almost nothing is lost.
+  if (p.stagger && blockIdx.x < 512 && (blockIdx.x & 1) == 0) {
+    const int steps = (int)(((blockIdx.x >> 1) * 40503u) & 255u) * nk >> 8;   // one s_sleep(127) ~ one k-tile
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+
   // ---- accumulators (start from (beta/alpha) C, see v1)
   const double alpha = p.alpha, beta = p.beta;
   double* __restrict__ cbase = p.C + (long)row0 * p.ldc + col0;
   const unsigned lane_off = (unsigned)((wm + lk) * (int)p.ldc + wn + lr);
   d4 acc[4][4];
-  if constexpr (CACC) {
+  // C is read either up front (accumulators start from (beta/alpha) C) or, when the k loop is long
+  // enough, one 16x16 MFMA tile per k-tile during the first 16 k-tiles: every workgroup of a round
+  // starts its tile at the same time, and 512 simultaneous 128 KB reads are an HBM-rate burst that
+  // nothing hides (measured: the up-front read costs exactly C / HBM bandwidth at K = 512).
+  const bool spread = CACC && p.cspread && nk >= 18;
+  if (CACC && !spread) {
     const double sc = beta / alpha;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -438,33 +455,61 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
   };
 
+  auto ktile = [&](int kt, bool more, auto&& inject) {
+    const int cur = kt & 1;
+    if (more) issue(kt + 1, cur ^ 1);
+    // at most three k-steps of fragments are live at any point (48 VGPRs)
+    read_frags(2, cur);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(3, cur);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(1);
+    mfma_step(2);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();   // next tile landed (vmcnt(0) of every wave) and buffer `cur` is free for tile kt+2
+    if (more) {
+      read_frags(0, cur ^ 1);
+      read_frags(1, cur ^ 1);
+    }
+    inject();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(3);
+  };
+  auto nothing = [] {};
+
   if (nk > 0) {
     issue(0, 0);
     __syncthreads();
     read_frags(0, 0);
     read_frags(1, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      const bool more = kt + 1 < nk;
-      if (more) issue(kt + 1, cur ^ 1);
-      // at most three k-steps of fragments are live at any point (48 VGPRs)
-      read_frags(2, cur);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_step(0);
-      __builtin_amdgcn_sched_barrier(0);
-      read_frags(3, cur);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_step(1);
-      mfma_step(2);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();   // next tile landed (vmcnt(0) of every wave) and buffer `cur` is free for tile kt+2
-      if (more) {
-        read_frags(0, cur ^ 1);
-        read_frags(1, cur ^ 1);
+    int kt = 0;
+    if constexpr (CACC) {
+      if (spread) {
+        const double sc = beta / alpha;
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7FFFFFFF, 0x00020000);
+        const int cvoff = (int)lane_off * 8;
+        const int ldc8 = (int)p.ldc * 8;
+#pragma unroll
+        for (int T = 0; T < 16; ++T) {
+          const int i = T >> 2, j = T & 3;
+          // the four rows of MFMA tile (i, j) are requested before this k-tile's operand loads and have
+          // landed by the k-tile's barrier (vmcnt(0)); they are folded in just before k-step 3
+          typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+          v2u craw[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            craw[r] = __builtin_amdgcn_raw_buffer_load_b64(rc, cvoff, (i * 16 + 4 * r) * ldc8 + j * 128, 0);
+          ktile(T, true, [&] {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = fma(sc, __builtin_bit_cast(double, craw[r]), acc[i][j][r]);
+          });
+        }
+        kt = 16;
       }
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_step(3);
     }
+    for (; kt < nk; ++kt) ktile(kt, kt + 1 < nk, nothing);
   }
 
 #pragma unroll
@@ -479,6 +524,176 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
         rp[lane_off + j * 16] = v;
       }
     }
+}
+
+// ================================================================================================
+// Panel solve of the blocked Cholesky, fused: X = A21 * L11^-T for a w-wide panel, one workgroup per
+// 128-row tile, no synchronisation between workgroups.  With G the block lower-triangular matrix
+//   G_jj = inv(L_jj),   G_ji = -inv(L_jj) L_ji  (i < j)            (build_panel_g_kernel below)
+// forward substitution over the 128-column blocks reads
+//   X_j = [X_0 .. X_{j-1} | A_j] * G[j, 0 : 128 (j+1)]^T
+// i.e. for each j ONE NT product whose left operand is simply the first 128 (j+1) columns of the row tile
+// in memory (solved blocks followed by the untouched block j) -- the v2 main loop, K = 128 (j+1), run
+// nb times by the same workgroup, output block j written in place before block j+1 starts.
+// Same arithmetic as the launch-per-block scheme (inverse of the 128 x 128 diagonal blocks only), but
+// one launch on the look-ahead critical path instead of two tall launches per 128 columns.
+struct PanelSolveParams {
+  double* A;        // A21: first row below the panel's square, first column of the panel
+  long lda;
+  const double* G;  // w x w, row-major
+  long ldg;
+  int nb;           // 128-column blocks in the panel
+};
+
+__global__ void __launch_bounds__(256, 2) panel_solve_kernel(PanelSolveParams p) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int lr = lane & 15, lk = lane >> 4;
+  double* __restrict__ arow = p.A + (long)blockIdx.x * BM * p.lda;
+  const unsigned lane_off = (unsigned)((wm + lk) * (int)p.lda + wn + lr);
+
+  int voffA[2], voffB[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    voffA[h] = ((lane >> 3) * (int)p.lda + 2 * ((lane & 7) ^ ((h * 4 + (lane >> 4)) & 7))) * 8;
+    voffB[h] = ((lane >> 3) * (int)p.ldg + 2 * ((lane & 7) ^ ((h * 4 + (lane >> 4)) & 7))) * 8;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(arow, 0, 0x7FFFFFFF, 0x00020000);
+
+  double fa[4][4], fb[4][4];
+  d4 acc[4][4];
+  for (int jb = 0; jb < p.nb; ++jb) {
+    const int nk = (jb + 1) * (BM / BK);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(p.G + (long)jb * BN * p.ldg), 0, 0x7FFFFFFF, 0x00020000);
+    auto issue = [&](int kt, int buf) {
+      const int k0 = kt * BK;
+      double* sa = smem + buf * 2 * V2_TILE;
+      double* sb = sa + V2_TILE;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(sa + (wave * 32 + s * 8) * 16), 16, voffA[s & 1],
+                                                 ((wave * 32 + s * 8) * (int)p.lda + k0) * 8, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(sb + (wave * 32 + s * 8) * 16), 16, voffB[s & 1],
+                                                 ((wave * 32 + s * 8) * (int)p.ldg + k0) * 8, 0, 0);
+    };
+    auto read_frags = [&](int ks, int buf) {
+      const double* sa = smem + buf * 2 * V2_TILE;
+      const double* sb = sa + V2_TILE;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[ks][i] = sa[v2_frag_addr<true>(wm + i * 16 + lr, ks * 4 + lk)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[ks][j] = sb[v2_frag_addr<true>(wn + j * 16 + lr, ks * 4 + lk)];
+    };
+    auto mfma_step = [&](int ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    issue(0, 0);
+    __syncthreads();
+    read_frags(0, 0);
+    read_frags(1, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const bool more = kt + 1 < nk;
+      if (more) issue(kt + 1, cur ^ 1);
+      read_frags(2, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(3, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(1);
+      mfma_step(2);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      if (more) {
+        read_frags(0, cur ^ 1);
+        read_frags(1, cur ^ 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(3);
+    }
+    // every wave has consumed block j of the row tile (the barrier of the last k-tile): overwrite it
+    double* cb = arow + jb * BN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* rp = cb + (long)(i * 16 + 4 * r) * p.lda;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rp[lane_off + j * 16] = acc[i][j][r];
+      }
+    // block j is an operand of block j+1: stores complete and visible to the workgroup before the next loads
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+// G for one panel: grid (nb, nb), block (j, i) with i <= j.  One workgroup = one 128 x 128 block,
+// MFMA straight from global memory (L2-resident operands, 4 MFLOP per block: latency matters, not rate).
+struct PanelGParams {
+  const double* L;     // top-left of the panel's factored w x w square
+  long ldl;
+  const double* dinv;  // inverse diagonal blocks of the panel, [nb][128][128]
+  double* G;
+  long ldg;
+};
+
+__global__ void __launch_bounds__(256) build_panel_g_kernel(PanelGParams p) {
+  const int jb = blockIdx.x, ib = blockIdx.y;
+  if (ib > jb) return;
+  const int t = threadIdx.x;
+  const double* __restrict__ D = p.dinv + (size_t)jb * BM * BM;
+  double* __restrict__ out = p.G + (long)jb * BM * p.ldg + ib * BN;
+  if (ib == jb) {
+    for (int e = t; e < BM * BN / 2; e += 256) {
+      const int r = e / (BN / 2), c = (e % (BN / 2)) * 2;
+      *reinterpret_cast<d2*>(out + (long)r * p.ldg + c) = *reinterpret_cast<const d2*>(D + r * BM + c);
+    }
+    return;
+  }
+  const double* __restrict__ Lb = p.L + (long)jb * BM * p.ldl + ib * BN;   // L_ji
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int lr = lane & 15, lk = lane >> 4;
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < BM; k0 += 4) {
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = D[(wm + i * 16 + lr) * BM + k0 + lk];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = Lb[(long)(k0 + lk) * p.ldl + wn + j * 16 + lr];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        out[(long)(wm + i * 16 + lk + 4 * r) * p.ldg + wn + j * 16 + lr] = -acc[i][j][r];
 }
 
 template <bool AKC, bool BKC, bool CACC>
@@ -520,6 +735,30 @@ int launch_c(const GemmParams& p, hipStream_t st) {
 
 }  // namespace
 
+int launch_panel_solve(double* A21, long lda, int rows, int nb, const double* L11, const double* dinv_panel,
+                       double* G, bool build_g, hipStream_t st) {
+  // rows must be a multiple of 128 (the caller peels a ragged remainder); nb <= 8
+  const long ldg = (long)nb * BN;
+  if (build_g) {
+    PanelGParams g{L11, lda, dinv_panel, G, ldg};
+    hipLaunchKernelGGL(build_panel_g_kernel, dim3(nb, nb), dim3(256), 0, st, g);
+    GPMP_HIP_TRY(hipGetLastError());
+  }
+  if (rows <= 0) return 0;
+  static bool attr_done = false;
+  const size_t lds2 = sizeof(double) * 4 * V2_TILE;
+  if (!attr_done) {
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_solve_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    attr_done = true;
+  }
+  PanelSolveParams p{A21, lda, G, ldg, nb};
+  ProfScope ps(PK_GEMM2_NT, st, (double)rows * (double)(nb * BN) * (double)((nb + 1) * BN));
+  hipLaunchKernelGGL(panel_solve_kernel, dim3(rows / BM), dim3(256), lds2, st, p);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, long lda,
                            const double* B, long ldb, double beta, double* C, long ldc, const GemmOpts& o,
                            hipStream_t st) {
@@ -531,14 +770,20 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   p.alpha = alpha; p.beta = beta;
   p.lower_only = o.lower_only; p.kstart_row = o.kstart_row; p.kend_row = o.kend_row;
   p.kstart_col = o.kstart_col; p.kstart_col_off = o.kstart_col_off;
+  p.stagger = o.stagger;
+  p.tile_skip = o.lower_only ? o.tile_skip : 0;
   p.tiles_m = (M + BM - 1) / BM;
   p.tiles_n = (N + BN - 1) / BN;
   if (o.lower_only) {
     const int tn = p.tiles_n < p.tiles_m ? p.tiles_n : p.tiles_m;
-    p.ntiles = tn * (tn + 1) / 2 + (p.tiles_m - tn) * tn;
+    p.ntiles = tn * (tn + 1) / 2 + (p.tiles_m - tn) * tn - o.tile_skip;
+    if (p.ntiles <= 0) return 0;
   } else {
     p.ntiles = p.tiles_m * p.tiles_n;
   }
+  static int cspread = -1;
+  if (cspread < 0) { const char* e = getenv("GPMP_GEMM_CSPREAD"); cspread = e ? atoi(e) : 1; }
+  p.cspread = cspread;
   p.aligned = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0) &&
               ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((ldb & 1) == 0);
   if (a_kc && b_kc) return launch_c<true, true>(p, st);

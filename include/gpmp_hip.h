@@ -81,7 +81,9 @@ int gpmp_matern_gram_deriv(const double* x, int n, int d, int p, const double* t
 
 /* ---- Cholesky and triangular solves ---------------------------------------------------------- */
 
-/* Number of doubles of the diagonal-block-inverse workspace for an n x n factorisation. */
+/* Number of doubles of the factorisation workspace `dinv` for an n x n matrix: the inverses of the
+ * ceil(n/128) diagonal blocks, [block][128][128], followed (n > 1024) by one 1024 x 1024 panel scratch area
+ * that only gpmp_potrf_lower_async uses. */
 size_t gpmp_dinv_elems(int n);
 
 /* In-place lower Cholesky A = L L^T (replaces numpy.linalg.cholesky, numpy_backend.py:466).
