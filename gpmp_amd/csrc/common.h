@@ -57,22 +57,19 @@ struct GemmOpts {
   int kend_row = 0;
   int kstart_col = 0;       // B(l, j) = 0 for l < j - kstart_col_off (B lower triangular after an offset)
   int kstart_col_off = 0;
-  int tile_skip = 0;        // lower_only: leave out the first tile_skip tiles of the row-major lower enumeration
-  int stagger = 0;          // first-round workgroups with an even id start after a pseudo-random part of one tile time
 };
 int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, long lda,
                 const double* B, long ldb, double beta, double* C, long ldc, const GemmOpts& o,
                 hipStream_t st);
 
+// Fused leaf of the forward solve (gemm_f64.hip): X = L^-1 B in place for a leaf of nb <= 8 full 128-row blocks and
+// ncols (multiple of 128) right-hand sides; G = (128 nb)^2 doubles of scratch.
+int launch_trsm_leaf_forward(const double* L, long ldl, const double* dinv_leaf, int nb, double* B, long ldb, int ncols,
+                             double* G, hipStream_t st);
+
 // ---- diagonal block kernels (potf2.hip) -------------------------------------------------------
 // Factor the jb x jb block at A (lower, in place) and write inv(L) (NB x NB, ld NB, zero padded /
 // identity padded) to dinv.  info_dev: set to (offset + k + 1) at the first non-positive pivot.
-// fused panel solve of the blocked Cholesky (gemm_f64.hip): builds G (nb*128 square, ld nb*128) and solves `rows` rows
-int launch_panel_solve(double* A21, long lda, int rows, int nb, const double* L11, const double* dinv_panel,
-                       double* G, bool build_g, hipStream_t st);
-// Cholesky of an nb*128 square (nb <= 8, full blocks) in one cooperative launch (potf2.hip): L in place, inverse
-// diagonal blocks to dinv_panel, and (G != nullptr) the substitution matrix G of the panel (ld nb*128).
-int launch_chol_square(double* A, long lda, int nb, double* dinv_panel, double* G, int* info_dev, int offset, hipStream_t st);
 int launch_potf2_inv(double* A, long lda, int jb, double* dinv, int* info_dev, int offset, hipStream_t st);
 // inv(L_kk) of every NB diagonal block of an already factored n x n lower L (one launch).
 int launch_trtri_blocks(const double* L, long ldl, int n, double* dinv, hipStream_t st);

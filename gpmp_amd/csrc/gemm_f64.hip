@@ -41,8 +41,6 @@ struct GemmParams {
   int tiles_m, tiles_n, ntiles;
   int aligned;  // 16-byte loads allowed on A and B
   int cspread;  // v2: read C inside the first 16 k-tiles instead of up front
-  int stagger;  // v2: desynchronise the first round (see GemmOpts::stagger)
-  int tile_skip;
 };
 
 __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& ti, int& tj) {
@@ -54,7 +52,7 @@ __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& t
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   // tiles of unequal cost (triangular k ranges) are dealt round-robin instead: a contiguous chunk per
   // XCD would hand one XCD all the long tiles (measured on lauum: 29 -> 50+ TFLOP/s)
-  const int v = ((p.kstart_row | p.kend_row | p.kstart_col) ? bid : base + bid / NXCD) + p.tile_skip;
+  const int v = (p.kstart_row | p.kend_row | p.kstart_col) ? bid : base + bid / NXCD;
   if (p.lower_only) {
     const int tn = p.tiles_n < p.tiles_m ? p.tiles_n : p.tiles_m;
     const int t1 = tn * (tn + 1) / 2;
@@ -349,6 +347,11 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int lr = lane & 15, lk = lane >> 4;
+  // edge tiles (M, N not multiples of 128; both even): operand rows are clamped / clipped so that nothing is read
+  // outside the matrices, the main loop is the same, and only valid rows / columns of C are read and written
+  const int rows_v = (p.M - row0) < BM ? (p.M - row0) : BM;
+  const int cols_v = (p.N - col0) < BN ? (p.N - col0) : BN;
+  const bool edge = (rows_v < BM) || (cols_v < BN);
 
   int kbeg = p.kstart_row ? row0 : 0;
   if (p.kstart_col) {
@@ -359,15 +362,6 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
   if (p.kend_row && row0 + BM < kend) kend = row0 + BM;
   const int nk = kend > kbeg ? (kend - kbeg) / BK : 0;
 
-  // Workgroups of one launch otherwise finish in lock-step rounds, and a latency-critical kernel on another
-  // (high-priority) stream then waits up to a whole tile time for a free slot.  Spreading the start of every
-  // second first-round workgroup over one tile time keeps completions -- free slots -- coming continuously;
-  // the co-resident workgroup runs alone meanwhile, so almost nothing is lost.
-  if (p.stagger && blockIdx.x < 512 && (blockIdx.x & 1) == 0) {
-    const int steps = (int)(((blockIdx.x >> 1) * 40503u) & 255u) * nk >> 8;   // one s_sleep(127) ~ one k-tile
-    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-
   // ---- accumulators (start from (beta/alpha) C, see v1)
   const double alpha = p.alpha, beta = p.beta;
   double* __restrict__ cbase = p.C + (long)row0 * p.ldc + col0;
@@ -377,17 +371,29 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
   // enough, one 16x16 MFMA tile per k-tile during the first 16 k-tiles: every workgroup of a round
   // starts its tile at the same time, and 512 simultaneous 128 KB reads are an HBM-rate burst that
   // nothing hides (measured: the up-front read costs exactly C / HBM bandwidth at K = 512).
-  const bool spread = CACC && p.cspread && nk >= 18;
+  const bool spread = CACC && p.cspread && nk >= 18 && !edge;
   if (CACC && !spread) {
     const double sc = beta / alpha;
+    if (!edge) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
+        for (int r = 0; r < 4; ++r) {
+          const double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j][r] = sc * rp[lane_off + j * 16];
-      }
+          for (int j = 0; j < 4; ++j) acc[i][j][r] = sc * rp[lane_off + j * 16];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
+          const bool rok = wm + i * 16 + 4 * r + lk < rows_v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j][r] = (rok && wn + j * 16 + lr < cols_v) ? sc * rp[lane_off + j * 16] : 0.0;
+        }
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -395,14 +401,28 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
       for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
   }
 
-  // ---- per-lane source offsets (bytes), two variants each (they depend on s & 1 only)
-  int voffA[2], voffB[2];
+  // ---- per-lane source offsets (bytes), one per load instruction.  Rows (k-contiguous operand) or column pairs
+  // (m/n-contiguous operand) past the edge are redirected to a valid one: every load stays inside the matrix and the
+  // duplicates only feed rows / columns of C that are never stored.
+  int voffA[4], voffB[4];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    if constexpr (AKC) voffA[h] = ((lane >> 3) * (int)p.lda + 2 * ((lane & 7) ^ ((h * 4 + (lane >> 4)) & 7))) * 8;
-    else voffA[h] = 2 * (lane ^ (h << 3)) * 8;
-    if constexpr (BKC) voffB[h] = ((lane >> 3) * (int)p.ldb + 2 * ((lane & 7) ^ ((h * 4 + (lane >> 4)) & 7))) * 8;
-    else voffB[h] = 2 * (lane ^ (h << 3)) * 8;
+  for (int s = 0; s < 4; ++s) {
+    if constexpr (AKC) {
+      int r = wave * 32 + s * 8 + (lane >> 3);
+      r = r < rows_v ? r : rows_v - 1;
+      voffA[s] = (r * (int)p.lda + 2 * ((lane & 7) ^ (((s & 1) * 4 + (lane >> 4)) & 7))) * 8;
+    } else {
+      const int cp = lane ^ ((s & 1) << 3);
+      voffA[s] = 2 * (2 * cp < rows_v ? cp : 0) * 8;
+    }
+    if constexpr (BKC) {
+      int r = wave * 32 + s * 8 + (lane >> 3);
+      r = r < cols_v ? r : cols_v - 1;
+      voffB[s] = (r * (int)p.ldb + 2 * ((lane & 7) ^ (((s & 1) * 4 + (lane >> 4)) & 7))) * 8;
+    } else {
+      const int cp = lane ^ ((s & 1) << 3);
+      voffB[s] = 2 * (2 * cp < cols_v ? cp : 0) * 8;
+    }
   }
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -414,26 +434,24 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.A + (long)row0 * p.lda), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sa + (wave * 32 + s * 8) * 16), 16, voffA[s & 1],
-                                                 ((wave * 32 + s * 8) * (int)p.lda + k0) * 8, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sa + (wave * 32 + s * 8) * 16), 16, voffA[s], k0 * 8, 0, 0);
     } else {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.A + (long)k0 * p.lda + row0), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sa + (wave * 4 + s) * 128), 16, voffA[s & 1],
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sa + (wave * 4 + s) * 128), 16, voffA[s],
                                                  ((wave * 4 + s) * (int)p.lda) * 8, 0, 0);
     }
     if constexpr (BKC) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.B + (long)col0 * p.ldb), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sb + (wave * 32 + s * 8) * 16), 16, voffB[s & 1],
-                                                 ((wave * 32 + s * 8) * (int)p.ldb + k0) * 8, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sb + (wave * 32 + s * 8) * 16), 16, voffB[s], k0 * 8, 0, 0);
     } else {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.B + (long)k0 * p.ldb + col0), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sb + (wave * 4 + s) * 128), 16, voffB[s & 1],
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sb + (wave * 4 + s) * 128), 16, voffB[s],
                                                  ((wave * 4 + s) * (int)p.ldb) * 8, 0, 0);
     }
   };
@@ -512,64 +530,86 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
     for (; kt < nk; ++kt) ktile(kt, kt + 1 < nk, nothing);
   }
 
+  if (!edge) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
+      for (int r = 0; r < 4; ++r) {
+        double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        double v = alpha * acc[i][j][r];
-        if constexpr (!CACC) { if (beta != 0.0) v += beta * rp[lane_off + j * 16]; }
-        rp[lane_off + j * 16] = v;
+        for (int j = 0; j < 4; ++j) {
+          double v = alpha * acc[i][j][r];
+          if constexpr (!CACC) { if (beta != 0.0) v += beta * rp[lane_off + j * 16]; }
+          rp[lane_off + j * 16] = v;
+        }
       }
-    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
+        const bool rok = wm + i * 16 + 4 * r + lk < rows_v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (rok && wn + j * 16 + lr < cols_v) {
+            double v = alpha * acc[i][j][r];
+            if constexpr (!CACC) { if (beta != 0.0) v += beta * rp[lane_off + j * 16]; }
+            rp[lane_off + j * 16] = v;
+          }
+        }
+      }
+  }
 }
 
 // ================================================================================================
-// Panel solve of the blocked Cholesky, fused: X = A21 * L11^-T for a w-wide panel, one workgroup per
-// 128-row tile, no synchronisation between workgroups.  With G the block lower-triangular matrix
-//   G_jj = inv(L_jj),   G_ji = -inv(L_jj) L_ji  (i < j)            (build_panel_g_kernel below)
-// forward substitution over the 128-column blocks reads
-//   X_j = [X_0 .. X_{j-1} | A_j] * G[j, 0 : 128 (j+1)]^T
-// i.e. for each j ONE NT product whose left operand is simply the first 128 (j+1) columns of the row tile
-// in memory (solved blocks followed by the untouched block j) -- the v2 main loop, K = 128 (j+1), run
-// nb times by the same workgroup, output block j written in place before block j+1 starts.
-// Same arithmetic as the launch-per-block scheme (inverse of the 128 x 128 diagonal blocks only), but
-// one launch on the look-ahead critical path instead of two tall launches per 128 columns.
-struct PanelSolveParams {
-  double* A;        // A21: first row below the panel's square, first column of the panel
-  long lda;
-  const double* G;  // w x w, row-major
+// Leaf of the recursive forward solve  X = L^-1 B  (many right-hand sides), fused over the leaf's 128-row
+// blocks.  With G the block lower-triangular matrix of the leaf
+//   G_jj = inv(L_jj),   G_ji = -inv(L_jj) L_ji  (i < j)            (build_leaf_g_kernel below)
+// forward substitution reads  X_j = G[j, 0 : 128 (j+1)] * [X_0; ..; X_{j-1}; B_j], i.e. for each j ONE product
+// whose right operand is simply the first 128 (j+1) rows of the column strip in memory (solved blocks followed
+// by the untouched block j).  One workgroup per 128-column strip runs the v2 main loop nb times, K = 128 (j+1),
+// writing block j in place before block j+1 starts; no synchronisation between workgroups.  Same arithmetic as
+// the launch-per-block leaf (inverses of the 128 x 128 diagonal blocks only) with K = 128..512 instead of 128
+// and one launch instead of seven.
+struct LeafSolveParams {
+  const double* G;  // (128 nb) x (128 nb), row-major, ld = ldg
   long ldg;
-  int nb;           // 128-column blocks in the panel
+  double* B;        // leaf rows of the right-hand sides
+  long ldb;
+  int nb;
+  int m;            // right-hand sides; the last strip may be narrower than 128
 };
 
-__global__ void __launch_bounds__(256, 2) panel_solve_kernel(PanelSolveParams p) {
+__global__ void __launch_bounds__(256, 2) trsm_leaf_kernel(LeafSolveParams p) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int lr = lane & 15, lk = lane >> 4;
-  double* __restrict__ arow = p.A + (long)blockIdx.x * BM * p.lda;
-  const unsigned lane_off = (unsigned)((wm + lk) * (int)p.lda + wn + lr);
+  double* __restrict__ strip = p.B + (long)blockIdx.x * BN;
+  const unsigned lane_off = (unsigned)((wm + lk) * (int)p.ldb + wn + lr);
+  // a narrow last strip (m even): column pairs past m are redirected to the strip's first pair, so every load stays
+  // inside B, and only columns < m are stored -- columns are independent
+  const int ncv = (p.m - (int)blockIdx.x * BN) < BN ? (p.m - (int)blockIdx.x * BN) : BN;
 
   int voffA[2], voffB[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    voffA[h] = ((lane >> 3) * (int)p.lda + 2 * ((lane & 7) ^ ((h * 4 + (lane >> 4)) & 7))) * 8;
-    voffB[h] = ((lane >> 3) * (int)p.ldg + 2 * ((lane & 7) ^ ((h * 4 + (lane >> 4)) & 7))) * 8;
+    voffA[h] = ((lane >> 3) * (int)p.ldg + 2 * ((lane & 7) ^ ((h * 4 + (lane >> 4)) & 7))) * 8;
+    const int cp = lane ^ (h << 3);
+    voffB[h] = 2 * (2 * cp < ncv ? cp : 0) * 8;
   }
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(arow, 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(strip, 0, 0x7FFFFFFF, 0x00020000);
 
   double fa[4][4], fb[4][4];
   d4 acc[4][4];
   for (int jb = 0; jb < p.nb; ++jb) {
     const int nk = (jb + 1) * (BM / BK);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double*>(p.G + (long)jb * BN * p.ldg), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(p.G + (long)jb * BM * p.ldg), 0, 0x7FFFFFFF, 0x00020000);
     auto issue = [&](int kt, int buf) {
       const int k0 = kt * BK;
       double* sa = smem + buf * 2 * V2_TILE;
@@ -577,11 +617,11 @@ __global__ void __launch_bounds__(256, 2) panel_solve_kernel(PanelSolveParams p)
 #pragma unroll
       for (int s = 0; s < 4; ++s)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(sa + (wave * 32 + s * 8) * 16), 16, voffA[s & 1],
-                                                 ((wave * 32 + s * 8) * (int)p.lda + k0) * 8, 0, 0);
+                                                 ((wave * 32 + s * 8) * (int)p.ldg + k0) * 8, 0, 0);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(sb + (wave * 32 + s * 8) * 16), 16, voffB[s & 1],
-                                                 ((wave * 32 + s * 8) * (int)p.ldg + k0) * 8, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(sb + (wave * 4 + s) * 128), 16, voffB[s & 1],
+                                                 ((k0 + wave * 4 + s) * (int)p.ldb) * 8, 0, 0);
     };
     auto read_frags = [&](int ks, int buf) {
       const double* sa = smem + buf * 2 * V2_TILE;
@@ -589,7 +629,7 @@ __global__ void __launch_bounds__(256, 2) panel_solve_kernel(PanelSolveParams p)
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[ks][i] = sa[v2_frag_addr<true>(wm + i * 16 + lr, ks * 4 + lk)];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[ks][j] = sb[v2_frag_addr<true>(wn + j * 16 + lr, ks * 4 + lk)];
+      for (int j = 0; j < 4; ++j) fb[ks][j] = sb[v2_frag_addr<false>(wn + j * 16 + lr, ks * 4 + lk)];
     };
     auto mfma_step = [&](int ks) {
 #pragma unroll
@@ -628,33 +668,45 @@ __global__ void __launch_bounds__(256, 2) panel_solve_kernel(PanelSolveParams p)
       __builtin_amdgcn_sched_barrier(0);
       mfma_step(3);
     }
-    // every wave has consumed block j of the row tile (the barrier of the last k-tile): overwrite it
-    double* cb = arow + jb * BN;
+    // every wave has consumed block j of the strip (the barrier of the last k-tile): overwrite it
+    double* cb = strip + (long)jb * BM * p.ldb;
+    if (ncv == BN) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double* rp = cb + (long)(i * 16 + 4 * r) * p.lda;
+        for (int r = 0; r < 4; ++r) {
+          double* rp = cb + (long)(i * 16 + 4 * r) * p.ldb;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rp[lane_off + j * 16] = acc[i][j][r];
-      }
+          for (int j = 0; j < 4; ++j) rp[lane_off + j * 16] = acc[i][j][r];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double* rp = cb + (long)(i * 16 + 4 * r) * p.ldb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (wn + j * 16 + lr < ncv) rp[lane_off + j * 16] = acc[i][j][r];
+        }
+    }
     // block j is an operand of block j+1: stores complete and visible to the workgroup before the next loads
     __threadfence_block();
     __syncthreads();
   }
 }
 
-// G for one panel: grid (nb, nb), block (j, i) with i <= j.  One workgroup = one 128 x 128 block,
-// MFMA straight from global memory (L2-resident operands, 4 MFLOP per block: latency matters, not rate).
-struct PanelGParams {
-  const double* L;     // top-left of the panel's factored w x w square
+// G of one leaf: grid (nb, nb), block (j, i) with i <= j.  One workgroup = one 128 x 128 block, MFMA straight
+// from global memory (L2-resident operands, 4 MFLOP per block: latency matters, not rate).
+struct LeafGParams {
+  const double* L;     // top-left of the leaf's triangular block
   long ldl;
-  const double* dinv;  // inverse diagonal blocks of the panel, [nb][128][128]
+  const double* dinv;  // inverse diagonal blocks of the leaf, [nb][128][128]
   double* G;
   long ldg;
 };
 
-__global__ void __launch_bounds__(256) build_panel_g_kernel(PanelGParams p) {
+__global__ void __launch_bounds__(256) build_leaf_g_kernel(LeafGParams p) {
   const int jb = blockIdx.x, ib = blockIdx.y;
   if (ib > jb) return;
   const int t = threadIdx.x;
@@ -710,9 +762,10 @@ int launch_t(const GemmParams& p, hipStream_t st) {
   }
   static int use_v2 = -1;
   if (use_v2 < 0) { const char* e = getenv("GPMP_GEMM_V2"); use_v2 = e ? atoi(e) : 1; }
-  // v2 (LDS-direct loads) handles full, aligned tiles only
+  // v2 (LDS-direct loads) needs aligned operands, even M and N, and a k range made of whole 16-wide tiles
   // (v2 wins from K = 512 up: 94 % vs 88-92 % of peak at K = 4096; below that its longer fill costs more)
-  const bool v2ok = use_v2 && p.K >= 512 && p.aligned && (p.M % BM == 0) && (p.N % BN == 0) && (p.K % BK == 0) && p.K > 0 &&
+  const bool v2ok = use_v2 && p.K >= 512 && p.aligned && (p.M % 2 == 0) && (p.N % 2 == 0) && (p.K % BK == 0) && p.K > 0 &&
+                    ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && (p.ldc % 2 == 0) &&
                     (p.lda % 2 == 0) && (p.ldb % 2 == 0) && (p.ldc >= p.N) &&
                     ((long)BM * p.lda * 8 + (long)p.K * 8 < 0x7FFFFFFFL) && ((long)BN * p.ldb * 8 + (long)p.K * 8 < 0x7FFFFFFFL);
   {
@@ -735,26 +788,26 @@ int launch_c(const GemmParams& p, hipStream_t st) {
 
 }  // namespace
 
-int launch_panel_solve(double* A21, long lda, int rows, int nb, const double* L11, const double* dinv_panel,
-                       double* G, bool build_g, hipStream_t st) {
-  // rows must be a multiple of 128 (the caller peels a ragged remainder); nb <= 8
+int launch_trsm_leaf_forward(const double* L, long ldl, const double* dinv_leaf, int nb, double* B, long ldb, int ncols,
+                             double* G, hipStream_t st) {
+  // leaf of nb <= 8 full 128-row blocks; ncols even (16-byte rows), any number of strips, the last one may be narrow
+  if (ncols <= 0) return 0;
   const long ldg = (long)nb * BN;
-  if (build_g) {
-    PanelGParams g{L11, lda, dinv_panel, G, ldg};
-    hipLaunchKernelGGL(build_panel_g_kernel, dim3(nb, nb), dim3(256), 0, st, g);
+  {
+    LeafGParams g{L, ldl, dinv_leaf, G, ldg};
+    hipLaunchKernelGGL(build_leaf_g_kernel, dim3(nb, nb), dim3(256), 0, st, g);
     GPMP_HIP_TRY(hipGetLastError());
   }
-  if (rows <= 0) return 0;
   static bool attr_done = false;
   const size_t lds2 = sizeof(double) * 4 * V2_TILE;
   if (!attr_done) {
-    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_solve_kernel),
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_leaf_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     attr_done = true;
   }
-  PanelSolveParams p{A21, lda, G, ldg, nb};
-  ProfScope ps(PK_GEMM2_NT, st, (double)rows * (double)(nb * BN) * (double)((nb + 1) * BN));
-  hipLaunchKernelGGL(panel_solve_kernel, dim3(rows / BM), dim3(256), lds2, st, p);
+  LeafSolveParams p{G, ldg, B, ldb, nb, ncols};
+  ProfScope ps(PK_GEMM_NN, st, (double)ncols * (double)(nb * BM) * (double)((nb + 1) * BM));   // counted with the small-K NN work it replaces
+  hipLaunchKernelGGL(trsm_leaf_kernel, dim3((ncols + BN - 1) / BN), dim3(256), lds2, st, p);
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -770,14 +823,11 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   p.alpha = alpha; p.beta = beta;
   p.lower_only = o.lower_only; p.kstart_row = o.kstart_row; p.kend_row = o.kend_row;
   p.kstart_col = o.kstart_col; p.kstart_col_off = o.kstart_col_off;
-  p.stagger = o.stagger;
-  p.tile_skip = o.lower_only ? o.tile_skip : 0;
   p.tiles_m = (M + BM - 1) / BM;
   p.tiles_n = (N + BN - 1) / BN;
   if (o.lower_only) {
     const int tn = p.tiles_n < p.tiles_m ? p.tiles_n : p.tiles_m;
-    p.ntiles = tn * (tn + 1) / 2 + (p.tiles_m - tn) * tn - o.tile_skip;
-    if (p.ntiles <= 0) return 0;
+    p.ntiles = tn * (tn + 1) / 2 + (p.tiles_m - tn) * tn;
   } else {
     p.ntiles = p.tiles_m * p.tiles_n;
   }
@@ -796,21 +846,21 @@ int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const d
                 const double* B, long ldb, double beta, double* C, long ldc, const GemmOpts& o,
                 hipStream_t st) {
   if (M <= 0 || N <= 0) return 0;
-  // The LDS-direct kernel takes full tiles only: peel a ragged last tile column / row off a large
-  // rectangular product so that everything else runs on it (e.g. m = 50000 prediction points).
+  // The LDS-direct kernel needs even M and N (16-byte clipping at the edges): peel an odd last row / column off a
+  // large rectangular product so that everything else runs on it.
   const bool plain = !o.lower_only && !o.kstart_row && !o.kend_row && !o.kstart_col;
-  const int Nr = N % BN, Mr = M % BM;
+  const int Nr = N % 2, Mr = M % 2;
   if (plain && (Nr || Mr) && (K % BK == 0) && K >= 512 && (M >= 4 * BM || N >= 4 * BN) && C != A && C != B) {
     const int Mf = M - Mr, Nf = N - Nr;
     int rc = 0;
     if (Mf > 0 && Nf > 0) rc = launch_gemm_one(a_kc, b_kc, Mf, Nf, K, alpha, A, lda, B, ldb, beta, C, ldc, o, st);
     if (rc) return rc;
-    if (Nr > 0) {  // last columns, all rows
+    if (Nr > 0) {  // last column, all rows
       const double* Bn = b_kc ? B + (long)Nf * ldb : B + Nf;
       rc = launch_gemm_one(a_kc, b_kc, M, Nr, K, alpha, A, lda, Bn, ldb, beta, C + Nf, ldc, o, st);
       if (rc) return rc;
     }
-    if (Mr > 0 && Nf > 0) {  // last rows, full-tile columns
+    if (Mr > 0 && Nf > 0) {  // last row, full columns
       const double* Am = a_kc ? A + (long)Mf * lda : A + Mf;
       rc = launch_gemm_one(a_kc, b_kc, Mr, Nf, K, alpha, Am, lda, B, ldb, beta, C + (long)Mf * ldc, ldc, o, st);
     }

@@ -235,33 +235,7 @@ int factor_panel(double* A, int n, long lda, double* dinv, int* info_dev, int p0
   return 0;
 }
 
-// Panel [p0, p1) in the order  potrf(square) -> G -> ONE fused solve of all rows below (gemm_f64.hip:
-// panel_solve_kernel).  On the look-ahead stream every launch of the chain competes with the trailing update
-// for workgroup slots, so the chain is kept to a handful of small launches plus one tall one.
-int factor_panel_fused(double* A, int n, long lda, double* dinv, double* gws, int* info_dev, int p0, int p1, hipStream_t st) {
-  const int sq_end = imin(p1, n);
-  const int w = sq_end - p0, nb = w / NB;
-  double* dpanel = dinv + (size_t)(p0 / NB) * NB * NB;
-  static int coop = -1;
-  if (coop < 0) { const char* e = getenv("GPMP_POTRF_COOP_SQUARE"); coop = e ? atoi(e) : 1; }
-  const bool one_launch = coop && (w % NB == 0) && nb >= 1 && nb <= 8;
-  int rc = one_launch ? launch_chol_square(A + (long)p0 * lda + p0, lda, nb, dpanel, gws, info_dev, p0, st)
-                      : factor_panel(A, sq_end, lda, dinv, info_dev, p0, p1, st);   // the square only: rows p0 .. p1
-  if (rc) return rc;
-  const int below = n - sq_end;
-  if (below <= 0) return 0;
-  const int full = (below / NB) * NB;
-  rc = launch_panel_solve(A + (long)sq_end * lda + p0, lda, full, nb, A + (long)p0 * lda + p0, dpanel, gws, !one_launch, st);
-  if (rc) return rc;
-  if (below > full)
-    rc = trsm_right(A + (long)p0 * lda + p0, w, lda, dpanel, A + (long)(sq_end + full) * lda + p0, below - full, lda, st);
-  return rc;
-}
-
 int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hipStream_t s0) {
-  double* gws = dinv + (size_t)((n + NB - 1) / NB) * NB * NB;   // panel workspace behind the block inverses
-  static int fused = -1;
-  if (fused < 0) { const char* e = getenv("GPMP_POTRF_FUSED_PANEL"); fused = e ? atoi(e) : 0; }
   // panel boundaries: 1024-wide panels while the trailing matrix is large (rank-1024 updates run at
   // ~89 % of the MFMA peak against ~84 % for rank-512, and the longer panel still hides behind them),
   // 512-wide afterwards (shorter latency-bound tail)
@@ -283,16 +257,11 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   g_la.used = 0;
   GemmOpts lower;
   lower.lower_only = 1;
-  static int stagger = -1;
-  if (stagger < 0) { const char* e = getenv("GPMP_POTRF_STAGGER"); stagger = e ? atoi(e) : 1; }
-  GemmOpts lower_main = lower;   // the big update shares the machine with the look-ahead chain
-  lower_main.stagger = stagger;
   // helper starts after everything already queued on the caller's stream (Gram build, memset of info)
   hipEvent_t e = g_la.next();
   GPMP_HIP_TRY(hipEventRecord(e, s0));
   GPMP_HIP_TRY(hipStreamWaitEvent(s1, e, 0));
-  int rc = fused ? factor_panel_fused(A, n, lda, dinv, gws, info_dev, pb[0], pb[1], s1)
-                 : factor_panel(A, n, lda, dinv, info_dev, pb[0], pb[1], s1);
+  int rc = factor_panel(A, n, lda, dinv, info_dev, pb[0], pb[1], s1);
   if (rc) return rc;
   hipEvent_t e_f = g_la.next();                 // panel k factored (on s1)
   GPMP_HIP_TRY(hipEventRecord(e_f, s1));
@@ -305,8 +274,7 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     rc = launch_gemm(true, true, n - p1, p2 - p1, w, -1.0, A + (long)p1 * lda + p0, lda, A + (long)p1 * lda + p0, lda,
                      1.0, A + (long)p1 * lda + p1, lda, lower, s1);
     if (rc) return rc;
-    rc = fused ? factor_panel_fused(A, n, lda, dinv, gws, info_dev, p1, p2, s1)
-               : factor_panel(A, n, lda, dinv, info_dev, p1, p2, s1);
+    rc = factor_panel(A, n, lda, dinv, info_dev, p1, p2, s1);
     if (rc) return rc;
     hipEvent_t e_f_next = g_la.next();
     GPMP_HIP_TRY(hipEventRecord(e_f_next, s1));
@@ -314,7 +282,7 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_f, 0));
     if (p2 < n) {
       rc = launch_gemm(true, true, n - p2, n - p2, w, -1.0, A + (long)p2 * lda + p0, lda, A + (long)p2 * lda + p0, lda,
-                       1.0, A + (long)p2 * lda + p2, lda, lower_main, s0);
+                       1.0, A + (long)p2 * lda + p2, lda, lower, s0);
       if (rc) return rc;
     }
     e_u2 = g_la.next();
@@ -325,113 +293,25 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   return 0;
 }
 
-// Large matrices: only the panel's SQUARE is factored on the look-ahead stream (one small update + one cooperative
-// launch per panel: every launch on that stream queues for ~half a tile time behind the big update, measured in
-// tools/chain_probe.hip, so the launch count is what matters there), while everything with many workgroups stays in
-// order on the caller's stream:
-//   main:    ... update_k (whole trailing matrix except the next square) -> solve_{k+1} (rows below the next square)
-//            -> update_{k+1} ...
-//   helper:  square_{k+1} -= P_k P_k^T ; chol(square_{k+1}) (+ inverse diagonal blocks and G)   [during update_k]
-int potrf_split(double* A, int n, long lda, double* dinv, int* info_dev, hipStream_t s0) {
-  double* gws = dinv + (size_t)((n + NB - 1) / NB) * NB * NB;
-  static int wide_thresh = -1;
-  if (wide_thresh < 0) { const char* e = getenv("GPMP_POTRF_WIDE_ABOVE"); wide_thresh = e ? atoi(e) : 12288; }
-  std::vector<int> pb;
-  for (int p = 0; p < n;) {
-    pb.push_back(p);
-    p += (n - p > wide_thresh) ? 2 * OUTER_BLOCKS * NB : OUTER_BLOCKS * NB;
-  }
-  pb.push_back(n);
-  const int np = (int)pb.size() - 1;
-  if (g_la.helper == nullptr) {
-    int lo = 0, hi = 0;
-    GPMP_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    GPMP_HIP_TRY(hipStreamCreateWithPriority(&g_la.helper, hipStreamNonBlocking, hi));
-  }
-  hipStream_t s1 = g_la.helper;
-  g_la.used = 0;
-  GemmOpts lower;
-  lower.lower_only = 1;
-
-  // square of panel [p0, p1): cooperative launch when it is made of full blocks, launch-per-block otherwise
-  auto factor_square = [&](int p0, int p1, hipStream_t st) -> int {
-    const int w = p1 - p0;
-    if (w % NB == 0 && w / NB <= 8)
-      return launch_chol_square(A + (long)p0 * lda + p0, lda, w / NB, dinv + (size_t)(p0 / NB) * NB * NB, gws, info_dev, p0, st);
-    return factor_panel(A, p1, lda, dinv, info_dev, p0, p1, st);
-  };
-  // rows below the square of panel [p0, p1)
-  auto solve_below = [&](int p0, int p1, hipStream_t st) -> int {
-    const int below = n - p1;
-    if (below <= 0) return 0;
-    const int w = p1 - p0, nb = w / NB;   // p1 < n, so w is a multiple of NB
-    double* dpanel = dinv + (size_t)(p0 / NB) * NB * NB;
-    const int full = (below / NB) * NB;
-    int rc = launch_panel_solve(A + (long)p1 * lda + p0, lda, full, nb, A + (long)p0 * lda + p0, dpanel, gws, false, st);
-    if (rc) return rc;
-    if (below > full)
-      rc = trsm_right(A + (long)p0 * lda + p0, w, lda, dpanel, A + (long)(p1 + full) * lda + p0, below - full, lda, st);
-    return rc;
-  };
-
-  int rc = factor_square(pb[0], pb[1], s0);
-  if (rc) return rc;
-  rc = solve_below(pb[0], pb[1], s0);
-  if (rc) return rc;
-  for (int k = 0; k + 1 < np; ++k) {
-    const int p0 = pb[k], p1 = pb[k + 1], p2 = pb[k + 2];   // panel k = [p0, p1) is final; next = [p1, p2)
-    const int w = p1 - p0, wn = p2 - p1;
-    const bool tiles_ok = (wn % NB == 0);   // the next square is a whole number of tiles: the main update can skip it
-    hipEvent_t e_solved = g_la.next();      // panel k solved (and every earlier update applied) on s0
-    GPMP_HIP_TRY(hipEventRecord(e_solved, s0));
-    GPMP_HIP_TRY(hipStreamWaitEvent(s1, e_solved, 0));
-    const double* Pk = A + (long)p1 * lda + p0;
-    if (tiles_ok) {
-      // helper: next square -= P_k[0:wn] P_k[0:wn]^T, then factor it
-      rc = launch_gemm(true, true, wn, wn, w, -1.0, Pk, lda, Pk, lda, 1.0, A + (long)p1 * lda + p1, lda, lower, s1);
-      if (rc) return rc;
-      rc = factor_square(p1, p2, s1);
-      if (rc) return rc;
-      hipEvent_t e_sq = g_la.next();
-      GPMP_HIP_TRY(hipEventRecord(e_sq, s1));
-      // main: the rest of the trailing matrix
-      GemmOpts rest = lower;
-      rest.tile_skip = (wn / NB) * (wn / NB + 1) / 2;
-      rc = launch_gemm(true, true, n - p1, n - p1, w, -1.0, Pk, lda, Pk, lda, 1.0, A + (long)p1 * lda + p1, lda, rest, s0);
-      if (rc) return rc;
-      GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_sq, 0));
-    } else {
-      // ragged last panel: everything in order on the caller's stream
-      rc = launch_gemm(true, true, n - p1, n - p1, w, -1.0, Pk, lda, Pk, lda, 1.0, A + (long)p1 * lda + p1, lda, lower, s0);
-      if (rc) return rc;
-      rc = factor_square(p1, p2, s0);
-      if (rc) return rc;
-    }
-    rc = solve_below(p1, p2, s0);
-    if (rc) return rc;
-  }
-  return 0;
-}
-
 int potrf_lower(double* A, int n, long lda, double* dinv, int* info_dev, hipStream_t st) {
   GPMP_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
-  if (n <= 2 * OUTER_BLOCKS * NB) {
-    static int coop = -1;
-    if (coop < 0) { const char* e = getenv("GPMP_POTRF_COOP_SMALL"); coop = e ? atoi(e) : 0; }
-    if (coop && n % NB == 0) return launch_chol_square(A, lda, n / NB, dinv, nullptr, info_dev, 0, st);
-    return potrf_blocked(A, n, lda, dinv, info_dev, 0, st);
-  }
-  static int split_above = -1;
-  if (split_above < 0) { const char* e = getenv("GPMP_POTRF_SPLIT_ABOVE"); split_above = e ? atoi(e) : 12288; }
-  if (n > split_above) return potrf_split(A, n, lda, dinv, info_dev, st);
+  if (n <= 2 * OUTER_BLOCKS * NB) return potrf_blocked(A, n, lda, dinv, info_dev, 0, st);
   return potrf_lookahead(A, n, lda, dinv, info_dev, st);
 }
 
+// gws: optional scratch of at least (LEAF_TRSM)^2 doubles; enables the fused leaf (gemm_f64.hip: trsm_leaf_kernel)
 int trsm_forward(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int tri,
-                 int tri_off, hipStream_t st) {
-  if (n <= LEAF_TRSM) return trsm_forward_blocked(L, n, ldl, dinv, B, m, ldb, tri, tri_off, st);
+                 int tri_off, double* gws, hipStream_t st) {
+  if (n <= LEAF_TRSM) {
+    static int fused = -1;
+    if (fused < 0) { const char* e = getenv("GPMP_TRSM_FUSED_LEAF"); fused = e ? atoi(e) : 1; }
+    const bool ok = fused && gws != nullptr && !tri && n % NB == 0 && m >= 4 * NB && (m % 2 == 0) && (ldb % 2 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((long)n * ldb * 8 < 0x7FFFFFFFL);
+    if (ok) return launch_trsm_leaf_forward(L, ldl, dinv, n / NB, B, ldb, m, gws, st);
+    return trsm_forward_blocked(L, n, ldl, dinv, B, m, ldb, tri, tri_off, st);
+  }
   const int n1 = split_point(n);
-  int rc = trsm_forward(L, n1, ldl, dinv, B, m, ldb, tri, tri_off, st);
+  int rc = trsm_forward(L, n1, ldl, dinv, B, m, ldb, tri, tri_off, gws, st);
   if (rc) return rc;
   GemmOpts plain;
   // B2 -= L21 * X1 ; with tri, X1 is non-zero only in its first tri_off + n1 columns and X1[l][c] = 0 for
@@ -442,7 +322,7 @@ int trsm_forward(const double* L, int n, long ldl, const double* dinv, double* B
                    plain, st);
   if (rc) return rc;
   return trsm_forward(L + (long)n1 * ldl + n1, n - n1, ldl, dinv + (size_t)(n1 / NB) * NB * NB, B + (long)n1 * ldb, m, ldb,
-                      tri, tri_off + n1, st);
+                      tri, tri_off + n1, gws, st);
 }
 
 int trsm_backward(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, hipStream_t st) {
@@ -465,7 +345,7 @@ using namespace gpmp;
 
 extern "C" size_t gpmp_dinv_elems(int n) {
   if (n <= 0) return 0;
-  // inverse diagonal blocks + (look-ahead path only) one 1024 x 1024 panel workspace
+  // inverse diagonal blocks + (n > 1024) one 1024 x 1024 scratch area for the fused solve leaves
   return (size_t)((n + NB - 1) / NB) * NB * NB + (n > 2 * OUTER_BLOCKS * NB ? (size_t)4 * OUTER_BLOCKS * OUTER_BLOCKS * NB * NB : 0);
 }
 
@@ -503,7 +383,9 @@ extern "C" int gpmp_trsm_lower(const double* L, int n, long ldl, const double* d
     dinv = scratch;
   }
   if (m <= 4) return trsv_few(L, n, ldl, dinv, B, m, ldb, trans, st);   // HBM-bound fused sweep
-  return trans ? trsm_backward(L, n, ldl, dinv, B, m, ldb, st) : trsm_forward(L, n, ldl, dinv, B, m, ldb, 0, 0, st);
+  // the panel scratch behind the block inverses (n > 1024, see gpmp_dinv_elems) of `scratch` enables the fused leaf
+  double* gws = (scratch != nullptr && n > 2 * OUTER_BLOCKS * NB) ? scratch + (size_t)((n + NB - 1) / NB) * NB * NB : nullptr;
+  return trans ? trsm_backward(L, n, ldl, dinv, B, m, ldb, st) : trsm_forward(L, n, ldl, dinv, B, m, ldb, 0, 0, gws, st);
 }
 
 extern "C" int gpmp_trsm_right_lower(const double* L, int k, long ldl, const double* dinv, double* B, int M, long ldb,
@@ -526,7 +408,7 @@ extern "C" int gpmp_trtri_lower(const double* L, int n, long ldl, const double* 
   hipStream_t st = as_stream(stream);
   int rc = launch_set_identity_lower(T, n, ldt, st);
   if (rc) return rc;
-  return trsm_forward(L, n, ldl, dinv, T, n, ldt, 1, 0, st);
+  return trsm_forward(L, n, ldl, dinv, T, n, ldt, 1, 0, nullptr, st);
 }
 
 extern "C" int gpmp_lauum_lower(const double* T, int n, long ldt, double* Kinv, long ldk, gpmp_stream_t stream) {

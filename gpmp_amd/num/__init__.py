@@ -318,9 +318,11 @@ class CholFactor:
         if Bm.shape[0] != self.n:
             raise ValueError("right-hand side has the wrong number of rows")
         X = as_matrix(Bm, copy=not overwrite)
+        # the factor's workspace doubles as scratch: its tail (n > 1024) feeds the fused forward-solve leaves
+        scratch = _ptr(self.dinv) if self.dinv.numel() >= int(lib.gpmp_dinv_elems(self.n)) else None
         _lib.check(
             lib.gpmp_trsm_lower(_ptr(self.L), self.n, _ld(self.L), _ptr(self.dinv), _ptr(X), X.shape[1], _ld(X),
-                                1 if trans else 0, None, _stream()),
+                                1 if trans else 0, scratch, _stream()),
             "gpmp_trsm_lower",
         )
         return X.reshape(-1) if vec else X

@@ -82,8 +82,8 @@ int gpmp_matern_gram_deriv(const double* x, int n, int d, int p, const double* t
 /* ---- Cholesky and triangular solves ---------------------------------------------------------- */
 
 /* Number of doubles of the factorisation workspace `dinv` for an n x n matrix: the inverses of the
- * ceil(n/128) diagonal blocks, [block][128][128], followed (n > 1024) by one 1024 x 1024 panel scratch area
- * that only gpmp_potrf_lower_async uses. */
+ * ceil(n/128) diagonal blocks, [block][128][128], followed (n > 1024) by one 1024 x 1024 scratch area that the
+ * many-right-hand-side forward solve uses when the buffer is also passed as `scratch` (see gpmp_trsm_lower). */
 size_t gpmp_dinv_elems(int n);
 
 /* In-place lower Cholesky A = L L^T (replaces numpy.linalg.cholesky, numpy_backend.py:466).
@@ -96,7 +96,10 @@ int gpmp_potrf_lower_async(double* A, int n, long lda, double* dinv, int* info_d
 
 /* B <- op(L)^-1 B for an n x m row-major B; trans = 0: L, 1: L^T.  Replaces
  * scipy.linalg.solve_triangular (numpy_backend.py:467-468, gpmp/core/linalg.py:41).  If
- * dinv == NULL the diagonal-block inverses are recomputed into `scratch` (gpmp_dinv_elems(n)). */
+ * dinv == NULL the diagonal-block inverses are recomputed into `scratch` (gpmp_dinv_elems(n)).
+ * `scratch` (gpmp_dinv_elems(n) doubles, may be the same buffer as dinv, may be NULL when dinv is given): for
+ * n > 1024 its tail behind the block inverses is overwritten by the fused solve leaves (trans = 0, m >= 512);
+ * without it the solve runs launch-per-block leaves (same results, about 5 % slower at n = 32768). */
 int gpmp_trsm_lower(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb,
                     int trans, double* scratch, gpmp_stream_t stream);
 

@@ -52,7 +52,9 @@ def param_mean(x, param):
 
 # ------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 384, 64), (130, 70, 33), (1, 5, 3), (257, 129, 130), (64, 1, 200)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 384, 64), (130, 70, 33), (1, 5, 3), (257, 129, 130), (64, 1, 200),
+                                   # K >= 512: the LDS-direct kernel incl. clamped / clipped edge tiles and odd-size peeling
+                                   (256, 256, 512), (1000, 770, 512), (130, 258, 1024), (642, 2, 528), (511, 333, 512), (2, 900, 640)])
 def test_dgemm_matches_numpy(gnp, ta, tb, M, N, K):
     import torch
     from gpmp_amd import _lib
@@ -102,6 +104,49 @@ def test_dgemm_lower_only_skips_upper_tiles(gnp):
     tile = np.add.outer(np.arange(M) // 128, -(np.arange(M) // 128))  # tile_row - tile_col
     assert rel_err(got[tile >= 0], ref[tile >= 0]) < 1e-13
     assert np.array_equal(got[tile < 0], C0[tile < 0])  # untouched
+
+
+def test_dgemm_lower_only_ragged_large_k(gnp):
+    """syrk-shaped update whose last tile row / column is partial (edge tiles of the LDS-direct kernel)"""
+    from gpmp_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    M, K = 1190, 512
+    A = rng.standard_normal((M, K))
+    C0 = rng.standard_normal((M, M))
+    At, Ct = gnp.as_matrix(gnp.asarray(A), copy=True), gnp.as_matrix(gnp.asarray(C0), copy=True)
+    _lib.check(lib.gpmp_dgemm(0, 1, M, M, K, -1.0, gnp._ptr(At), gnp._ld(At), gnp._ptr(At), gnp._ld(At), 1.0, gnp._ptr(Ct), gnp._ld(Ct), 1,
+                              gnp._stream()), "gpmp_dgemm")
+    got, ref = gnp.to_np(Ct), C0 - A @ A.T
+    tile = np.add.outer(np.arange(M) // 128, -(np.arange(M) // 128))
+    assert rel_err(got[tile >= 0], ref[tile >= 0]) < 1e-13
+    assert np.array_equal(got[tile < 0], C0[tile < 0])
+
+
+@pytest.mark.parametrize("n,m", [(1536, 700), (2048, 1024), (1280, 514), (1500, 900)])
+def test_forward_solve_many_rhs_fused_leaves(gnp, n, m):
+    """L^-1 B with the factor's scratch area (n > 1024): fused 512-row leaves incl. a narrow last column strip;
+    n = 1500 has a ragged last leaf (launch-per-block path) behind fused ones"""
+    import scipy.linalg as sla
+    from oracle import gp_oracle as orc
+
+    rng = np.random.default_rng(n + m)
+    x = rng.random((n, 3))
+    K = orc.maternp_covariance(x, None, 2, np.array([0.1, 0.4, 0.2, 0.3])) + 1e-4 * np.eye(n)
+    B = rng.standard_normal((n, m))
+    F = gnp.cholesky_factor(gnp.asarray(K))
+    X = gnp.to_np(F.solve_lower(gnp.asarray(B)))
+    Lr = sla.cholesky(K, lower=True)
+    ref = sla.solve_triangular(Lr, B, lower=True)
+    assert rel_err(X, ref) < 1e-9
+    # the launch-per-block path (no scratch) gives the same answer
+    from gpmp_amd import _lib
+    lib = _lib.load()
+    Xb = gnp.as_matrix(gnp.asarray(B), copy=True)
+    _lib.check(lib.gpmp_trsm_lower(gnp._ptr(F.L), n, gnp._ld(F.L), gnp._ptr(F.dinv), gnp._ptr(Xb), m, gnp._ld(Xb), 0, None, gnp._stream()),
+               "gpmp_trsm_lower")
+    assert rel_err(gnp.to_np(Xb), X) < 1e-11
 
 
 # ------------------------------------------------------------------------------ Matern / Gram
