@@ -157,6 +157,28 @@ int gpmp_matern_grad_trace(const double* Kinv, long ldk, const double* x, int n,
                            int r, long ldf, double* g_dev, double* ws, gpmp_stream_t stream);
 size_t gpmp_grad_ws_elems(int n, int d);
 
+/* ---- fused drivers (zero-mean GP, Matern covariance) ------------------------------------------- */
+
+/* *nll_dev = 1/2 (n ln 2 pi + ln|K| + z^T K^-1 z) with K = gpmp_matern_gram(x) + nugget (or noise variance):
+ * the whole of negative_log_likelihood_zero_mean (gpmp/core/likelihood.py:18-52) -- Gram build, Cholesky,
+ * one triangular solve, two reductions -- enqueued by one call.  x: n x d row-major, z: n, both on the device.
+ * *info_dev as gpmp_potrf_lower_async; when it is non-zero *nll_dev = +inf (the reference returns safe_inf(),
+ * likelihood.py:47-48).  ws: gpmp_nll_ws_elems(n) doubles (holds K / L on return).  Enqueue only. */
+size_t gpmp_nll_ws_elems(int n);
+int gpmp_nll_zero_mean(const double* x, const double* z, int n, int d, int p, const double* theta_host,
+                       int noise, double* ws, double* nll_dev, int* info_dev, gpmp_stream_t stream);
+
+/* Posterior mean and variance at m points: kriging_predictor_with_zero_mean + _compute_posterior_variance
+ * (gpmp/core/kriging.py:35-67,170-199) restated as ONE solve  V = L^-1 K(xi, xt):
+ *   zpm = V^T (L^-1 zi),   zpv = sigma^2 - colsumsq(V)   (clamped at 0 when zero_neg_variances != 0, as
+ * Model.predict does, gpmp/core/model.py:290-296).  xi: n x d, zi: n, xt: m x d, zpm_dev / zpv_dev: m, all on the
+ * device.  A failed factorisation (*info_dev != 0) fills both outputs with NaN.
+ * ws: gpmp_predict_ws_elems(n, m) doubles.  Enqueue only. */
+size_t gpmp_predict_ws_elems(int n, int m);
+int gpmp_predict_zero_mean(const double* xi, const double* zi, const double* xt, int n, int m, int d, int p,
+                           const double* theta_host, int noise, int zero_neg_variances, double* ws,
+                           double* zpm_dev, double* zpv_dev, int* info_dev, gpmp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

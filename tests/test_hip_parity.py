@@ -149,6 +149,93 @@ def test_forward_solve_many_rhs_fused_leaves(gnp, n, m):
     assert rel_err(gnp.to_np(Xb), X) < 1e-11
 
 
+@pytest.mark.parametrize("n,m,d,noise", [(300, 77, 3, 0), (1500, 1000, 4, 0), (640, 130, 2, 1)])
+def test_c_abi_fused_drivers_match_oracle(gnp, n, m, d, noise):
+    """gpmp_nll_zero_mean / gpmp_predict_zero_mean (one C call each) against the oracle's op sequence"""
+    import torch
+    from oracle import gp_oracle as orc
+    from gpmp_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(n + m)
+    xi, xt = rng.random((n, d)), rng.random((m, d))
+    zi = np.sin(3 * xi[:, 0]) + xi.sum(axis=1)
+    th = np.concatenate(([0.3], [-4.0] if noise else [], -np.log(0.4 + 0.3 * np.arange(d))))
+    dev = gnp._dev()
+    X, Z, T = (torch.as_tensor(a, device=dev).contiguous() for a in (xi, zi, xt))
+    hv = _lib.host_vec(th)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    # NLL
+    ws = torch.empty(int(lib.gpmp_nll_ws_elems(n)), dtype=torch.float64, device=dev)
+    nll = torch.empty(1, dtype=torch.float64, device=dev)
+    _lib.check(lib.gpmp_nll_zero_mean(gnp._ptr(X), gnp._ptr(Z), n, d, 2, hv, noise, gnp._ptr(ws), gnp._ptr(nll), gnp._ptr(info), gnp._stream()),
+               "gpmp_nll_zero_mean")
+    cov = (lambda x, y, c, pairwise=False: orc.noisy_maternp_covariance(x, y, 2, c, pairwise)) if noise else \
+          (lambda x, y, c, pairwise=False: orc.maternp_covariance(x, y, 2, c, pairwise))
+    om = orc.OracleModel(None, cov, None, th, "zero")
+    ref = float(orc.negative_log_likelihood_zero_mean(om, th, xi, zi))
+    assert int(info.item()) == 0
+    assert abs(float(nll.item()) - ref) <= 1e-10 * abs(ref)
+    # predict
+    ws = torch.empty(int(lib.gpmp_predict_ws_elems(n, m)), dtype=torch.float64, device=dev)
+    zpm, zpv = (torch.empty(m, dtype=torch.float64, device=dev) for _ in range(2))
+    _lib.check(lib.gpmp_predict_zero_mean(gnp._ptr(X), gnp._ptr(Z), gnp._ptr(T), n, m, d, 2, hv, noise, 1, gnp._ptr(ws), gnp._ptr(zpm),
+                                          gnp._ptr(zpv), gnp._ptr(info), gnp._stream()), "gpmp_predict_zero_mean")
+    rm, rv = orc.predict(om, xi, zi, xt)[:2]
+    assert int(info.item()) == 0
+    np.testing.assert_allclose(gnp.to_np(zpm), rm, rtol=0, atol=1e-9 * np.abs(zi).max())
+    np.testing.assert_allclose(gnp.to_np(zpv), np.maximum(rv, 0.0), rtol=0, atol=1e-9 * math.exp(th[0]))
+
+
+def test_c_host_example_matches_python_path(gp, gnp):
+    """examples/c_abi_predict.c (plain C on the ABI, built by __graft_entry__.build) against the Python layer"""
+    import os, re, subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "c_abi_predict.bin")
+    if not os.path.exists(exe):
+        pytest.skip("C example not built (run __graft_entry__.build())")
+    n, m, d = 1280, 300, 4
+    out = subprocess.run([exe, str(n), str(m)], check=True, capture_output=True, text=True, timeout=120).stdout
+    nll_c = float(re.search(r"nll=([-+0-9.eE]+)", out).group(1))
+    means = [float(v) for v in re.findall(r"mean ([-+0-9.eE]+)", out)]
+    variances = [float(v) for v in re.findall(r"var ([-+0-9.eE]+)", out)]
+    # the example's LCG
+    s, mask, vals = 1234, (1 << 64) - 1, []
+    for _ in range(n * d + m * d):
+        s = (s * 6364136223846793005 + 1442695040888963407) & mask
+        vals.append((s >> 11) / 9007199254740992.0)
+    xi = np.array(vals[: n * d]).reshape(n, d)
+    xt = np.array(vals[n * d:]).reshape(m, d)
+    zi = np.sin(6.283185307179586 * xi[:, 0]) + xi[:, 1:].sum(axis=1)
+    theta = np.concatenate(([0.0], -np.log(0.5 * (1 + np.arange(d) / d))))
+    model = gp.Model(None, gp.kernel.MaternCovariance(2), None, theta, "zero")
+    zpm, zpv = model.predict(xi, zi, xt)
+    nll = float(model.negative_log_likelihood_zero_mean(theta, xi, zi))
+    assert abs(nll_c - nll) <= 1e-10 * abs(nll)
+    np.testing.assert_allclose(means, zpm[:4], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(variances, zpv[:4], rtol=1e-5, atol=1e-12)
+
+
+def test_c_abi_nll_driver_reports_failure_as_inf(gnp):
+    import torch
+    from gpmp_amd import _lib
+
+    lib = _lib.load()
+    n, d = 256, 2
+    x = np.tile(np.random.default_rng(0).random((n // 2, d)), (2, 1))   # duplicated points, huge length-scales
+    th = np.array([0.0, -30.0, -30.0])
+    dev = gnp._dev()
+    X = torch.as_tensor(x, device=dev).contiguous()
+    Z = torch.ones(n, dtype=torch.float64, device=dev)
+    ws = torch.empty(int(lib.gpmp_nll_ws_elems(n)), dtype=torch.float64, device=dev)
+    nll = torch.zeros(1, dtype=torch.float64, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.gpmp_nll_zero_mean(gnp._ptr(X), gnp._ptr(Z), n, d, 2, _lib.host_vec(th), 0, gnp._ptr(ws), gnp._ptr(nll), gnp._ptr(info),
+                                      gnp._stream()), "gpmp_nll_zero_mean")
+    assert int(info.item()) > 0 and math.isinf(float(nll.item()))
+
+
 # ------------------------------------------------------------------------------ Matern / Gram
 def test_matern_kernel_grid(gp, gnp, golden):
     g = golden("matern")
