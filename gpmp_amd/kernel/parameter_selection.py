@@ -53,9 +53,10 @@ def make_selection_criterion_with_gradient(model, selection_criterion, xi=None, 
     ``gradient`` is analytic for the library's ML / REML criteria on a ``MaternCovariance`` and None
     otherwise (SciPy then differentiates numerically, as with the reference's NumPy backend).
     """
-    if dataloader is not None:
-        raise NotImplementedError("dataloaders are outside the hot path (SURVEY.md section 2, row 23)")
-    if xi is None or zi is None:
+    arrays = xi is not None and zi is not None
+    if arrays and dataloader is not None:
+        raise ValueError("Provide either (xi, zi) or dataloader, not both.")   # kernel/utils.py:12-20
+    if not arrays and dataloader is None:
         raise ValueError("Provide either (xi, zi) or dataloader.")
     if parameterized_mean:
 
@@ -67,8 +68,12 @@ def make_selection_criterion_with_gradient(model, selection_criterion, xi=None, 
         def crit_(covparam, xi, zi):
             return selection_criterion(model, covparam, xi, zi)
 
-    xi_, zi_ = gnp.asarray(xi), gnp.asarray(zi)
-    crit = gnp.DifferentiableSelectionCriterion(crit_, xi_, zi_, analytic=_analytic_for(model, selection_criterion, parameterized_mean))
+    analytic = _analytic_for(model, selection_criterion, parameterized_mean)
+    if arrays:
+        xi_, zi_ = gnp.asarray(xi), gnp.asarray(zi)
+        crit = gnp.DifferentiableSelectionCriterion(crit_, xi_, zi_, analytic=analytic)
+    else:   # mini-batches: sized iterable of (x_batch, z_batch)
+        crit = gnp.BatchDifferentiableSelectionCriterion(crit_, dataloader, batches_per_eval=batches_per_eval, analytic=analytic)
     return crit.evaluate, crit.evaluate_pre_grad, crit.evaluate_no_grad, crit.gradient
 
 

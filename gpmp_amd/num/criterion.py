@@ -68,3 +68,100 @@ class DifferentiableSelectionCriterion:
         if self._state is None:
             return numpy.zeros_like(p_arr)  # criterion was +inf at p
         return self._analytic.gradient_from_state(self._state)
+
+
+class BatchDifferentiableSelectionCriterion:
+    """Scalar criterion evaluated on mini-batches: gpmp/num/torch_backend.py:607-718, same constructor
+    arguments, same weighting (each batch value times its size, ``reduction='mean'`` divides by the number of
+    points seen) and the same cycling rule for ``batches_per_eval > 0``.
+
+    ``loader`` is any sized iterable of ``(x_batch, z_batch)``.  The reference differentiates every batch with
+    autograd inside ``evaluate_pre_grad``; here each batch contributes its analytic gradient
+    (``analytic.value_and_state`` + ``gradient_from_state``), and without an analytic form ``gradient`` is None
+    exactly as for the array criterion.
+    """
+
+    def __init__(self, crit, loader, reduction="mean", batches_per_eval=0, analytic=None):
+        if reduction not in ("mean", "sum"):
+            raise ValueError("reduction must be 'mean' or 'sum'")
+        if batches_per_eval < 0:
+            raise ValueError("batches_per_eval must be >= 0")
+        if len(loader) == 0:
+            raise ValueError("DataLoader is empty.")
+        self.crit, self.loader, self.reduction, self.bpe = crit, loader, reduction, int(batches_per_eval)
+        self._batch_iter = iter(loader) if self.bpe > 0 else None
+        self._analytic = analytic
+        self._gradient = None
+        self.gradient = None if analytic is None else self._cached_gradient
+
+    def __call__(self, p):
+        return self.evaluate(p)
+
+    def _batches(self):
+        if self.bpe == 0:
+            yield from self.loader
+            return
+        for _ in range(self.bpe):
+            try:
+                yield next(self._batch_iter)
+            except StopIteration:
+                self._batch_iter = iter(self.loader)
+                yield next(self._batch_iter)
+
+    @staticmethod
+    def _prepare(xb, zb):
+        from . import asarray
+
+        return asarray(xb), asarray(zb)
+
+    def _reduce(self, total, n):
+        if n == 0:
+            raise ValueError("Loader is empty.")
+        return total / n if self.reduction == "mean" else total
+
+    def evaluate(self, p):
+        total, n = 0.0, 0
+        for xb, zb in self._batches():
+            xb, zb = self._prepare(xb, zb)
+            bs = xb.shape[0]
+            total += float(self.crit(p, xb, zb)) * bs
+            n += bs
+        return self._reduce(total, n)
+
+    def evaluate_no_grad(self, p):
+        try:
+            return self.evaluate(p)
+        except Exception as exc:
+            if _is_linalg_exception(exc):
+                return math.inf
+            raise
+
+    def evaluate_pre_grad(self, p):
+        p_arr = numpy.array(numpy.asarray(p, dtype=numpy.float64), copy=True)
+        if self._analytic is None:
+            return self.evaluate_no_grad(p_arr)
+        total, n, grad = 0.0, 0, numpy.zeros_like(p_arr)
+        try:
+            for xb, zb in self._batches():
+                xb, zb = self._prepare(xb, zb)
+                bs = xb.shape[0]
+                value, state = self._analytic.value_and_state(p_arr, xb, zb)
+                grad += bs * numpy.asarray(self._analytic.gradient_from_state(state), dtype=numpy.float64)
+                total += float(value) * bs
+                n += bs
+        except Exception as exc:
+            if _is_linalg_exception(exc):
+                self._gradient = numpy.zeros_like(p_arr)
+                return math.inf
+            raise
+        if n == 0:
+            raise ValueError("Loader is empty.")
+        if self.reduction == "mean":
+            total, grad = total / n, grad / n
+        self._gradient = grad
+        return total
+
+    def _cached_gradient(self, _p):
+        if self._gradient is None:
+            raise RuntimeError("Call `evaluate_pre_grad` first.")
+        return self._gradient

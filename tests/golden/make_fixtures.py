@@ -366,10 +366,54 @@ def torch_pass():
     path = os.path.join(HERE, "ref_gradients.npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+    gen_batch_criterion()
+
+
+def gen_batch_criterion():
+    """BatchDifferentiableSelectionCriterion (gpmp/num/torch_backend.py:607-718) on a list-of-batches loader:
+    full-epoch evaluation and the cycling batches_per_eval mode, ML and REML, value + autograd gradient."""
+    import torch
+
+    out = {}
+    rng = np.random.default_rng(77)
+    n, d, p = 330, 3, 2
+    xi, zi = make_xz(n, d, 78)
+    sizes = [100, 100, 80, 50]                      # ragged last batches
+    bounds = np.concatenate(([0], np.cumsum(sizes)))
+    out["batch_xi"], out["batch_zi"], out["batch_bounds"], out["batch_p"] = xi, zi, bounds, np.array(p)
+    loader = [(torch.as_tensor(xi[a:b]), torch.as_tensor(zi[a:b])) for a, b in zip(bounds[:-1], bounds[1:])]
+    k = make_kernel(p)
+    thetas = np.stack([theta_aniso(d) + 0.2 * rng.standard_normal(d + 1) for _ in range(3)])
+    out["batch_thetas"] = thetas
+    for name, model, crit_fn in (
+        ("nll", gp.core.Model(None, k, None, None, "zero"), gp.kernel.negative_log_likelihood_zero_mean),
+        ("reml", gp.core.Model(constant_mean, k, None, None, "linear_predictor"), gp.kernel.negative_log_restricted_likelihood),
+    ):
+        ev, pre, nograd, grad = gp.kernel.make_selection_criterion_with_gradient(model, crit_fn, dataloader=loader)
+        vals, grads, ng = [], [], []
+        for t in thetas:
+            tt = torch.as_tensor(t, dtype=torch.float64)
+            vals.append(float(pre(tt)))
+            grads.append(tonp(grad(tt)))
+            ng.append(float(nograd(tt)))
+        out[f"batch_{name}_val"], out[f"batch_{name}_grad"], out[f"batch_{name}_nograd"] = np.array(vals), np.stack(grads), np.array(ng)
+        # cycling mode: 3 batches per call over a 4-batch loader -> calls see batches (0,1,2), (3,0,1), (2,3,0)
+        ev, pre, nograd, grad = gp.kernel.make_selection_criterion_with_gradient(model, crit_fn, dataloader=loader, batches_per_eval=3)
+        tt = torch.as_tensor(thetas[0], dtype=torch.float64)
+        cyc_v, cyc_g = [], []
+        for _ in range(3):
+            cyc_v.append(float(pre(tt)))
+            cyc_g.append(tonp(grad(tt)))
+        out[f"batch_{name}_cycle_val"], out[f"batch_{name}_cycle_grad"] = np.array(cyc_v), np.stack(cyc_g)
+    path = os.path.join(HERE, "ref_batch.npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
 if __name__ == "__main__":
     if backend == "numpy":
         numpy_pass()
+    elif len(sys.argv) > 2 and sys.argv[2] == "batch":
+        gen_batch_criterion()
     else:
         torch_pass()

@@ -475,6 +475,38 @@ def test_gradients_vs_reference_autograd(gp, gnp, golden, tag):
             assert rel_err(gr, g[f"grad_{tag}_{name}_grad"][i]) < 1e-7, (name, i)
 
 
+def test_batch_criterion_vs_reference(gp, gnp, golden):
+    """make_selection_criterion_with_gradient(dataloader=...) -- gnp.BatchDifferentiableSelectionCriterion -- against
+    the reference's torch batch wrapper: full epoch, cycling batches_per_eval, analytic vs autograd gradient"""
+    g = golden("batch")
+    p, b = int(g["batch_p"]), g["batch_bounds"]
+    loader = [(g["batch_xi"][a:c], g["batch_zi"][a:c]) for a, c in zip(b[:-1], b[1:])]
+    k = gp.kernel.MaternCovariance(p)
+    cases = (
+        ("nll", gp.Model(None, k, None, None, "zero"), gp.kernel.negative_log_likelihood_zero_mean),
+        ("reml", gp.Model(constant_mean, k, None, None), gp.kernel.negative_log_restricted_likelihood),
+    )
+    for name, model, crit in cases:
+        ev, pre, nograd, grad = gp.kernel.make_selection_criterion_with_gradient(model, crit, dataloader=loader)
+        assert grad is not None
+        for i, t in enumerate(g["batch_thetas"]):
+            v = pre(t)
+            assert abs(v - g[f"batch_{name}_val"][i]) < 1e-9 * abs(v), (name, i)
+            assert rel_err(grad(t), g[f"batch_{name}_grad"][i]) < 1e-7, (name, i)
+            assert abs(nograd(t) - g[f"batch_{name}_nograd"][i]) < 1e-9 * abs(v)
+            assert abs(ev(t) - g[f"batch_{name}_val"][i]) < 1e-9 * abs(v)
+        ev, pre, nograd, grad = gp.kernel.make_selection_criterion_with_gradient(model, crit, dataloader=loader, batches_per_eval=3)
+        t = g["batch_thetas"][0]
+        for c in range(3):
+            v = pre(t)
+            assert abs(v - g[f"batch_{name}_cycle_val"][c]) < 1e-9 * abs(v), (name, c)
+            assert rel_err(grad(t), g[f"batch_{name}_cycle_grad"][c]) < 1e-7, (name, c)
+    with pytest.raises(ValueError):
+        gp.kernel.make_selection_criterion_with_gradient(cases[0][1], cases[0][2], g["batch_xi"], g["batch_zi"], dataloader=loader)
+    with pytest.raises(ValueError):
+        gp.kernel.make_selection_criterion_with_gradient(cases[0][1], cases[0][2], dataloader=[])
+
+
 @pytest.mark.parametrize("tag", ["na", "nb"])
 def test_gradients_noisy_kernel(gp, gnp, golden, tag):
     g = golden("gradients")
