@@ -42,16 +42,19 @@ def synth(n, m, d, rank):
 
 def pmc_traffic_per_launch(kernel_substr):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r1/bench_v3_pmc_{fetch,write}_size_by_kernel.csv; FETCH_SIZE / WRITE_SIZE are in KB and, on gfx950,
+    (profiles/r*/bench_v*_pmc_{fetch,write}_size_by_kernel.csv, latest; FETCH_SIZE / WRITE_SIZE are in KB and, on gfx950,
     FETCH_SIZE reports half of a wide streaming read -- MI355X_MICROARCH.md, HBM section).  None if absent."""
     import csv
+
+    import glob
 
     tot = 0.0
     n_disp = None
     for name, factor in (("fetch", 2.0), ("write", 1.0)):
-        path = os.path.join(ROOT, "profiles", "r1", f"bench_v3_pmc_{name}_size_by_kernel.csv")
-        if not os.path.exists(path):
+        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"bench_v*_pmc_{name}_size_by_kernel.csv")))
+        if not found:
             return None
+        path = found[-1]   # the latest committed pass
         for row in csv.DictReader(open(path)):
             if kernel_substr in row["kernel"]:
                 tot += factor * 1024.0 * float(row["per_dispatch_KB_raw"])

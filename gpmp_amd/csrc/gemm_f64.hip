@@ -67,6 +67,17 @@ __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& t
       ti = tn + rr / tn;
       tj = rr % tn;
     }
+  } else if (p.kstart_col | p.kend_row) {
+    // unequal k ranges: longest tiles first, so that the last workgroups to start are the short ones
+    // (kstart_col: tile column 0 has the full k range; kend_row: the last tile row has it)
+    if (p.kstart_col) {
+      tj = v / p.tiles_m;
+      ti = v - tj * p.tiles_m;
+    } else {
+      const int r = v / p.tiles_n;
+      ti = p.tiles_m - 1 - r;
+      tj = v - r * p.tiles_n;
+    }
   } else {
     constexpr int GM = 8;
     const int per_group = GM * p.tiles_n;
