@@ -759,6 +759,109 @@ __global__ void __launch_bounds__(256) build_leaf_g_kernel(LeafGParams p) {
         out[(long)(wm + i * 16 + lk + 4 * r) * p.ldg + wn + j * 16 + lr] = -acc[i][j][r];
 }
 
+// ================================================================================================
+// Latency kernel for the panel chain of the Cholesky (NT products with K = 128 on a grid far smaller than the
+// machine: A21 <- A21 inv(L_kk)^T and the rank-128 updates inside a panel).  A 128 x 128 x 128 tile is 4.2 MFLOP,
+// i.e. 14 us of MFMA on one CU however fast its operands arrive (measured 22 us per launch for ANY tile count up to
+// 256); 32 x 128 tiles put four times as many CUs on the same product.  A tile spans 128 columns so that the
+// in-place panel scaling (C == A, N == K == 128) stays race-free: a workgroup reads its 32 rows completely before
+// it writes them and nobody else touches them.  All operands of up to 8 k-tiles are requested before the first is
+// used, so one load latency is exposed per launch.  Edge tiles and lower-only products are predicated.
+constexpr int SBM = 32, SBN = 128, SLD = 18;   // tile shape, padded row stride of a [rows][16] operand image
+
+__global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) double sA[2][SBM * SLD];
+  __shared__ __attribute__((aligned(16))) double sB[2][SBN * SLD];
+  const int row0 = blockIdx.y * SBM, col0 = blockIdx.x * SBN;
+  if (p.lower_only && col0 > row0 + SBM - 1) return;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wn = wave * 32;
+  const int lr = lane & 15, lk = lane >> 4;
+  // staging: thread t owns k quad (t & 3) of row (t >> 2) of A (t < 128) and of rows (t >> 2), (t >> 2) + 64 of B
+  const int srow = t >> 2, skq = (t & 3) * 4;
+  const bool has_a = t < 4 * SBM;
+  int ar = row0 + (has_a ? srow : 0), br0 = col0 + srow, br1 = col0 + srow + 64;
+  ar = ar < p.M ? ar : p.M - 1;     // clamped rows only feed outputs that are never stored
+  br0 = br0 < p.N ? br0 : p.N - 1;
+  br1 = br1 < p.N ? br1 : p.N - 1;
+  const double* __restrict__ ap = p.A + (long)ar * p.lda + skq;
+  const double* __restrict__ bp0 = p.B + (long)br0 * p.ldb + skq;
+  const double* __restrict__ bp1 = p.B + (long)br1 * p.ldb + skq;
+
+  d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const int nk = p.K / BK;
+  for (int kc = 0; kc < nk; kc += 8) {
+    const int cnt = (nk - kc) < 8 ? (nk - kc) : 8;
+    d2 ra[8][2], rb[8][4];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q < cnt) {
+        const int ko = (kc + q) * BK;
+        if (has_a) {
+          ra[q][0] = *reinterpret_cast<const d2*>(ap + ko);
+          ra[q][1] = *reinterpret_cast<const d2*>(ap + ko + 2);
+        }
+        rb[q][0] = *reinterpret_cast<const d2*>(bp0 + ko);
+        rb[q][1] = *reinterpret_cast<const d2*>(bp0 + ko + 2);
+        rb[q][2] = *reinterpret_cast<const d2*>(bp1 + ko);
+        rb[q][3] = *reinterpret_cast<const d2*>(bp1 + ko + 2);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q < cnt) {
+        const int buf = q & 1;
+        if (has_a) {
+          *reinterpret_cast<d2*>(&sA[buf][srow * SLD + skq]) = ra[q][0];
+          *reinterpret_cast<d2*>(&sA[buf][srow * SLD + skq + 2]) = ra[q][1];
+        }
+        *reinterpret_cast<d2*>(&sB[buf][srow * SLD + skq]) = rb[q][0];
+        *reinterpret_cast<d2*>(&sB[buf][srow * SLD + skq + 2]) = rb[q][1];
+        *reinterpret_cast<d2*>(&sB[buf][(srow + 64) * SLD + skq]) = rb[q][2];
+        *reinterpret_cast<d2*>(&sB[buf][(srow + 64) * SLD + skq + 2]) = rb[q][3];
+        __syncthreads();   // image q complete; image q-1 (other buffer) was released by the previous barrier
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          double fa[2], fb[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) fa[i] = sA[buf][(16 * i + lr) * SLD + 4 * ks + lk];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) fb[j] = sB[buf][(wn + 16 * j + lr) * SLD + 4 * ks + lk];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();   // both images free before the next chunk overwrites them
+  }
+
+  const double alpha = p.alpha, beta = p.beta;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 16 * i + 4 * r + lk;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = col0 + wn + 16 * j + lr;
+        if (row < p.M && col < p.N) {
+          double* cp = p.C + (long)row * p.ldc + col;
+          double v = alpha * acc[i][j][r];
+          if (beta != 0.0) v += beta * *cp;
+          *cp = v;
+        }
+      }
+    }
+}
+
 template <bool AKC, bool BKC, bool CACC>
 int launch_t(const GemmParams& p, hipStream_t st) {
   static bool attr_done = false;
@@ -779,12 +882,18 @@ int launch_t(const GemmParams& p, hipStream_t st) {
                     ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && (p.ldc % 2 == 0) &&
                     (p.lda % 2 == 0) && (p.ldb % 2 == 0) && (p.ldc >= p.N) &&
                     ((long)BM * p.lda * 8 + (long)p.K * 8 < 0x7FFFFFFFL) && ((long)BN * p.ldb * 8 + (long)p.K * 8 < 0x7FFFFFFFL);
+  // small NT products on a grid that cannot fill the machine: 64 x 64 tiles (latency kernel above)
+  static int use_small = -1;
+  if (use_small < 0) { const char* e = getenv("GPMP_GEMM_SMALL_NT"); use_small = e ? atoi(e) : 1; }
+  const bool small_nt = AKC && BKC && !v2ok && use_small && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
+                        p.ntiles <= 128 && !(p.kstart_row | p.kend_row | p.kstart_col);
   {
     // executed flops of this launch (tiles actually visited, k range actually swept)
     const double kavg = (p.kstart_row || p.kend_row || p.kstart_col) ? 0.5 * p.K : (double)p.K;
     ProfScope ps((AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN)) + (v2ok ? 8 : 0), st,
                  2.0 * (double)p.ntiles * BM * BN * kavg);
     if (v2ok) hipLaunchKernelGGL((gemm_f64_kernel_v2<AKC, BKC, CACC>), dim3(p.ntiles), dim3(256), lds2, st, p);
+    else if (small_nt) hipLaunchKernelGGL(gemm_nt_small_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC, CACC>), dim3(p.ntiles), dim3(256), lds, st, p);
   }
   GPMP_HIP_TRY(hipGetLastError());

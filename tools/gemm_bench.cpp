@@ -44,6 +44,7 @@ int main(int argc, char** argv) {
   if (which < 0 || which == 6) run("square TN K=4096", 1, 0, 8192, 8192, 4096, 0, 0.0, reps);
   if (which < 0 || which == 7) run("small NT L2-resident K=4096", 0, 1, 2048, 2048, 4096, 0, 0.0, reps);
   if (which < 0 || which == 8) run("panel scale N=128 K=128", 0, 1, 32640, 128, 128, 0, 0.0, reps);
+  if (which == 30) { for (int M : {128, 1024, 4096, 32640}) { run("panel scale NT N=128 K=128 b0", 0, 1, M, 128, 128, 0, 0.0, reps); run("rank-128 update NT N=384 b1", 0, 1, M, 384, 128, 0, 1.0, reps); run("NN K=128 N=4096 b1", 0, 0, M, 4096, 128, 0, 1.0, reps); } }
   if (which == 20) { for (int K : {128, 256, 512, 1024, 2048, 4096}) { run("NN beta=1 K sweep", 0, 0, 16384, 16384, K, 0, 1.0, reps); run("NN beta=0 K sweep", 0, 0, 16384, 16384, K, 0, 0.0, reps); } }
   return 0;
 }
