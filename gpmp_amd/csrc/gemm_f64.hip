@@ -885,15 +885,15 @@ int launch_t(const GemmParams& p, hipStream_t st) {
   // small NT products on a grid that cannot fill the machine: 64 x 64 tiles (latency kernel above)
   static int use_small = -1;
   if (use_small < 0) { const char* e = getenv("GPMP_GEMM_SMALL_NT"); use_small = e ? atoi(e) : 1; }
-  const bool small_nt = AKC && BKC && !v2ok && use_small && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
-                        p.ntiles <= 128 && !(p.kstart_row | p.kend_row | p.kstart_col);
+  const bool small_nt = AKC && BKC && use_small && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
+                        p.ntiles <= (p.K >= 512 ? 384 : 128) && !(p.kstart_row | p.kend_row | p.kstart_col);
   {
     // executed flops of this launch (tiles actually visited, k range actually swept)
     const double kavg = (p.kstart_row || p.kend_row || p.kstart_col) ? 0.5 * p.K : (double)p.K;
-    ProfScope ps((AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN)) + (v2ok ? 8 : 0), st,
+    ProfScope ps((AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN)) + ((v2ok && !small_nt) ? 8 : 0), st,
                  2.0 * (double)p.ntiles * BM * BN * kavg);
-    if (v2ok) hipLaunchKernelGGL((gemm_f64_kernel_v2<AKC, BKC, CACC>), dim3(p.ntiles), dim3(256), lds2, st, p);
-    else if (small_nt) hipLaunchKernelGGL(gemm_nt_small_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
+    if (small_nt) hipLaunchKernelGGL(gemm_nt_small_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
+    else if (v2ok) hipLaunchKernelGGL((gemm_f64_kernel_v2<AKC, BKC, CACC>), dim3(p.ntiles), dim3(256), lds2, st, p);
     else hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC, CACC>), dim3(p.ntiles), dim3(256), lds, st, p);
   }
   GPMP_HIP_TRY(hipGetLastError());

@@ -52,6 +52,13 @@ __device__ __forceinline__ double rsqrt_full(double d) {
   return y;
 }
 
+#ifdef GPMP_POTF2_TRACE   // tools/potf2_probe.hip
+__device__ long long g_potf2_trace[64];
+#define PF_MARK(slot) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_potf2_trace[slot] = (long long)wall_clock64(); } while (0)
+#else
+#define PF_MARK(slot) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__ A, long lda, int n_total,
                                                             double* __restrict__ dinv, int* info, int offset,
                                                             int do_factor) {
@@ -70,15 +77,28 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
   const int lr = lane & 15, lk = lane >> 4;
 
   // ---- load: lower triangle of the jb x jb block, identity padding, zeros elsewhere
-  for (int idx = t; idx < NB * NB; idx += THREADS) {
-    const int i = idx >> 7, j = idx & (NB - 1);
-    if ((i >> 4) < (j >> 4)) continue;   // sub-block above the diagonal: not stored
-    double v = (i == j) ? 1.0 : 0.0;
-    if (i < jb && j <= i) v = A[(long)i * lda + j];
-    S[pidx(i, j)] = v;
+  PF_MARK(0);
+  // (all 32 loads of a thread are issued before the first LDS store: one exposed latency instead of 32 -- the
+  //  rolled loop took 16 us of the kernel's 65; phase timeline: tools/potf2_probe.hip)
+  {
+    double v[NB * NB / THREADS];
+#pragma unroll
+    for (int q = 0; q < NB * NB / THREADS; ++q) {
+      const int idx = t + q * THREADS;
+      const int i = idx >> 7, j = idx & (NB - 1);
+      v[q] = (i == j) ? 1.0 : 0.0;
+      if (i < jb && j <= i) v[q] = A[(long)i * lda + j];
+    }
+#pragma unroll
+    for (int q = 0; q < NB * NB / THREADS; ++q) {
+      const int idx = t + q * THREADS;
+      const int i = idx >> 7, j = idx & (NB - 1);
+      if ((i >> 4) >= (j >> 4)) S[pidx(i, j)] = v[q];   // sub-blocks above the diagonal are not stored
+    }
   }
   __syncthreads();
 
+  PF_MARK(1);
   if (do_factor) {
     for (int j = 0; j < NSB; ++j) {
       const int j0 = j * SB;
@@ -112,6 +132,7 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
         }
       }
       __syncthreads();
+      PF_MARK(8 + 3 * j);
       // ---- A2: panel rows below the diagonal block: x L_jj^T = a, one row per thread
       {
         const int row = j0 + SB + t;
@@ -131,6 +152,7 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
         }
       }
       __syncthreads();
+      PF_MARK(9 + 3 * j);
       // ---- A3: trailing update on MFMA: blocks (bi, bk), j < bk <= bi < 8
       {
         const int rem = NSB - 1 - j;
@@ -157,7 +179,9 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
         }
       }
       __syncthreads();
+      PF_MARK(10 + 3 * j);
     }
+    PF_MARK(2);
     // factor back to global memory (lower triangle only)
     for (int idx = t; idx < NB * NB; idx += THREADS) {
       const int i = idx >> 7, j = idx & (NB - 1);
@@ -168,6 +192,7 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
     __syncthreads();
   }
 
+  PF_MARK(3);
   // ---- phase B: T_ww = L_ww^-1 for the 8 diagonal 16 x 16 blocks, wave w, column (lane & 15) per lane
   {
     const double* Dww = S + ((wave * (wave + 1) / 2 + wave) << 8);
@@ -188,6 +213,7 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
   }
   __syncthreads();
 
+  PF_MARK(4);
   // ---- phase C + D: wave w computes block column w of T = L^-1, keeps it in registers, streams it out.
   {
     const int bj = wave;
@@ -227,6 +253,7 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
         tcol[bi] = res;
       }
     }
+    PF_MARK(5);
     // phase D: block column bj of dinv (row-major NB x NB): zeros above, Td on the diagonal, tcol below
 #pragma unroll
     for (int bi = 0; bi < NSB; ++bi) {
@@ -240,6 +267,7 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
       }
     }
   }
+  PF_MARK(6);
 }
 
 int launch(double* A, long lda, int n_total, int nblocks, double* dinv, int* info_dev, int offset,

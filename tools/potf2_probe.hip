@@ -1,0 +1,27 @@
+// Diagnostic: phase timeline of potf2_inv_kernel on one 128 x 128 SPD block (100 MHz wall clock).
+#define GPMP_POTF2_TRACE 1
+#include "../gpmp_amd/csrc/potf2.hip"
+#include <vector>
+#include <cmath>
+using namespace gpmp;
+int main() {
+  const int n = 128;
+  std::vector<double> h((size_t)n * n);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) h[(size_t)i * n + j] = (i == j ? n + 1.0 : std::cos(0.37 * i * j + 0.11 * (i + j)));
+  double *A, *dinv; int* info;
+  if (hipMalloc(&A, h.size() * 8) != hipSuccess || hipMalloc(&dinv, (size_t)n * n * 8) != hipSuccess || hipMalloc(&info, 4) != hipSuccess) return 1;
+  for (int rep = 0; rep < 3; ++rep) {
+    (void)hipMemcpy(A, h.data(), h.size() * 8, hipMemcpyHostToDevice); (void)hipMemset(info, 0, 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, 0);
+    launch_potf2_inv(A, n, n, dinv, info, 0, 0);
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); printf("rep %d: %.1f us\n", rep, ms * 1e3);
+  }
+  long long tr[64];
+  (void)hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_potf2_trace), sizeof(tr));
+  auto us = [&](int s) { return (tr[s] - tr[0]) * 0.01; };
+  printf("load done %.1f | factor done %.1f | L stored %.1f | B done %.1f | C done %.1f | end %.1f\n", us(1), us(2), us(3), us(4), us(5), us(6));
+  for (int j = 0; j < 8; ++j) printf("  j=%d: A1 done %.1f  A2 done %.1f  A3 done %.1f\n", j, us(8 + 3 * j), us(9 + 3 * j), us(10 + 3 * j));
+  return 0;
+}
