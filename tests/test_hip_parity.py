@@ -124,6 +124,35 @@ def test_dgemm_lower_only_ragged_large_k(gnp):
     assert np.array_equal(got[tile < 0], C0[tile < 0])
 
 
+@pytest.mark.parametrize("n,rho", [(1024, 3.0), (2048, 3.0), (1536, 8.0)])
+def test_cholesky_backward_error_ill_conditioned(gnp, n, rho):
+    """Smooth kernel, long length-scales: cond(K) up to ~1e13 with only the reference's 10 eps nugget (hard
+    part ii).  The blocked factorisation (explicit inverses of the 128 x 128 diagonal blocks) must stay backward stable:
+    ||L L^T - K|| / ||K|| of the order of eps, and the solve residual of the order of eps * cond-independent bound."""
+    import scipy.linalg as sla
+    from oracle import gp_oracle as orc
+
+    rng = np.random.default_rng(n)
+    x = rng.random((n, 2))
+    th = np.array([0.0, -math.log(rho), -math.log(rho)])
+    K = orc.maternp_covariance(x, None, 2, th)          # includes the 10 sigma^2 eps nugget
+    try:
+        Lr = sla.cholesky(K, lower=True)
+    except np.linalg.LinAlgError:
+        Lr = None
+    try:
+        F = gnp.cholesky_factor(gnp.asarray(K))
+    except np.linalg.LinAlgError:
+        assert Lr is None or np.min(np.diag(Lr)) < 1e-6, "HIP factorisation failed where LAPACK succeeds comfortably"
+        return
+    L = np.tril(gnp.to_np(F.L))
+    assert np.linalg.norm(L @ L.T - K) / np.linalg.norm(K) < 200 * np.finfo(float).eps
+    b = rng.standard_normal(n)
+    xs = gnp.to_np(F.solve(gnp.asarray(b)))
+    # normwise backward error of the solve
+    assert np.linalg.norm(K @ xs - b) / (np.linalg.norm(K, 2) * np.linalg.norm(xs) + np.linalg.norm(b)) < 1e-12
+
+
 @pytest.mark.parametrize("n,m", [(1536, 700), (2048, 1024), (1280, 514), (1500, 900)])
 def test_forward_solve_many_rhs_fused_leaves(gnp, n, m):
     """L^-1 B with the factor's scratch area (n > 1024): fused 512-row leaves incl. a narrow last column strip;
