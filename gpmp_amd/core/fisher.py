@@ -77,3 +77,17 @@ def fisher_information_cpd(model, xi, covparam=None, epsilon: float = 1e-3):
         KD = F.solve(D)
         B.append(KD - US @ (U.T @ D))
     return _pairwise_half_traces(B)
+
+
+def fisher_information_torch(model, xi, covparam):
+    """gpmp/core/fisher.py:158-191: 0.5 * Hessian of log|K(theta)| through ``gnp.SecondOrderDifferentiableFunction``
+    (second-order autograd in the reference's torch backend; central finite differences of the HIP log-det here)."""
+    xi = gnp.asarray(xi)
+
+    def log_det_cov(params):
+        return gnp.cholesky_factor(gnp.asarray(model.covariance(xi, xi, params)), overwrite=True).logdet()
+
+    sodf = gnp.SecondOrderDifferentiableFunction(log_det_cov)
+    sodf.evaluate(np.asarray(gnp.to_np(covparam), dtype=np.float64))
+    sodf.gradient()
+    return 0.5 * sodf.hessian()

@@ -4,7 +4,7 @@ Same constructor, attributes and method signatures as the reference ``Model`` fo
 ``predict`` / ``loo`` / ``negative_log_likelihood*`` / ``negative_log_restricted_likelihood`` /
 ``norm_k_sqrd*`` / ``k_inverses`` and the kriging predictors; the arithmetic runs in libgpmp_hip.so.
 Also carried: Fisher information (analytic covariance derivatives) and sample paths by
-the Cholesky route; ``fisher_information_torch`` (autograd Hessian) has no counterpart here.
+the Cholesky route; ``fisher_information_torch`` differentiates the HIP log-det by finite differences.
 """
 import warnings
 
@@ -104,6 +104,10 @@ class Model:
 
     def fisher_information_cpd(self, xi, covparam=None, epsilon=1e-3):
         return fisher.fisher_information_cpd(self, xi, covparam=covparam, epsilon=epsilon)
+
+    def fisher_information_torch(self, xi, covparam):
+        """gpmp/core/model.py:569-571 (0.5 * Hessian of log|K|; finite differences on this backend)."""
+        return fisher.fisher_information_torch(self, xi, covparam)
 
     # ------------------------------------------------------------------ sample paths (gpmp/core/model.py:576-696)
     def sample_paths(self, xt, nb_paths, method="chol", check_result=True):

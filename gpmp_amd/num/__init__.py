@@ -529,4 +529,5 @@ def randn(*shape):
     return torch.randn(shape, dtype=torch.float64, device=_dev(), generator=_generator())
 
 
-from .criterion import BatchDifferentiableSelectionCriterion, DifferentiableSelectionCriterion  # noqa: E402,F401
+from .criterion import (BatchDifferentiableSelectionCriterion, DifferentiableSelectionCriterion,  # noqa: E402,F401
+                        SecondOrderDifferentiableFunction)

@@ -165,3 +165,55 @@ class BatchDifferentiableSelectionCriterion:
         if self._gradient is None:
             raise RuntimeError("Call `evaluate_pre_grad` first.")
         return self._gradient
+
+
+class SecondOrderDifferentiableFunction:
+    """Gradient and Hessian of a scalar function of a small parameter vector -- same method set as
+    gpmp/num/torch_backend.py:721-779 (``evaluate(x)``, ``gradient()``, ``hessian()``), which uses second-order
+    autograd.  The hip backend records no autograd graph through its kernels, so the derivatives are central
+    finite differences of ``f`` (5-point first derivative as gpmp/num/shared.py:44-55, 4-point mixed second
+    derivatives), i.e. O(p^2) evaluations of ``f`` for p parameters; intended for the p ~ d + 1 covariance
+    parameters of gpmp/core/fisher.py:158-191.
+    """
+
+    def __init__(self, f, step=1e-3):
+        self.f, self.h = f, float(step)
+        self._x = self._y = None
+
+    def _val(self, x):
+        v = self.f(numpy.array(x, dtype=numpy.float64))
+        v = v.item() if hasattr(v, "item") else float(v)
+        return float(v)
+
+    def evaluate(self, x):
+        self._x = numpy.array(numpy.asarray(x.detach().cpu() if hasattr(x, "detach") else x, dtype=numpy.float64), copy=True).reshape(-1)
+        self._y = self._val(self._x)
+        return self._y
+
+    def gradient(self, retain=True):
+        if self._x is None:
+            raise RuntimeError("Call evaluate(x) before calling gradient().")
+        x, h = self._x, self.h
+        g = numpy.zeros_like(x)
+        for i in range(x.size):
+            e = numpy.zeros_like(x)
+            e[i] = h
+            g[i] = (-self._val(x + 2 * e) + 8 * self._val(x + e) - 8 * self._val(x - e) + self._val(x - 2 * e)) / (12 * h)
+        self._grad = g
+        return g
+
+    def hessian(self):
+        if self._x is None:
+            raise RuntimeError("Call evaluate(x) before calling hessian().")
+        x, h, p = self._x, self.h, self._x.size
+        H = numpy.zeros((p, p))
+        f0 = self._y
+        for i in range(p):
+            ei = numpy.zeros_like(x)
+            ei[i] = h
+            H[i, i] = (-self._val(x + 2 * ei) + 16 * self._val(x + ei) - 30 * f0 + 16 * self._val(x - ei) - self._val(x - 2 * ei)) / (12 * h * h)
+            for j in range(i):
+                ej = numpy.zeros_like(x)
+                ej[j] = h
+                H[i, j] = H[j, i] = (self._val(x + ei + ej) - self._val(x + ei - ej) - self._val(x - ei + ej) + self._val(x - ei - ej)) / (4 * h * h)
+        return H

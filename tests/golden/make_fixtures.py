@@ -405,6 +405,13 @@ def gen_batch_criterion():
             cyc_v.append(float(pre(tt)))
             cyc_g.append(tonp(grad(tt)))
         out[f"batch_{name}_cycle_val"], out[f"batch_{name}_cycle_grad"] = np.array(cyc_v), np.stack(cyc_g)
+    # second-order autograd Fisher (gpmp/core/fisher.py:158-191) on a small problem
+    xs, _ = make_xz(60, 2, 79)
+    ks = make_kernel(2)
+    ms = gp.core.Model(None, ks, None, None, "zero")
+    th = theta_aniso(2) + 0.1
+    out["hess_xi"], out["hess_theta"] = xs, th
+    out["hess_fisher_torch"] = tonp(ms.fisher_information_torch(torch.as_tensor(xs), torch.as_tensor(th, dtype=torch.float64)))
     path = os.path.join(HERE, "ref_batch.npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -536,6 +536,21 @@ def test_batch_criterion_vs_reference(gp, gnp, golden):
         gp.kernel.make_selection_criterion_with_gradient(cases[0][1], cases[0][2], dataloader=[])
 
 
+def test_fisher_information_from_logdet_hessian(gp, gnp, golden):
+    """Model.fisher_information_torch: 0.5 * Hessian of log|K(theta)|; the reference uses second-order autograd,
+    this backend central finite differences of the HIP log-det (gnp.SecondOrderDifferentiableFunction)"""
+    g = golden("batch")
+    model = gp.Model(None, gp.kernel.MaternCovariance(2), None, None, "zero")
+    H = model.fisher_information_torch(g["hess_xi"], g["hess_theta"])
+    ref = g["hess_fisher_torch"]
+    assert np.allclose(H, H.T)
+    assert np.max(np.abs(H - ref)) < 2e-5 * max(1.0, np.max(np.abs(ref)))
+    f = gnp.SecondOrderDifferentiableFunction(lambda v: float(v[0] ** 2 * v[1] + np.sin(v[1])), step=1e-2)
+    f.evaluate(np.array([0.7, -0.3]))
+    np.testing.assert_allclose(f.gradient(), [2 * 0.7 * -0.3, 0.49 + np.cos(-0.3)], atol=1e-7)
+    np.testing.assert_allclose(f.hessian(), [[2 * -0.3, 1.4], [1.4, -np.sin(-0.3)]], atol=1e-6)
+
+
 @pytest.mark.parametrize("tag", ["na", "nb"])
 def test_gradients_noisy_kernel(gp, gnp, golden, tag):
     g = golden("gradients")
