@@ -98,3 +98,25 @@ def norm_k_sqrd(model, xi, zi, covparam):
     P = gnp.asarray(model.mean(xi, model.meanparam))
     ms = MeanSpace(F, zi.reshape(-1), P)
     return gnp.asarray(numpy.asarray(ms.quad())).reshape(())
+
+
+# ---- explicit contrast matrices (API parity; the criteria above never form them) --------------------------------
+def compute_contrast_matrix(P):
+    """gpmp/core/linalg.py:49-70: W = Q[:, q:] of the complete QR of P (n x (n - q), orthonormal, W^T P = 0)."""
+    P = gnp.asarray(P)
+    q = P.shape[1]
+    Q, _ = gnp.qr(P, mode="complete")
+    return Q[:, q:]
+
+
+def compute_contrast_covariance(W, K):
+    """gpmp/core/linalg.py:73-88: W^T K W (two MFMA GEMMs)."""
+    return gnp.matmul(gnp.asarray(W).T, gnp.matmul(gnp.asarray(K), gnp.asarray(W)))
+
+
+def qr_nullspace(P):
+    """gpmp/core/linalg.py:91-110: (Q1, W, R1) with P = Q1 R1 and W spanning Null(P^T)."""
+    P = gnp.asarray(P)
+    q = P.shape[1]
+    Q, R = gnp.qr(P, mode="complete")
+    return Q[:, :q], Q[:, q:], R[:q, :q]

@@ -21,6 +21,7 @@ from .parameter_selection import (
     select_parameters_with_criterion,
     select_parameters_with_reml,
     select_parameters_with_remap,
+    select_parameters_with_remap_gaussian_logsigma2,
     select_parameters_with_remap_gaussian_logsigma2_and_logrho_prior,
     select_parameters_with_remap_with_power_laws_prior,
     select_parameters_with_ml_constant_mean,
@@ -28,13 +29,20 @@ from .parameter_selection import (
     update_parameters_with_ml_constant_mean,
     update_parameters_with_reml,
     update_parameters_with_remap,
+    update_parameters_with_remap_gaussian_logsigma2,
+    update_parameters_with_remap_gaussian_logsigma2_and_logrho_prior,
+    update_parameters_with_remap_with_power_laws_prior,
 )
-from .prior_helpers import compute_logrho_min_from_xi
+from .bounds import empirical_bounds_factory
+from .exponential import exponential_kernel
+from .utils import check_xi_zi_or_loader, prepare_data
+from .prior_helpers import compute_logrho_min_from_xi, resolve_covparam0_roles_for_update
 from .priors import (
     log_prior_gaussian_logsigma2,
     log_prior_jeffreys_variance,
     log_prior_logrho_barrier_linear,
     log_prior_power_law,
+    log_prior_reference,
     neg_log_restricted_posterior_logsigma2_and_logrho_prior,
     neg_log_restricted_posterior_logsigma2_prior,
     neg_log_restricted_posterior_power_laws_prior,
@@ -57,5 +65,8 @@ __all__ = [
     "neg_log_restricted_posterior_power_laws_prior", "neg_log_restricted_posterior_with_logrho_prior", "prior_defaults",
     "anisotropic_parameters_initial_guess_constant_mean", "select_parameters_with_ml_constant_mean",
     "update_parameters_with_criterion", "update_parameters_with_ml_constant_mean", "update_parameters_with_reml",
-    "update_parameters_with_remap",
+    "update_parameters_with_remap", "select_parameters_with_remap_gaussian_logsigma2",
+    "update_parameters_with_remap_gaussian_logsigma2", "update_parameters_with_remap_gaussian_logsigma2_and_logrho_prior",
+    "update_parameters_with_remap_with_power_laws_prior", "empirical_bounds_factory", "exponential_kernel",
+    "check_xi_zi_or_loader", "prepare_data", "log_prior_reference", "resolve_covparam0_roles_for_update",
 ]

@@ -13,7 +13,9 @@ from scipy.optimize import minimize
 from .. import num as gnp
 from .init import anisotropic_parameters_initial_guess, anisotropic_parameters_initial_guess_constant_mean
 from .matern import MaternCovariance
-from .prior_helpers import resolve_covparam0_prior_and_init, resolve_logsigma2_logrho_prior_args
+from .prior_defaults import resolve_prior_defaults_for_selection
+from .prior_helpers import (resolve_covparam0_prior_and_init, resolve_covparam0_roles_for_update,
+                            resolve_logsigma2_logrho_prior_args)
 from . import priors as _priors
 
 
@@ -244,6 +246,30 @@ def select_parameters_with_remap_gaussian_logsigma2_and_logrho_prior(
                                             bounds_delta=bounds_delta, method=method, method_options=method_options)
 
 
+def select_parameters_with_remap_gaussian_logsigma2(
+        model, xi=None, zi=None, dataloader=None, covparam0=None, info=False, verbosity=0, *, covparam0_prior=None,
+        prior_gamma=None, prior_sigma2_coverage=None, covparam0_init=None, bounds=None, bounds_auto=True, bounds_delta=10.0,
+        method="SLSQP", method_options=None):
+    """gpmp/kernel/parameter_selection.py:1089-1201: REML - log p(log sigma^2), Gaussian prior centred at covparam0_prior[0]."""
+    covparam0_prior, covparam0_init = resolve_covparam0_prior_and_init(
+        model, xi=xi, zi=zi, dataloader=dataloader, covparam0=covparam0, covparam0_prior=covparam0_prior,
+        covparam0_init=covparam0_init)
+    prior_gamma, prior_sigma2_coverage, _, _ = resolve_prior_defaults_for_selection(
+        xi=xi, dataloader=dataloader, gamma=prior_gamma, sigma2_coverage=prior_sigma2_coverage)
+    log_sigma2_0 = float(covparam0_prior[0])
+
+    def criterion(m, covparam, x, z):
+        return _priors.neg_log_restricted_posterior_logsigma2_prior(m, covparam, x, z, log_sigma2_0=log_sigma2_0, gamma=prior_gamma,
+                                                                    sigma2_coverage=prior_sigma2_coverage)
+
+    criterion._gpmp_analytic_factory = lambda m: _RemapAnalytic(
+        m, lambda c: -_priors.log_prior_gaussian_logsigma2(c, log_sigma2_0, gamma=prior_gamma, sigma2_coverage=prior_sigma2_coverage),
+        lambda c: _priors.grad_neg_log_prior_gaussian_logsigma2(c, log_sigma2_0, gamma=prior_gamma, sigma2_coverage=prior_sigma2_coverage))
+    return select_parameters_with_criterion(model, criterion, xi=xi, zi=zi, dataloader=dataloader, covparam0=covparam0_init,
+                                            info=info, verbosity=verbosity, bounds=bounds, bounds_auto=bounds_auto,
+                                            bounds_delta=bounds_delta, method=method, method_options=method_options)
+
+
 def select_parameters_with_remap(model, xi=None, zi=None, dataloader=None, covparam0=None, covparam0_init=None, info=False,
                                  verbosity=0, **kwargs):
     """gpmp/kernel/parameter_selection.py:867-965: alias of the Gaussian-log-sigma2 + log-rho procedure."""
@@ -282,18 +308,43 @@ def update_parameters_with_reml(model, xi=None, zi=None, dataloader=None, info=F
                                             info=info, verbosity=verbosity, **kw)
 
 
+def update_parameters_with_remap_gaussian_logsigma2_and_logrho_prior(
+        model, xi=None, zi=None, dataloader=None, info=False, verbosity=0, *, covparam0=None, covparam0_prior=None,
+        covparam0_init=None, **kw):
+    """gpmp/kernel/parameter_selection.py:1486-1577: prior anchor / optimiser start resolved by
+    resolve_covparam0_roles_for_update (model.covparam when nothing is given, with the reference's warning)."""
+    covparam0_prior, covparam0_init = resolve_covparam0_roles_for_update(
+        model, xi=xi, zi=zi, dataloader=dataloader, covparam0=covparam0, covparam0_prior=covparam0_prior,
+        covparam0_init=covparam0_init)
+    return select_parameters_with_remap_gaussian_logsigma2_and_logrho_prior(
+        model, xi=xi, zi=zi, dataloader=dataloader, covparam0=covparam0, covparam0_prior=covparam0_prior,
+        covparam0_init=covparam0_init, info=info, verbosity=verbosity, **kw)
+
+
 def update_parameters_with_remap(model, xi=None, zi=None, dataloader=None, covparam0=None, covparam0_prior=None,
                                  covparam0_init=None, info=False, verbosity=0, **kw):
-    """gpmp/kernel/parameter_selection.py:922-965,1486-1577: prior anchored at covparam0_prior (default: the model's
-    current parameters), optimiser started at covparam0_init (default: the model's current parameters)."""
-    cur = model.covparam
-    if covparam0_prior is None:
-        covparam0_prior = covparam0 if covparam0 is not None else cur
-    if covparam0_init is None:
-        covparam0_init = covparam0 if covparam0 is not None else cur
-    return select_parameters_with_remap_gaussian_logsigma2_and_logrho_prior(
-        model, xi=xi, zi=zi, dataloader=dataloader, covparam0_prior=covparam0_prior, covparam0_init=covparam0_init, info=info,
-        verbosity=verbosity, **kw)
+    """gpmp/kernel/parameter_selection.py:922-965: alias of the Gaussian-log-sigma2 + log-rho update."""
+    return update_parameters_with_remap_gaussian_logsigma2_and_logrho_prior(
+        model, xi=xi, zi=zi, dataloader=dataloader, covparam0=covparam0, covparam0_prior=covparam0_prior,
+        covparam0_init=covparam0_init, info=info, verbosity=verbosity, **kw)
+
+
+def update_parameters_with_remap_gaussian_logsigma2(
+        model, xi=None, zi=None, dataloader=None, info=False, verbosity=0, *, covparam0=None, covparam0_prior=None,
+        covparam0_init=None, **kw):
+    """gpmp/kernel/parameter_selection.py:1204-1297."""
+    covparam0_prior, covparam0_init = resolve_covparam0_roles_for_update(
+        model, xi=xi, zi=zi, dataloader=dataloader, covparam0=covparam0, covparam0_prior=covparam0_prior,
+        covparam0_init=covparam0_init)
+    return select_parameters_with_remap_gaussian_logsigma2(
+        model, xi=xi, zi=zi, dataloader=dataloader, covparam0=covparam0, covparam0_prior=covparam0_prior,
+        covparam0_init=covparam0_init, info=info, verbosity=verbosity, **kw)
+
+
+def update_parameters_with_remap_with_power_laws_prior(model, xi=None, zi=None, dataloader=None, info=False, verbosity=0, **kw):
+    """gpmp/kernel/parameter_selection.py:1033-1086: re-optimise from model.covparam with the power-laws prior."""
+    return update_parameters_with_criterion(model, _priors.neg_log_restricted_posterior_power_laws_prior, xi=xi, zi=zi,
+                                            dataloader=dataloader, info=info, verbosity=verbosity, **kw)
 
 
 def select_parameters_with_ml_constant_mean(model, xi=None, zi=None, dataloader=None, meanparam0=None, covparam0=None,

@@ -42,6 +42,14 @@ def set_default_prior_hyperparameters(*, gamma=None, sigma2_coverage=None, alpha
         _PRIOR_DEFAULTS.rho_min_range_factor = float(rho_min_range_factor)
 
 
+def set_default_prior_hyperparameters_from_kwargs(kwargs):
+    """prior_defaults.py:115-135: pop the ``prior_*`` convenience keys of a kwargs dict into the defaults."""
+    for key, name in (("prior_logsigma2_gamma", "gamma"), ("prior_logsigma2_coverage", "sigma2_coverage"),
+                      ("prior_logrho_alpha", "alpha"), ("prior_logrho_min_range_factor", "rho_min_range_factor")):
+        if key in kwargs:
+            set_default_prior_hyperparameters(**{name: kwargs.pop(key)})
+
+
 def resolve_prior_defaults_for_selection(xi=None, dataloader=None, gamma=None, sigma2_coverage=None, alpha=None,
                                          rho_min_range_factor=None):
     """prior_defaults.py:137-175."""

@@ -55,6 +55,41 @@ def resolve_covparam0_prior_and_init(model, xi=None, zi=None, dataloader=None, *
     return tonp(covparam0_prior), tonp(covparam0_init)
 
 
+def resolve_covparam0_roles_for_update(model, xi=None, zi=None, dataloader=None, *, covparam0=None, covparam0_prior=None,
+                                       covparam0_init=None, warn_covparam0_prior=True):
+    """prior_helpers.py:152-218: roles in an update procedure.  Optimiser start: covparam0_init, else covparam0, else
+    model.covparam, else an initial guess.  Prior anchor: covparam0_prior, else covparam0 or model.covparam (with a
+    warning about the coupling), else the initial guess."""
+    import warnings
+
+    guess = None
+    if covparam0_init is None:
+        if covparam0 is not None:
+            covparam0_init = covparam0
+        elif model.covparam is not None:
+            covparam0_init = model.covparam
+        else:
+            guess = anisotropic_parameters_initial_guess(model, xi, zi, dataloader)
+            covparam0_init = guess
+    if covparam0_prior is None:
+        if covparam0 is not None:
+            if warn_covparam0_prior:
+                warnings.warn("covparam0 provided without covparam0_prior in update procedure; using covparam0 as "
+                              "covparam0_prior. Pass covparam0_prior explicitly to avoid this coupling.", stacklevel=2)
+            covparam0_prior = covparam0
+        elif model.covparam is not None:
+            if warn_covparam0_prior:
+                warnings.warn("covparam0 and covparam0_prior not provided in update procedure; using model.covparam as "
+                              "covparam0_prior. Pass covparam0_prior explicitly to avoid this coupling.", stacklevel=2)
+            covparam0_prior = model.covparam
+        elif guess is not None:
+            covparam0_prior = guess
+        else:
+            covparam0_prior = anisotropic_parameters_initial_guess(model, xi, zi, dataloader)
+    tonp = lambda v: np.asarray(gnp.to_np(v), dtype=np.float64).reshape(-1)  # noqa: E731
+    return tonp(covparam0_prior), tonp(covparam0_init)
+
+
 def resolve_logsigma2_logrho_prior_args(*, covparam0_prior, xi=None, dataloader=None, prior_gamma=None,
                                         prior_sigma2_coverage=None, prior_alpha=None, prior_rho_min_range_factor=None,
                                         prior_log_sigma2_0=None, prior_logrho_0=None, prior_logrho_min=None):

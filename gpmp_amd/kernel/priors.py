@@ -9,6 +9,7 @@ from statistics import NormalDist
 
 import numpy as np
 
+from .. import num as gnp
 from .prior_defaults import get_default_prior_hyperparameters
 
 
@@ -54,6 +55,15 @@ def log_prior_power_law(covparam, lambda_var=1.0, cut_logvariance_high=9.21, lam
     extra_high = penalty_factor * np.maximum(p - cut_loginvrho_high, 0)
     log_prior_lengths = -lambda_lengthscales * np.sum(p) - np.sum(extra_low) - np.sum(extra_high)
     return log_prior_sigma2 + extra_sigma2 + log_prior_lengths
+
+
+def log_prior_reference(model, covparam, xi):
+    """priors.py:131-166: reference prior, 1/2 log det of the Fisher information of the covariance parameters."""
+    info = np.asarray(gnp.to_np(model.fisher_information(xi, covparam)), dtype=np.float64)
+    sign, logabs = np.linalg.slogdet(info)
+    if sign <= 0:
+        raise np.linalg.LinAlgError("Fisher information is not positive definite")
+    return 0.5 * logabs
 
 
 def log_prior_gaussian_logsigma2(covparam, log_sigma2_0, gamma=None, sigma2_coverage=None):

@@ -284,6 +284,36 @@ def gen_fisher_paths(out):
     out["paths_cond_param"] = mpm.conditional_sample_paths_parameterized_mean(ztsim, xi, xi_ind, zi, xt, xt_ind, lam2)
 
 
+def gen_remap_extra(out):
+    """procedures added after ref_remap.npz: Gaussian-log-sigma2-only REMAP (select + update), power-laws update,
+    reference prior, empirical bounds"""
+    from gpmp.kernel import priors as rp
+    from gpmp.kernel.bounds import empirical_bounds_factory
+
+    xi, zi = make_xz(90, 2, 91)
+    p = 2
+    out["rx_xi"], out["rx_zi"], out["rx_p"] = xi, zi, np.array(p)
+    model = gp.core.Model(constant_mean, make_kernel(p))
+    c0 = theta_aniso(2) + np.array([0.3, -0.2, 0.1])
+    out["rx_covparam0"] = c0
+    model, info = gp.kernel.select_parameters_with_remap_gaussian_logsigma2(model, xi, zi, covparam0=c0, info=True)
+    out["rx_sel_covparam"], out["rx_sel_crit"] = tonp(model.covparam), np.array(float(info.selection_criterion(model.covparam)))
+    out["rx_crit_at_c0"] = np.array(float(info.selection_criterion(gnp.asarray(c0))))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model2 = gp.core.Model(constant_mean, make_kernel(p), covparam=gnp.asarray(c0))
+        model2, info2 = gp.kernel.update_parameters_with_remap_gaussian_logsigma2(model2, xi, zi, info=True)
+        out["rx_upd_covparam"] = tonp(model2.covparam)
+        model3 = gp.core.Model(constant_mean, make_kernel(p), covparam=gnp.asarray(c0))
+        model3, info3 = gp.kernel.update_parameters_with_remap_with_power_laws_prior(model3, xi, zi, info=True)
+        out["rx_upd_pl_covparam"], out["rx_upd_pl_crit"] = tonp(model3.covparam), np.array(float(info3.selection_criterion(model3.covparam)))
+    mz = gp.core.Model(None, make_kernel(p), None, gnp.asarray(c0), "zero")
+    out["rx_log_prior_reference"] = np.array(float(rp.log_prior_reference(mz, gnp.asarray(c0), gnp.asarray(xi))))
+    out["rx_bounds"] = tonp(empirical_bounds_factory(xi, zi, mean_paramlength=1))
+    W = gp.core.linalg.compute_contrast_matrix(gnp.asarray(linear_mean(xi, None)))
+    out["rx_contrast_proj"] = tonp(gnp.matmul(W, W.T))          # the projector is unique, W is not
+
+
 def numpy_pass():
     for name, fn in (("matern", gen_matern), ("predict", gen_predict), ("likelihood", gen_likelihood), ("example02", gen_example02), ("remap", gen_remap), ("fisher_paths", gen_fisher_paths)):
         out = {}
@@ -418,7 +448,13 @@ def gen_batch_criterion():
 
 
 if __name__ == "__main__":
-    if backend == "numpy":
+    if len(sys.argv) > 2 and sys.argv[2] == "remap_extra":
+        o = {}
+        gen_remap_extra(o)
+        path = os.path.join(HERE, "ref_remap_extra.npz")
+        np.savez_compressed(path, **{k: np.asarray(v) for k, v in o.items()})
+        print("wrote", path, os.path.getsize(path), "bytes,", len(o), "arrays")
+    elif backend == "numpy":
         numpy_pass()
     elif len(sys.argv) > 2 and sys.argv[2] == "batch":
         gen_batch_criterion()
