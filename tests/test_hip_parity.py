@@ -124,6 +124,37 @@ def test_dgemm_lower_only_ragged_large_k(gnp):
     assert np.array_equal(got[tile < 0], C0[tile < 0])
 
 
+@pytest.mark.parametrize("n,m,d", [(1, 1, 1), (2, 3, 1), (1, 5, 3), (129, 1, 2), (5, 0, 2), (257, 130, 3)])
+def test_degenerate_shapes_predict_loo_criteria(gp, gnp, n, m, d):
+    """one observation, no prediction point, one dimension, one row more than a block: same answers as the oracle"""
+    from oracle import gp_oracle as orc
+
+    rng = np.random.default_rng(n * 7 + m)
+    xi, xt, zi = rng.random((n, d)), rng.random((m, d)), rng.standard_normal(n)
+    th = np.concatenate(([0.1], np.log(1.0 / 0.2) * np.ones(d)))
+    okern = lambda x, y, t, pairwise=False: orc.maternp_covariance(x, y, 2, t, pairwise)  # noqa: E731
+    for mt, mean, omean in (("zero", None, None), ("linear_predictor", constant_mean, np_constant_mean)):
+        if mt != "zero" and n < 2:
+            continue
+        model = gp.Model(mean, gp.kernel.MaternCovariance(2), None, th, mt)
+        om = orc.OracleModel(omean, okern, None, th, mt)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            zpm, zpv = model.predict(xi, zi, xt)
+            rpm, rpv = orc.predict(om, xi, zi, xt)[:2]
+        assert zpm.shape == (m,) and zpv.shape == (m,)
+        np.testing.assert_allclose(zpm, rpm, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(zpv, rpv, rtol=0, atol=1e-10)
+        got = [gnp.to_np(v) for v in model.loo(xi, zi)]
+        for u, v in zip(got, orc.loo(om, xi, zi)):
+            np.testing.assert_allclose(u, np.asarray(v), rtol=0, atol=1e-8)
+        if mt == "zero":
+            a, b = float(model.negative_log_likelihood_zero_mean(th, xi, zi)), float(orc.negative_log_likelihood_zero_mean(om, th, xi, zi))
+        else:
+            a, b = float(model.negative_log_restricted_likelihood(th, xi, zi)), float(orc.negative_log_restricted_likelihood(om, th, xi, zi))
+        assert abs(a - b) <= 1e-10 * max(1.0, abs(b))
+
+
 @pytest.mark.parametrize("n,rho", [(1024, 3.0), (2048, 3.0), (1536, 8.0)])
 def test_cholesky_backward_error_ill_conditioned(gnp, n, rho):
     """Smooth kernel, long length-scales: cond(K) up to ~1e13 with only the reference's 10 eps nugget (hard
