@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--size-m", dest="m", type=int, default=50000)
     ap.add_argument("--dim-d", dest="d", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not record per-kernel HIP events in the timed region")
     ap.add_argument("--cpu-n", type=int, default=4096)
     ap.add_argument("--cpu-m", type=int, default=10000)
     args = ap.parse_args()
@@ -130,7 +131,13 @@ def main():
     barrier()
     import ctypes
 
-    lib.gpmp_profile_begin()
+    # HIP events on the launch stream around every launch of the DOMINANT kernel only (kind 9: the LDS-direct NN GEMM
+    # of the n x m solve, 63 launches per step) inside the timed region; recording every kind (9000 events per step
+    # around the small launches of the factorisations) costs 0.8 % of the step, so the other kinds are collected from
+    # one extra, untimed step below.
+    DOMINANT = 1 << 9
+    if not args.no_kernel_events:
+        lib.gpmp_profile_begin_kinds(DOMINANT)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -138,7 +145,14 @@ def main():
     elapsed = time.perf_counter() - t0
     table = (ctypes.c_double * 36)()
     lib.gpmp_profile_end(table)
-    prof = np.array(list(table)).reshape(12, 3)
+    prof_timed = np.array(list(table)).reshape(12, 3)
+    # diagnostics of the other kernels: one untimed step with every kind recorded, scaled to the timed step count
+    lib.gpmp_profile_begin_kinds(0xFFFFFFFF & ~DOMINANT)
+    step()
+    torch.cuda.synchronize()
+    lib.gpmp_profile_end(table)
+    prof = np.array(list(table)).reshape(12, 3) * args.steps
+    prof[9] = prof_timed[9]
 
     if dist_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=gnp._dev())

@@ -20,6 +20,7 @@ SIGNATURES = {
     "gpmp_hip_abi_version": (c_int, []),
     "gpmp_last_error": (c_char_p, []),
     "gpmp_profile_begin": (c_int, []),
+    "gpmp_profile_begin_kinds": (c_int, [ctypes.c_uint]),
     "gpmp_profile_end": (c_int, [_P]),
     "gpmp_matern_gram": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_double, c_int, _P, c_long, _P]),
     "gpmp_matern_pairwise": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P]),

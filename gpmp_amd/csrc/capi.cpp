@@ -22,6 +22,7 @@ int hip_fail(hipError_t e, const char* what) {
 
 namespace gpmp {
 bool g_prof_on = false;
+unsigned g_prof_mask = 0xFFFFFFFFu;
 namespace {
 struct Rec { hipEvent_t a, b; int kind; double work; };
 std::vector<Rec> g_recs;
@@ -33,23 +34,27 @@ hipEvent_t get_event() {
 }
 }  // namespace
 void prof_start(int kind, hipStream_t st) {
+  if (!((g_prof_mask >> kind) & 1u)) return;
   hipEvent_t e = get_event();
   (void)hipEventRecord(e, st);
   g_open[kind] = e;
 }
 void prof_stop(int kind, hipStream_t st, double work) {
+  if (!((g_prof_mask >> kind) & 1u)) return;
   hipEvent_t e = get_event();
   (void)hipEventRecord(e, st);
   g_recs.push_back({g_open[kind], e, kind, work});
 }
 }  // namespace gpmp
 
-extern "C" int gpmp_profile_begin(void) {
+extern "C" int gpmp_profile_begin_kinds(unsigned kinds) {
   for (auto& r : gpmp::g_recs) { gpmp::g_pool.push_back(r.a); gpmp::g_pool.push_back(r.b); }
   gpmp::g_recs.clear();
+  gpmp::g_prof_mask = kinds;
   gpmp::g_prof_on = true;
   return 0;
 }
+extern "C" int gpmp_profile_begin(void) { return gpmp_profile_begin_kinds(0xFFFFFFFFu); }
 
 extern "C" int gpmp_profile_end(double* table_host) {
   gpmp::g_prof_on = false;

@@ -47,6 +47,10 @@ const char* gpmp_last_error(void);
  * 6 column reductions (work = bytes read), 7 gradient trace, 8..11 GEMM (LDS-direct kernel
  * gemm_f64_kernel_v2) NT / NN / TN / TT.  Used by bench.py for `roofline`. */
 int gpmp_profile_begin(void);
+/* Same, for the kinds whose bit is set only (bit k = kind k): a pair of events per launch costs about 1 us on the
+ * launch stream, which adds up over the thousands of small launches of a factorisation (0.8 % of the benchmark step
+ * with every kind recorded). */
+int gpmp_profile_begin_kinds(unsigned kinds);
 int gpmp_profile_end(double* table_host);
 
 /* ---- Matern kernels ------------------------------------------------------------------------ */
