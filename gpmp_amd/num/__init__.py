@@ -121,6 +121,10 @@ def asarray(x, dtype=None):
         return x.to(device=_dev())
     if isinstance(x, (int, float)):
         return torch.tensor([x], dtype=torch.float64 if isinstance(x, float) else None, device=_dev())
+    if isinstance(x, (list, tuple)) and builtins.any(isinstance(v, torch.Tensor) for v in x):
+        # e.g. gnp.array([gnp.log(gnp.var(z))]): a sequence holding device scalars (torch backend: torch_backend.py asarray)
+        return torch.stack([asarray(v).reshape(()) if isinstance(v, torch.Tensor) and v.numel() == 1 and v.dim() <= 1
+                            else asarray(v) for v in x]).to(dtype=dtype or torch.float64)
     arr = numpy.asarray(x)
     if numpy.issubdtype(arr.dtype, numpy.floating):
         return torch.as_tensor(numpy.ascontiguousarray(arr, dtype=numpy.float64), device=_dev())
@@ -180,8 +184,23 @@ def arange(*args):
 
 
 # cheap O(n) / O(m) vector helpers used by mean functions and post-processing
-exp, log, sqrt, abs = torch.exp, torch.log, torch.sqrt, torch.abs
-sin, cos, tanh = torch.sin, torch.cos, torch.tanh
+def _elementwise(torch_fn, numpy_fn):
+    """Device tensors go to torch; host values (the covariance / mean PARAMETERS, which reach user kernels as NumPy
+    vectors from SciPy) are evaluated on the host as with the reference's NumPy backend.  Host scalars come back as
+    Python floats so that ``gnp.exp(param[0]) * K`` multiplies a device matrix from the left without NumPy trying to
+    convert it."""
+    def f(x):
+        if isinstance(x, torch.Tensor):
+            return torch_fn(x)
+        y = numpy_fn(numpy.asarray(x, dtype=numpy.float64))
+        return float(y) if y.ndim == 0 else y
+    f.__name__ = numpy_fn.__name__
+    return f
+
+
+exp, log, sqrt, abs = (_elementwise(torch.exp, numpy.exp), _elementwise(torch.log, numpy.log),  # noqa: A001
+                       _elementwise(torch.sqrt, numpy.sqrt), _elementwise(torch.abs, numpy.abs))
+sin, cos, tanh = _elementwise(torch.sin, numpy.sin), _elementwise(torch.cos, numpy.cos), _elementwise(torch.tanh, numpy.tanh)
 maximum = lambda a, b: torch.clamp(a, min=b) if not isinstance(b, torch.Tensor) else torch.maximum(a, b)  # noqa: E731
 minimum = lambda a, b: torch.clamp(a, max=b) if not isinstance(b, torch.Tensor) else torch.minimum(a, b)  # noqa: E731
 where, isnan, isinf, isfinite = torch.where, torch.isnan, torch.isinf, torch.isfinite
@@ -531,3 +550,5 @@ def randn(*shape):
 
 from .criterion import (BatchDifferentiableSelectionCriterion, DifferentiableSelectionCriterion,  # noqa: E402,F401
                         SecondOrderDifferentiableFunction)
+from .extras import *  # noqa: E402,F401,F403  (the rest of the backend contract: thin wrappers, see extras.py)
+from .extras import multivariate_normal, normal, scipy_mvnormal  # noqa: E402,F401

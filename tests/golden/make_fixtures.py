@@ -447,8 +447,19 @@ def gen_batch_criterion():
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
+def gen_namespace():
+    """public names of the reference's NumPy backend namespace (the backend contract), one per line"""
+    names = [n for n in dir(gnp) if not n.startswith("_")]
+    path = os.path.join(HERE, "ref_gnp_names.txt")
+    with open(path, "w") as f:
+        f.write("\n".join(names) + "\n")
+    print("wrote", path, len(names), "names")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[2] == "remap_extra":
+    if len(sys.argv) > 2 and sys.argv[2] == "namespace":
+        gen_namespace()
+    elif len(sys.argv) > 2 and sys.argv[2] == "remap_extra":
         o = {}
         gen_remap_extra(o)
         path = os.path.join(HERE, "ref_remap_extra.npz")

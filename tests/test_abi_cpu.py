@@ -75,3 +75,18 @@ def test_config_rules():
         config.set_backend("numpy")
     config.set_dtype("float64")
     assert config.get_backend() == "hip"
+
+
+def test_backend_namespace_covers_the_reference_contract():
+    """every public name of the reference's NumPy backend (tests/golden/ref_gnp_names.txt, written by make_fixtures.py)
+    exists in gpmp_amd.num, except typing aliases and module objects"""
+    import os
+
+    import gpmp_amd.num as gnp
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    names = [l.strip() for l in open(os.path.join(here, "golden", "ref_gnp_names.txt")) if l.strip()]
+    not_api = {"Any", "ArrayLike", "Callable", "CriterionCallable", "Iterable", "LoaderLike", "NDArray", "Scalar", "Tuple", "Union",
+               "numpy_backend", "os", "shared", "warnings"}
+    missing = [n for n in names if n not in not_api and not hasattr(gnp, n)]
+    assert len(names) > 100 and missing == []

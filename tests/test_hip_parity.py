@@ -599,6 +599,78 @@ def test_gradients_noisy_kernel(gp, gnp, golden, tag):
             assert rel_err(gr, g[f"grad_{tag}_{name}_grad"][i]) < 1e-7
 
 
+def test_user_kernel_written_with_gnp_primitives(gp, gnp):
+    """A covariance written by the user from backend primitives, as examples/gpmp_example07_nd_regression.py:95-131 does
+    (gnp.exp on the PARAMETERS, gnp.scaled_distance, maternp_kernel, gnp.eye): parameters arrive as host vectors from
+    SciPy, so the elementwise gnp functions must take host scalars / vectors as the NumPy backend's do."""
+    from oracle import gp_oracle as orc
+
+    def kernel(x, y, param, pairwise=False):
+        sigma2, noise_variance, loginvrho = gnp.exp(param[0]), gnp.exp(param[1]), param[2:]
+        if y is x or y is None:
+            if pairwise:
+                return sigma2 * gnp.ones((x.shape[0],))
+            D = gnp.scaled_distance(loginvrho, x, x)
+            return sigma2 * gp.kernel.maternp_kernel(2, D) + noise_variance * gnp.eye(D.shape[0])
+        D = gnp.scaled_distance_elementwise(loginvrho, x, y) if pairwise else gnp.scaled_distance(loginvrho, x, y)
+        return sigma2 * gp.kernel.maternp_kernel(2, D)
+
+    rng = np.random.default_rng(3)
+    xi, xt = rng.random((150, 3)), rng.random((40, 3))
+    zi = np.sin(4 * xi[:, 0]) + xi[:, 1] + 0.05 * rng.standard_normal(150)
+    zt = gnp.asarray(zi)
+    # the example's initial guess, written with the backend's own functions
+    covparam0 = gnp.concatenate((gnp.array([gnp.log(gnp.var(zt))]), gnp.array([2 * gnp.log(0.1) + gnp.log(gnp.var(zt))]),
+                                 -gnp.log(gnp.std(gnp.asarray(xi), axis=0)).flatten()))
+    th = gnp.to_np(covparam0)
+    assert th.shape == (5,) and np.all(np.isfinite(th))
+    assert isinstance(gnp.exp(th[0]), float) and gnp.exp(th[2:]).shape == (3,)
+    user = gp.Model(constant_mean, kernel, None, th)
+    decl = gp.Model(constant_mean, gp.kernel.MaternCovariance(2, noise=True), None, th)
+    om = orc.OracleModel(np_constant_mean, lambda x, y, t, pairwise=False: orc.noisy_maternp_covariance(x, y, 2, t, pairwise), None, th)
+    ref = float(orc.negative_log_restricted_likelihood(om, th, xi, zi))
+    for model in (user, decl):
+        assert abs(float(model.negative_log_restricted_likelihood(th, xi, zi)) - ref) < 1e-10 * abs(ref)
+    (m1, v1), (m2, v2) = user.predict(xi, zi, xt), decl.predict(xi, zi, xt)
+    rm, rv = orc.predict(om, xi, zi, xt)[:2]
+    for m_, v_ in ((m1, v1), (m2, v2)):
+        np.testing.assert_allclose(m_, rm, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(v_, rv, rtol=0, atol=1e-11)
+    _, pre, _, grad = gp.kernel.make_selection_criterion_with_gradient(user, gp.kernel.negative_log_restricted_likelihood, xi, zi)
+    assert grad is None and abs(pre(th) - ref) < 1e-10 * abs(ref)
+
+
+def test_backend_namespace_extras_match_numpy(gnp):
+    """the thin wrappers that complete the backend contract (gpmp_amd/num/extras.py) against NumPy / SciPy"""
+    import scipy.linalg as sla
+    from scipy.spatial.distance import cdist
+
+    rng = np.random.default_rng(12)
+    a, b = rng.standard_normal((7, 5)), rng.standard_normal((6, 5))
+    A, B = gnp.asarray(a), gnp.asarray(b)
+    np.testing.assert_allclose(gnp.to_np(gnp.cdist(A, B)), cdist(a, b), rtol=1e-13)
+    np.testing.assert_allclose(gnp.to_np(gnp.std(A, axis=0)), a.std(axis=0), rtol=1e-13)
+    np.testing.assert_allclose(gnp.to_np(gnp.prod(A, axis=1)), a.prod(axis=1), rtol=1e-13)
+    np.testing.assert_allclose(gnp.to_np(gnp.cumsum(A, axis=1)), a.cumsum(axis=1), rtol=1e-13)
+    np.testing.assert_allclose(gnp.to_np(gnp.percentile(A, 30.0)), np.percentile(a, 30.0), rtol=1e-12)
+    np.testing.assert_allclose(gnp.to_np(gnp.cov(A)), np.cov(a), rtol=1e-12)
+    np.testing.assert_allclose(gnp.to_np(gnp.norm(A)), np.linalg.norm(a), rtol=1e-13)
+    np.testing.assert_allclose(gnp.to_np(gnp.clip(A, -0.5, 0.5)), np.clip(a, -0.5, 0.5))
+    np.testing.assert_allclose(gnp.to_np(gnp.transpose(A, 0, 1)), a.T)
+    np.testing.assert_allclose(gnp.to_np(gnp.tile(gnp.asarray(a[0]), 3)), np.tile(a[0], 3))
+    assert [tuple(p.shape) for p in gnp.split(A, [2, 5], axis=0)] == [(2, 5), (3, 5), (2, 5)]
+    assert int(gnp.argmax(A)) == int(a.argmax()) and gnp.allclose(A, a) and not gnp.array_equal(A, B[:, :5][:7].T if False else A + 1)
+    assert gnp.log10(100.0) == 2.0 and isinstance(gnp.floor(2.5), float)
+    S = a.T @ a + 5 * np.eye(5)
+    x = gnp.to_np(gnp.cho_solve(gnp.cho_factor(gnp.asarray(S)), gnp.asarray(b.T)))
+    np.testing.assert_allclose(x, sla.cho_solve(sla.cho_factor(S), b.T), rtol=1e-11)
+    f = lambda v: float(v[0] ** 2 + 3 * v[0] * v[1])  # noqa: E731
+    np.testing.assert_allclose(gnp.grad(f)(np.array([1.0, 2.0])), [8.0, 3.0], atol=1e-8)
+    lp = gnp.multivariate_normal.logpdf(np.zeros(3), 0.0, np.eye(3))
+    assert abs(float(gnp.to_np(lp).reshape(-1)[0]) + 1.5 * math.log(2 * math.pi)) < 1e-12
+    assert gnp.multivariate_normal.rvs(0.0, np.eye(2), n=5).shape == (5, 2)
+
+
 def test_generic_callable_has_no_analytic_gradient(gp, gnp):
     def kernel(x, y, covparam, pairwise=False):
         return gp.kernel.maternp_covariance(x, y, 2, covparam, pairwise)
