@@ -18,7 +18,7 @@ __all__ = ["Model", "config", "num", "kernel", "core", "__version__"]
 
 
 def __getattr__(name):
-    if name in ("num", "kernel", "core", "dist"):
+    if name in ("num", "kernel", "core", "dist", "dataloader"):
         import importlib
 
         mod = importlib.import_module(f"{__name__}.{name}")

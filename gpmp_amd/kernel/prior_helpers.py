@@ -102,6 +102,11 @@ def resolve_logsigma2_logrho_prior_args(*, covparam0_prior, xi=None, dataloader=
         prior_log_sigma2_0 = covparam0_prior[0]
     prior_logrho_0 = -covparam0_prior[1:] if prior_logrho_0 is None else np.asarray(gnp.to_np(prior_logrho_0), dtype=np.float64)
     if prior_logrho_min is None:
+        if xi is None and dataloader is not None and hasattr(dataloader, "dataset"):   # prior_helpers.py:263-273
+            ds = dataloader.dataset
+            if not hasattr(ds, "x_list"):
+                raise ValueError("dataloader.dataset must provide x_list when prior_logrho_min is None.")
+            xi = gnp.concatenate(ds.x_list, 0) if isinstance(ds.x_list, list) else ds.x_list
         if xi is None:
             raise ValueError("xi or dataloader.dataset.x_list must be provided when prior_logrho_min is None.")
         prior_logrho_min = compute_logrho_min_from_xi(xi, prior_rho_min_range_factor=prior_rho_min_range_factor)

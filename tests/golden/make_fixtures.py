@@ -447,6 +447,28 @@ def gen_batch_criterion():
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
+def gen_dataloader(out):
+    """examples/gpmp_example30_dataloader.py flow at small size: Dataset / DataLoader (no shuffle), loader-based initial
+    guess, REMAP selection through the batch criterion (NumPy backend: finite-difference jacobian)."""
+    from gpmp.dataloader import Dataset, DataLoader
+
+    xi, zi = make_xz(240, 3, 93)
+    out["dl_xi"], out["dl_zi"], out["dl_p"], out["dl_batch"] = xi, zi, np.array(2), np.array(80)
+    loader = DataLoader(Dataset(xi, zi), batch_size=80, shuffle=False)
+    model = gp.core.Model(constant_mean, make_kernel(2))
+    out["dl_len"] = np.array(len(loader))
+    out["dl_guess"] = tonp(gp.kernel.anisotropic_parameters_initial_guess(model, dataloader=loader))
+    out["dl_guess_zero_mean"] = tonp(gp.kernel.anisotropic_parameters_initial_guess_zero_mean(
+        gp.core.Model(None, make_kernel(2), None, None, "zero"), dataloader=loader))
+    m0, c0 = gp.kernel.anisotropic_parameters_initial_guess_constant_mean(
+        gp.core.Model(param_mean, make_kernel(2), None, None, "parameterized"), dataloader=loader)
+    out["dl_guess_cm_mean"], out["dl_guess_cm_cov"] = tonp(m0), tonp(c0)
+    model, info = gp.kernel.select_parameters_with_remap(model, dataloader=loader, info=True)
+    out["dl_covparam"] = tonp(model.covparam)
+    out["dl_crit_opt"] = np.array(float(info.selection_criterion_nograd(model.covparam)))
+    out["dl_crit_at_guess"] = np.array(float(info.selection_criterion_nograd(gnp.asarray(out["dl_guess"]))))
+
+
 def gen_namespace():
     """public names of the reference's NumPy backend namespace (the backend contract), one per line"""
     names = [n for n in dir(gnp) if not n.startswith("_")]
@@ -459,6 +481,12 @@ def gen_namespace():
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "namespace":
         gen_namespace()
+    elif len(sys.argv) > 2 and sys.argv[2] == "dataloader":
+        o = {}
+        gen_dataloader(o)
+        path = os.path.join(HERE, "ref_dataloader.npz")
+        np.savez_compressed(path, **{k: np.asarray(v) for k, v in o.items()})
+        print("wrote", path, os.path.getsize(path), "bytes,", len(o), "arrays")
     elif len(sys.argv) > 2 and sys.argv[2] == "remap_extra":
         o = {}
         gen_remap_extra(o)

@@ -599,6 +599,40 @@ def test_gradients_noisy_kernel(gp, gnp, golden, tag):
             assert rel_err(gr, g[f"grad_{tag}_{name}_grad"][i]) < 1e-7
 
 
+def test_dataloader_flow_example30(gp, gnp, golden):
+    """examples/gpmp_example30_dataloader.py at small size: gpmp_amd.dataloader.Dataset / DataLoader, loader-based initial
+    guesses, select_parameters_with_remap(dataloader=...) through the batch criterion"""
+    from gpmp_amd.dataloader import DataLoader, Dataset
+
+    g = golden("dataloader")
+    xi, zi, bs = g["dl_xi"], g["dl_zi"], int(g["dl_batch"])
+    ds = Dataset([xi[:100], xi[100:]], [zi[:100], zi[100:]])        # two shards, batches straddle them
+    loader = DataLoader(ds, batch_size=bs, shuffle=False)
+    assert len(loader) == int(g["dl_len"]) and len(ds) == 240
+    xb, zb = next(iter(loader))
+    np.testing.assert_array_equal(gnp.to_np(xb), xi[:bs])
+    got = [gnp.to_np(b[0]) for b in loader]
+    np.testing.assert_array_equal(np.concatenate(got), xi)
+    sh = DataLoader(ds, batch_size=bs, shuffle=True, seed=3)
+    perm = np.concatenate([gnp.to_np(b[1]) for b in sh])
+    assert not np.array_equal(perm, zi) and np.allclose(np.sort(perm), np.sort(zi))
+    k = gp.kernel.MaternCovariance(2)
+    model = gp.Model(constant_mean, k)
+    np.testing.assert_allclose(gp.kernel.anisotropic_parameters_initial_guess(model, dataloader=loader), g["dl_guess"], rtol=1e-9)
+    np.testing.assert_allclose(gp.kernel.anisotropic_parameters_initial_guess_zero_mean(gp.Model(None, k, None, None, "zero"), dataloader=loader),
+                               g["dl_guess_zero_mean"], rtol=1e-9)
+    m0, c0 = gp.kernel.anisotropic_parameters_initial_guess_constant_mean(gp.Model(param_mean, k, None, None, "parameterized"), dataloader=loader)
+    np.testing.assert_allclose(m0, g["dl_guess_cm_mean"], rtol=1e-9)
+    np.testing.assert_allclose(c0, g["dl_guess_cm_cov"], rtol=1e-9)
+    model, info = gp.kernel.select_parameters_with_remap(model, dataloader=loader, info=True)
+    crit = info.selection_criterion_nograd
+    assert abs(float(crit(g["dl_guess"])) - float(g["dl_crit_at_guess"])) < 1e-9 * abs(float(g["dl_crit_at_guess"]))
+    assert abs(float(crit(g["dl_covparam"])) - float(g["dl_crit_opt"])) < 1e-8 * abs(float(g["dl_crit_opt"]))
+    assert float(crit(model.covparam)) <= float(g["dl_crit_opt"]) + 1e-4 * abs(float(g["dl_crit_opt"]))
+    zpm, zpv = model.predict(xi, zi, xi[:10] + 0.01)
+    assert zpm.shape == (10,) and np.all(zpv >= 0)
+
+
 def test_user_kernel_written_with_gnp_primitives(gp, gnp):
     """A covariance written by the user from backend primitives, as examples/gpmp_example07_nd_regression.py:95-131 does
     (gnp.exp on the PARAMETERS, gnp.scaled_distance, maternp_kernel, gnp.eye): parameters arrive as host vectors from
