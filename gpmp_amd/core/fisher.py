@@ -10,6 +10,7 @@ import torch
 
 from .. import _lib
 from .. import num as gnp
+from .utils import mean_values as _mean_values
 from ..kernel.matern import MaternCovariance
 
 
@@ -68,7 +69,7 @@ def fisher_information_cpd(model, xi, covparam=None, epsilon: float = 1e-3):
     theta = np.asarray(gnp.to_np(model.covparam if covparam is None else covparam), dtype=np.float64).reshape(-1)
     xi = gnp.asarray(xi)
     F = gnp.cholesky_factor(gnp.asarray(model.covariance(xi, xi, theta)), overwrite=True)
-    P = gnp.asarray(model.mean(xi, model.meanparam))
+    P = _mean_values(model, xi, model.meanparam)
     U = F.solve(P)                                   # n x q
     S = P.T @ U
     US = U @ torch.linalg.inv(0.5 * (S + S.T))       # n x q

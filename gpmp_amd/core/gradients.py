@@ -19,6 +19,7 @@ import torch
 
 from .. import _lib
 from .. import num as gnp
+from .utils import mean_values as _mean_values
 from ..kernel.matern import MaternCovariance
 from .linalg import MeanSpace, covariance_factor
 
@@ -78,7 +79,7 @@ class REMLAnalytic:
     def value_and_state(self, covparam, xi, zi):
         xi, zi = gnp.asarray(xi), gnp.asarray(zi).reshape(-1)
         F = covariance_factor(self.model, xi, covparam)
-        P = gnp.asarray(self.model.mean(xi, self.model.meanparam))
+        P = _mean_values(self.model, xi, self.model.meanparam)
         n, q = P.shape
         ms = MeanSpace(F, zi, P)
         value = 0.5 * ((n - q) * math.log(2.0 * math.pi) + ms.logdet_contrast() + ms.quad())

@@ -15,6 +15,7 @@ import numpy
 import torch
 
 from .. import num as gnp
+from .utils import mean_values as _mean_values
 from ..config import get_config
 from .linalg import covariance_factor
 
@@ -35,7 +36,7 @@ class _Predictor:
         cols = [zi_centered.reshape(-1, 1)]
         self.q = 0
         if use_mean:
-            P = gnp.asarray(model.mean(xi, model.meanparam))
+            P = _mean_values(model, xi, model.meanparam)
             self.q = P.shape[1]
             cols.append(P)
         self.W = self.F.solve_lower(gnp.hstack(cols) if len(cols) > 1 else cols[0])
@@ -55,7 +56,7 @@ class _Predictor:
         reduction = D[-1].clone()                           # lambda^T Kit (+ mu^T Pt^T)
         mu = None
         if self.q:
-            Pt = gnp.asarray(model.mean(xt, model.meanparam))   # m x q
+            Pt = _mean_values(model, xt, model.meanparam)   # m x q
             R = D[1:-1] - Pt.T                                  # S mu
             mu = self.Sinv @ R                                  # q x m
             mean = mean - self.b @ mu
@@ -129,7 +130,7 @@ def _posterior_variance(model, xi, xt, lam, mu, red, return_type):
         Kit = gnp.asarray(model.covariance(xi, xt, model.covparam))
         cov = Ktt - gnp.matmul(lam.T.contiguous(), Kit)
         if mu is not None:
-            Pt = gnp.asarray(model.mean(xt, model.meanparam))
+            Pt = _mean_values(model, xt, model.meanparam)
             cov = cov - mu.T @ Pt.T
         return cov
     raise ValueError("return_type must be in {-1, 0, 1}")
@@ -151,8 +152,8 @@ def select_predictor(model, xi, zi, xt, return_lambdas=True):
         if model.meanparam is None:
             raise ValueError("For meantype 'parameterized', meanparam should not be None.")
         use_mean = False
-        zi_centered = zi - gnp.asarray(model.mean(xi, model.meanparam)).reshape(-1)
-        zt_prior_mean = gnp.asarray(model.mean(xt, model.meanparam)).reshape(-1)
+        zi_centered = zi - _mean_values(model, xi, model.meanparam).reshape(-1)
+        zt_prior_mean = _mean_values(model, xt, model.meanparam).reshape(-1)
     else:
         raise ValueError(
             f"Invalid meantype {model.meantype}. Supported types are 'zero', 'parameterized', and 'linear_predictor'."

@@ -4,6 +4,7 @@ import math
 import numpy
 
 from .. import num as gnp
+from .utils import mean_values as _mean_values
 from .linalg import MeanSpace, covariance_factor
 
 
@@ -27,7 +28,7 @@ def negative_log_likelihood_zero_mean(model, covparam, xi, zi):
 def negative_log_likelihood(model, meanparam, covparam, xi, zi):
     """gpmp/core/likelihood.py:55-89."""
     xi, zi = gnp.asarray(xi), gnp.asarray(zi).reshape(-1)
-    centered = zi - gnp.asarray(model.mean(xi, meanparam)).reshape(-1)
+    centered = zi - _mean_values(model, xi, meanparam).reshape(-1)
     return negative_log_likelihood_zero_mean(model, covparam, xi, centered)
 
 
@@ -38,7 +39,7 @@ def negative_log_restricted_likelihood(model, covparam, xi, zi):
         F = covariance_factor(model, xi, covparam)
     except RuntimeError:
         return gnp.safe_inf()
-    P = gnp.asarray(model.mean(xi, model.meanparam))
+    P = _mean_values(model, xi, model.meanparam)
     n, q = P.shape
     ms = MeanSpace(F, zi, P)
     return _scalar(0.5 * ((n - q) * math.log(2.0 * math.pi) + ms.logdet_contrast() + ms.quad()))

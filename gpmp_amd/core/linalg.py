@@ -12,6 +12,7 @@ exact and need only the Cholesky factor of K and q + 1 triangular solves:
 import numpy
 
 from .. import num as gnp
+from .utils import mean_values as _mean_values
 from ..kernel.matern import MaternCovariance
 
 
@@ -95,7 +96,7 @@ def k_inverses(model, xi, zi, covparam):
 def norm_k_sqrd(model, xi, zi, covparam):
     """gpmp/core/linalg.py:132-141: (Wz)^T (WKW)^-1 (Wz) through the Schur identity."""
     F = covariance_factor(model, xi, covparam)
-    P = gnp.asarray(model.mean(xi, model.meanparam))
+    P = _mean_values(model, xi, model.meanparam)
     ms = MeanSpace(F, zi.reshape(-1), P)
     return gnp.asarray(numpy.asarray(ms.quad())).reshape(())
 

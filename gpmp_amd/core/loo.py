@@ -2,6 +2,7 @@
 import torch
 
 from .. import num as gnp
+from .utils import mean_values as _mean_values
 from .linalg import covariance_factor
 
 
@@ -34,14 +35,14 @@ def _loo_with_zero_mean(model, covparam, xi, zi):
 
 def _loo_with_parameterized_mean(model, meanparam, covparam, xi, zi):
     """gpmp/core/loo.py:89-97."""
-    zi_prior_mean = gnp.asarray(model.mean(xi, meanparam)).reshape(-1)
+    zi_prior_mean = _mean_values(model, xi, meanparam).reshape(-1)
     zloo_c, sigma2loo, eloo_c = _loo_with_zero_mean(model, covparam, xi, zi - zi_prior_mean)
     return zloo_c + zi_prior_mean, sigma2loo, eloo_c
 
 
 def _loo_with_linear_predictor_mean_cpd(model, meanparam, covparam, xi, zi):
     """gpmp/core/loo.py:103-130 with Qinv = K^-1 - U S^-1 U^T, U = K^-1 P (no QR, no n^3 GEMMs)."""
-    P = gnp.asarray(model.mean(xi, meanparam))
+    P = _mean_values(model, xi, meanparam)
     Y = gnp.hstack((zi.reshape(-1, 1), P))
     d, X = _kinv_diag_and_solve(model, covparam, xi, Y)
     Kinv_z, U = X[:, 0], X[:, 1:]

@@ -38,3 +38,16 @@ def validate_model_mean(meantype: str, mean, meanparam):
         raise TypeError(
             "For meantype 'parameterized' or 'linear_predictor', mean must be a callable function"
         )
+
+
+def mean_values(model, x, param):
+    """``model.mean(x, param)`` as a device array.  Mean PARAMETERS reach this backend as host vectors (SciPy's iterate, a
+    slice of it, ``model.meanparam``); user mean functions combine them with device arrays (``param * gnp.ones(...)``,
+    examples/gpmp_example22_1d_interpolation_variation_ml.py:38-39), so they are moved to the device first."""
+    import torch
+
+    from .. import num as gnp
+
+    if param is not None and not isinstance(param, torch.Tensor):
+        param = gnp.asarray(param)
+    return gnp.asarray(model.mean(x, param))

@@ -204,7 +204,24 @@ sin, cos, tanh = _elementwise(torch.sin, numpy.sin), _elementwise(torch.cos, num
 maximum = lambda a, b: torch.clamp(a, min=b) if not isinstance(b, torch.Tensor) else torch.maximum(a, b)  # noqa: E731
 minimum = lambda a, b: torch.clamp(a, max=b) if not isinstance(b, torch.Tensor) else torch.minimum(a, b)  # noqa: E731
 where, isnan, isinf, isfinite = torch.where, torch.isnan, torch.isinf, torch.isfinite
-hstack, vstack, stack, concatenate = torch.hstack, torch.vstack, torch.stack, torch.cat
+def _joiner(torch_fn, numpy_fn):
+    """Sequences of device tensors are joined on the device; sequences made only of host values (parameter vectors, which
+    this backend keeps on the host as the NumPy backend does) are joined by NumPy; mixtures are moved to the device."""
+    def f(seq, *args, **kwargs):
+        seq = list(seq)
+        if not builtins.any(isinstance(v, torch.Tensor) for v in seq):
+            if "dim" in kwargs:
+                kwargs["axis"] = kwargs.pop("dim")
+            return numpy_fn([numpy.asarray(v) for v in seq], *args, **kwargs)
+        if "axis" in kwargs:
+            kwargs["dim"] = kwargs.pop("axis")
+        return torch_fn([asarray(v) for v in seq], *args, **kwargs)
+    f.__name__ = numpy_fn.__name__
+    return f
+
+
+hstack, vstack = _joiner(torch.hstack, numpy.hstack), _joiner(torch.vstack, numpy.vstack)
+stack, concatenate = _joiner(torch.stack, numpy.stack), _joiner(torch.cat, numpy.concatenate)
 diag, trace, copy = torch.diag, torch.trace, torch.clone
 any, all = torch.any, torch.all  # noqa: A001
 
