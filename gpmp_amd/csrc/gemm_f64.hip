@@ -883,10 +883,13 @@ int launch_t(const GemmParams& p, hipStream_t st) {
                     (p.lda % 2 == 0) && (p.ldb % 2 == 0) && (p.ldc >= p.N) &&
                     ((long)BM * p.lda * 8 + (long)p.K * 8 < 0x7FFFFFFFL) && ((long)BN * p.ldb * 8 + (long)p.K * 8 < 0x7FFFFFFFL);
   // small NT products on a grid that cannot fill the machine: 64 x 64 tiles (latency kernel above)
-  static int use_small = -1;
-  if (use_small < 0) { const char* e = getenv("GPMP_GEMM_SMALL_NT"); use_small = e ? atoi(e) : 1; }
+  static int use_small = -1, small_max = 128;
+  if (use_small < 0) {
+    const char* e = getenv("GPMP_GEMM_SMALL_NT"); use_small = e ? atoi(e) : 1;
+    const char* m = getenv("GPMP_GEMM_SMALL_NT_MAX"); if (m) small_max = atoi(m);
+  }
   const bool small_nt = AKC && BKC && use_small && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
-                        p.ntiles <= (p.K >= 512 ? 384 : 128) && !(p.kstart_row | p.kend_row | p.kstart_col);
+                        p.ntiles <= (p.K >= 512 ? 384 : small_max) && !(p.kstart_row | p.kend_row | p.kstart_col);
   {
     // executed flops of this launch (tiles actually visited, k range actually swept)
     const double kavg = (p.kstart_row || p.kend_row || p.kstart_col) ? 0.5 * p.K : (double)p.K;
