@@ -6,7 +6,8 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXAMPLES = ["example02_1d_interpolation", "example07_nd_noisy_regression", "example10_sample_paths",
+EXAMPLES = ["example02_1d_interpolation", "example03_06_remap_2d_and_side_information", "example07_nd_noisy_regression",
+            "example10_sample_paths",
             "example11_22_noisy_paths_and_ml"]
 
 
