@@ -30,9 +30,15 @@ def _chunk_cols(n, m):
 class _Predictor:
     """State shared by every chunk of one prediction: factor of K, W = L^-1 [z, P], S^-1."""
 
-    def __init__(self, model, xi, zi_centered, use_mean):
+    def __init__(self, model, xi, zi_centered, use_mean, xt_first=None):
         self.model, self.xi = model, xi
-        self.F = covariance_factor(model, xi, model.covparam)
+        self.V_first = None
+        if xt_first is not None and xt_first.shape[0] > 4:
+            # K(xi, xt) of the first chunk is built before the factorisation so that its solve can overlap the factorisation
+            Kit = gnp.as_matrix(gnp.asarray(model.covariance(xi, xt_first, model.covparam)))
+            self.F, self.V_first = covariance_factor(model, xi, model.covparam, solve_along=Kit)
+        else:
+            self.F = covariance_factor(model, xi, model.covparam)
         cols = [zi_centered.reshape(-1, 1)]
         self.q = 0
         if use_mean:
@@ -49,8 +55,11 @@ class _Predictor:
 
     def chunk(self, xt, want_lambda, want_var=True):
         model = self.model
-        Kit = gnp.as_matrix(gnp.asarray(model.covariance(self.xi, xt, model.covparam)))
-        V = self.F.solve_lower(Kit, overwrite=True)         # V = L^-1 Kit, in place
+        if self.V_first is not None:                        # first chunk: solved together with the factorisation
+            V, self.V_first = self.V_first, None
+        else:
+            Kit = gnp.as_matrix(gnp.asarray(model.covariance(self.xi, xt, model.covparam)))
+            V = self.F.solve_lower(Kit, overwrite=True)     # V = L^-1 Kit, in place
         D = gnp.coldots(V, self.W)                          # rows: V^T w, V^T Wp (q rows), colsumsq(V)
         mean = D[0].clone()
         reduction = D[-1].clone()                           # lambda^T Kit (+ mu^T Pt^T)
@@ -79,8 +88,8 @@ class _Predictor:
 
 def _run(model, xi, zi_centered, xt, use_mean, want_lambda):
     n, m = xi.shape[0], xt.shape[0]
-    pred = _Predictor(model, xi, zi_centered, use_mean)
     mc = _chunk_cols(n, m)
+    pred = _Predictor(model, xi, zi_centered, use_mean, xt_first=xt[: max(mc, 1)] if m > 0 else None)
     means, reds, lams, mus = [], [], [], []
     for j0 in range(0, m, max(mc, 1)):
         xtc = xt[j0 : j0 + mc]

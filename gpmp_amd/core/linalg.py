@@ -16,13 +16,16 @@ from .utils import mean_values as _mean_values
 from ..kernel.matern import MaternCovariance
 
 
-def covariance_factor(model, xi, covparam):
-    """Cholesky factor of K(xi, xi): lower-triangle Gram build when the covariance is declared Matern."""
+def covariance_factor(model, xi, covparam, solve_along=None):
+    """Cholesky factor of K(xi, xi): lower-triangle Gram build when the covariance is declared Matern.
+    ``solve_along``: an n x m matrix B to be overwritten by L^-1 B in the same library call -> (factor, L^-1 B)."""
     cov = model.covariance
     if isinstance(cov, MaternCovariance):
         K = cov.gram_lower(xi, covparam)
     else:
         K = gnp.asarray(cov(xi, xi, covparam))
+    if solve_along is not None:
+        return gnp.cholesky_factor_solve(K, solve_along, overwrite=True)
     return gnp.cholesky_factor(K, overwrite=True)
 
 

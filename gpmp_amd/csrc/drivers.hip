@@ -140,14 +140,14 @@ extern "C" int gpmp_predict_zero_mean(const double* xi, const double* zi, const 
   const double diag = noise ? std::exp(theta_host[1]) : 10.0 * sigma2 * DBL_EPSILON;
   int rc = gpmp_matern_gram(xi, nullptr, n, n, d, p, theta_host, noise, diag, 1, K, l.ldn, stream);
   if (rc) return rc;
-  rc = gpmp_potrf_lower_async(K, n, l.ldn, dinv, info_dev, stream);
+  rc = gpmp_matern_gram(xi, xt, n, m, d, p, theta_host, noise, 0.0, 0, Kit, l.ldm, stream);
+  if (rc) return rc;
+  // factorisation and V = L^-1 K(xi, xt) (in place) in one call: the leading half of the solve overlaps the trailing half
+  // of the factorisation
+  rc = gpmp_potrf_trsm_lower_async(K, n, l.ldn, dinv, info_dev, Kit, m, l.ldm, stream);
   if (rc) return rc;
   GPMP_HIP_TRY(hipMemcpy2DAsync(w, 16 * sizeof(double), zi, sizeof(double), sizeof(double), n, hipMemcpyDeviceToDevice, st));
   rc = gpmp_trsm_lower(K, n, l.ldn, dinv, w, 1, 16, 0, nullptr, stream);                    // w = L^-1 z
-  if (rc) return rc;
-  rc = gpmp_matern_gram(xi, xt, n, m, d, p, theta_host, noise, 0.0, 0, Kit, l.ldm, stream);
-  if (rc) return rc;
-  rc = gpmp_trsm_lower(K, n, l.ldn, dinv, Kit, m, l.ldm, 0, dinv, stream);                  // V = L^-1 K(xi, xt), in place
   if (rc) return rc;
   rc = gpmp_coldots(Kit, n, m, l.ldm, w, 1, 16, D, l.ldm, ws + l.cd, stream);               // V^T w and colsumsq(V)
   if (rc) return rc;

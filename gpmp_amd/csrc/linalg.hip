@@ -235,7 +235,22 @@ int factor_panel(double* A, int n, long lda, double* dinv, int* info_dev, int p0
   return 0;
 }
 
-int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hipStream_t s0) {
+int trsm_forward(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int tri,
+                 int tri_off, double* gws, hipStream_t st);
+
+// Optional overlap (predict): B (n x m) <- L^-1 B.  The leading half of the forward solve needs only the columns of L
+// left of n1; it is enqueued on a third stream as soon as the panel ending at n1 is factored and runs while the trailing
+// half of the factorisation -- 1/8 of its flops, but bound by the panel chain -- proceeds (at n = 32768 that half takes
+// 47 ms for 21 ms of MFMA work).  The rest of the solve follows on the caller's stream.
+struct SolveAlong {
+  double* B = nullptr;
+  int m = 0;
+  long ldb = 0;
+  double* gws = nullptr;
+};
+hipStream_t g_solve_stream = nullptr;
+
+int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hipStream_t s0, const SolveAlong* sa = nullptr) {
   // panel boundaries: 1024-wide panels while the trailing matrix is large (rank-1024 updates run at
   // ~89 % of the MFMA peak against ~84 % for rank-512, and the longer panel still hides behind them),
   // 512-wide afterwards (shorter latency-bound tail)
@@ -266,6 +281,15 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   hipEvent_t e_f = g_la.next();                 // panel k factored (on s1)
   GPMP_HIP_TRY(hipEventRecord(e_f, s1));
   hipEvent_t e_u2 = nullptr;                    // trailing update k-1 finished (on s0)
+  bool half_launched = false;
+  int n1_solved = 0;
+  hipEvent_t e_half = nullptr;
+  if (sa != nullptr && g_solve_stream == nullptr) GPMP_HIP_TRY(hipStreamCreateWithFlags(&g_solve_stream, hipStreamNonBlocking));
+  if (sa != nullptr) {   // the solve stream starts after everything already queued by the caller (B is built there)
+    hipEvent_t eb = g_la.next();
+    GPMP_HIP_TRY(hipEventRecord(eb, s0));
+    GPMP_HIP_TRY(hipStreamWaitEvent(g_solve_stream, eb, 0));
+  }
   for (int k = 0; k + 1 < np; ++k) {
     const int p0 = pb[k], p1 = pb[k + 1], p2 = pb[k + 2];   // panel k = [p0, p1), next panel = [p1, p2)
     const int w = p1 - p0;
@@ -278,6 +302,16 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     if (rc) return rc;
     hipEvent_t e_f_next = g_la.next();
     GPMP_HIP_TRY(hipEventRecord(e_f_next, s1));
+    if (sa != nullptr && !half_launched && p2 >= n / 2 && p2 < n && p2 % (OUTER_BLOCKS * NB) == 0) {
+      // columns [0, p2) of L are final once e_f_next has fired: solve the first p2 rows of B behind it
+      half_launched = true;
+      n1_solved = p2;
+      GPMP_HIP_TRY(hipStreamWaitEvent(g_solve_stream, e_f_next, 0));
+      rc = trsm_forward(A, p2, lda, dinv, sa->B, sa->m, sa->ldb, 0, 0, sa->gws, g_solve_stream);
+      if (rc) return rc;
+      e_half = g_la.next();
+      GPMP_HIP_TRY(hipEventRecord(e_half, g_solve_stream));
+    }
     // -- main: rank-w update of the rest of the trailing matrix with P_k
     GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_f, 0));
     if (p2 < n) {
@@ -290,6 +324,18 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     e_f = e_f_next;
   }
   GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_f, 0));  // join: everything visible to the caller's stream
+  if (sa != nullptr) {
+    if (!half_launched) return trsm_forward(A, n, lda, dinv, sa->B, sa->m, sa->ldb, 0, 0, sa->gws, s0);
+    // B2 -= L21 X1, then the trailing rows, on the caller's stream
+    GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_half, 0));
+    GemmOpts plain;
+    const int n1 = n1_solved;
+    rc = launch_gemm(true, false, n - n1, sa->m, n1, -1.0, A + (long)n1 * lda, lda, sa->B, sa->ldb, 1.0, sa->B + (long)n1 * sa->ldb,
+                     sa->ldb, plain, s0);
+    if (rc) return rc;
+    return trsm_forward(A + (long)n1 * lda + n1, n - n1, lda, dinv + (size_t)(n1 / NB) * NB * NB, sa->B + (long)n1 * sa->ldb, sa->m,
+                        sa->ldb, 0, 0, sa->gws, s0);
+  }
   return 0;
 }
 
@@ -358,6 +404,32 @@ extern "C" int gpmp_potrf_lower_async(double* A, int n, long lda, double* dinv, 
   GPMP_ARG(info_dev != nullptr, 5, "info is NULL");
   if (n == 0) return 0;
   return potrf_lower(A, n, lda, dinv, info_dev, as_stream(stream));
+}
+
+extern "C" int gpmp_potrf_trsm_lower_async(double* A, int n, long lda, double* dinv, int* info_dev, double* B, int m, long ldb,
+                                           gpmp_stream_t stream) {
+  GPMP_ARG(A != nullptr, 1, "A is NULL");
+  GPMP_ARG(n >= 0, 2, "n < 0");
+  GPMP_ARG(lda >= n, 3, "lda < n");
+  GPMP_ARG(dinv != nullptr, 4, "dinv is NULL");
+  GPMP_ARG(info_dev != nullptr, 5, "info_dev is NULL");
+  GPMP_ARG(B != nullptr, 6, "B is NULL");
+  GPMP_ARG(m >= 0 && ldb >= m, 8, "ldb < m");
+  if (n == 0) return 0;
+  hipStream_t st = as_stream(stream);
+  GPMP_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
+  double* gws = (n > 2 * OUTER_BLOCKS * NB) ? dinv + (size_t)((n + NB - 1) / NB) * NB * NB : nullptr;
+  static int overlap = -1;
+  if (overlap < 0) { const char* e = getenv("GPMP_POTRF_SOLVE_OVERLAP"); overlap = e ? atoi(e) : 1; }
+  if (!overlap || m <= 4 || n <= 8 * OUTER_BLOCKS * NB) {
+    int rc = (n <= 2 * OUTER_BLOCKS * NB) ? potrf_blocked(A, n, lda, dinv, info_dev, 0, st) : potrf_lookahead(A, n, lda, dinv, info_dev, st);
+    if (rc || m == 0) return rc;
+    if (m <= 4) return trsv_few(A, n, lda, dinv, B, m, ldb, 0, st);
+    return trsm_forward(A, n, lda, dinv, B, m, ldb, 0, 0, gws, st);
+  }
+  SolveAlong sa;
+  sa.B = B; sa.m = m; sa.ldb = ldb; sa.gws = gws;
+  return potrf_lookahead(A, n, lda, dinv, info_dev, st, &sa);
 }
 
 extern "C" int gpmp_trtri_diag_blocks(const double* L, int n, long ldl, double* dinv, gpmp_stream_t stream) {

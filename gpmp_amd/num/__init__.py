@@ -406,6 +406,29 @@ def cholesky_factor(A, overwrite=False, check=True) -> CholFactor:
     return CholFactor(L, dinv)
 
 
+def cholesky_factor_solve(A, B, overwrite=True, check=True):
+    """Factor A and solve L X = B in one library call (gpmp_potrf_trsm_lower_async: the solve of the leading rows
+    overlaps the trailing part of the factorisation).  Returns (CholFactor, X); A and B are overwritten by default."""
+    lib = _lib.load()
+    A, B = asarray(A), asarray(B)
+    n = A.shape[0]
+    if A.dim() != 2 or A.shape[1] != n or B.dim() != 2 or B.shape[0] != n:
+        raise ValueError("cholesky_factor_solve needs a square A (n x n) and a 2-D B (n x m)")
+    L = as_matrix(A, copy=not overwrite)
+    X = as_matrix(B, copy=not overwrite)
+    dinv = torch.empty(builtins.max(int(lib.gpmp_dinv_elems(n)), 1), dtype=torch.float64, device=_dev())
+    info = torch.zeros(1, dtype=torch.int32, device=_dev())
+    _lib.check(lib.gpmp_potrf_trsm_lower_async(_ptr(L), n, _ld(L), _ptr(dinv), _ptr(info), _ptr(X), X.shape[1], _ld(X), _stream()),
+               "gpmp_potrf_trsm_lower_async")
+    if check:
+        k = int(info.item())
+        if k != 0:
+            raise HipLinAlgError(
+                f"Matrix is not positive definite: Cholesky factorization failed at leading minor {k} (potrf info={k})"
+            )
+    return CholFactor(L, dinv), X
+
+
 def cholesky(A):
     """numpy.linalg.cholesky (numpy_backend.py:136): lower factor, zeros above the diagonal."""
     lib = _lib.load()

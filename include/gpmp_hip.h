@@ -98,6 +98,14 @@ size_t gpmp_dinv_elems(int n);
  * gpmp/num/numpy_backend.py:30-46,158-162); the factor is then unspecified.  Enqueue only. */
 int gpmp_potrf_lower_async(double* A, int n, long lda, double* dinv, int* info_dev, gpmp_stream_t stream);
 
+/* gpmp_potrf_lower_async followed by B <- L^-1 B (n x m, as gpmp_trsm_lower with trans = 0), with the solve of the leading
+ * half of the rows enqueued on an internal stream as soon as those columns of L are final, so that it overlaps the
+ * chain-bound trailing half of the factorisation (the path of one prediction: cholesky_solve on K(xi,xi) and K(xi,xt),
+ * gpmp/core/kriging.py:59-62).  dinv: gpmp_dinv_elems(n) doubles (block inverses + scratch of the solve leaves).
+ * Everything is joined into `stream` before return; *info_dev as gpmp_potrf_lower_async (B is then unspecified). */
+int gpmp_potrf_trsm_lower_async(double* A, int n, long lda, double* dinv, int* info_dev, double* B, int m, long ldb,
+                                gpmp_stream_t stream);
+
 /* B <- op(L)^-1 B for an n x m row-major B; trans = 0: L, 1: L^T.  Replaces
  * scipy.linalg.solve_triangular (numpy_backend.py:467-468, gpmp/core/linalg.py:41).  If
  * dinv == NULL the diagonal-block inverses are recomputed into `scratch` (gpmp_dinv_elems(n)).
@@ -173,7 +181,7 @@ int gpmp_nll_zero_mean(const double* x, const double* z, int n, int d, int p, co
                        int noise, double* ws, double* nll_dev, int* info_dev, gpmp_stream_t stream);
 
 /* Posterior mean and variance at m points: kriging_predictor_with_zero_mean + _compute_posterior_variance
- * (gpmp/core/kriging.py:35-67,170-199) restated as ONE solve  V = L^-1 K(xi, xt):
+ * (gpmp/core/kriging.py:35-67,170-199) restated as ONE solve  V = L^-1 K(xi, xt) (gpmp_potrf_trsm_lower_async):
  *   zpm = V^T (L^-1 zi),   zpv = sigma^2 - colsumsq(V)   (clamped at 0 when zero_neg_variances != 0, as
  * Model.predict does, gpmp/core/model.py:290-296).  xi: n x d, zi: n, xt: m x d, zpm_dev / zpv_dev: m, all on the
  * device.  A failed factorisation (*info_dev != 0) fills both outputs with NaN.

@@ -184,6 +184,28 @@ def test_cholesky_backward_error_ill_conditioned(gnp, n, rho):
     assert np.linalg.norm(K @ xs - b) / (np.linalg.norm(K, 2) * np.linalg.norm(xs) + np.linalg.norm(b)) < 1e-12
 
 
+@pytest.mark.parametrize("n,m", [(5120, 700), (4736, 1030), (1300, 200), (6000, 3)])
+def test_factor_and_solve_in_one_call(gnp, n, m):
+    """gnp.cholesky_factor_solve / gpmp_potrf_trsm_lower_async (n > 4096: the leading half of the solve runs on a
+    third stream while the factorisation finishes) gives the factor and L^-1 B of the two separate calls"""
+    from oracle import gp_oracle as orc
+
+    rng = np.random.default_rng(n + m)
+    x = rng.random((n, 4))
+    K = orc.maternp_covariance(x, None, 2, np.array([0.0, 1.2, 1.0, 0.8, 1.1])) + 1e-6 * np.eye(n)
+    B = rng.standard_normal((n, m))
+    F0 = gnp.cholesky_factor(gnp.asarray(K))
+    V0 = gnp.to_np(F0.solve_lower(gnp.asarray(B)))
+    F1, V1 = gnp.cholesky_factor_solve(gnp.asarray(K), gnp.asarray(B), overwrite=False)
+    L0, L1 = np.tril(gnp.to_np(F0.L)), np.tril(gnp.to_np(F1.L))
+    assert np.array_equal(L0, L1)                      # same kernels, same order: bit-identical factor
+    assert rel_err(gnp.to_np(V1), V0) < 1e-12
+    assert rel_err(L1 @ gnp.to_np(V1), B) < 1e-9
+    # the factor object returned by the fused call serves further solves
+    z = rng.standard_normal(n)
+    np.testing.assert_allclose(gnp.to_np(F1.solve(gnp.asarray(z))), gnp.to_np(F0.solve(gnp.asarray(z))), rtol=1e-10, atol=1e-12)
+
+
 @pytest.mark.parametrize("n,m", [(1536, 700), (2048, 1024), (1280, 514), (1500, 900)])
 def test_forward_solve_many_rhs_fused_leaves(gnp, n, m):
     """L^-1 B with the factor's scratch area (n > 1024): fused 512-row leaves incl. a narrow last column strip;
