@@ -419,8 +419,11 @@ extern "C" int gpmp_potrf_trsm_lower_async(double* A, int n, long lda, double* d
   hipStream_t st = as_stream(stream);
   GPMP_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
   double* gws = (n > 2 * OUTER_BLOCKS * NB) ? dinv + (size_t)((n + NB - 1) / NB) * NB * NB : nullptr;
-  static int overlap = -1;
-  if (overlap < 0) { const char* e = getenv("GPMP_POTRF_SOLVE_OVERLAP"); overlap = e ? atoi(e) : 1; }
+  // Overlap of the leading half of the solve with the trailing half of the factorisation: off by default.  It gains
+  // 5-7 ms of a 950 ms call (the two GEMM streams lose ~7 % to each other) and makes per-kernel timings of the solve
+  // depend on what the factorisation is doing; read at every call so that tests can exercise both schedules.
+  const char* ov = getenv("GPMP_POTRF_SOLVE_OVERLAP");
+  const int overlap = ov ? atoi(ov) : 0;
   if (!overlap || m <= 4 || n <= 8 * OUTER_BLOCKS * NB) {
     int rc = (n <= 2 * OUTER_BLOCKS * NB) ? potrf_blocked(A, n, lda, dinv, info_dev, 0, st) : potrf_lookahead(A, n, lda, dinv, info_dev, st);
     if (rc || m == 0) return rc;

@@ -186,8 +186,8 @@ def test_cholesky_backward_error_ill_conditioned(gnp, n, rho):
 
 @pytest.mark.parametrize("n,m", [(5120, 700), (4736, 1030), (1300, 200), (6000, 3)])
 def test_factor_and_solve_in_one_call(gnp, n, m):
-    """gnp.cholesky_factor_solve / gpmp_potrf_trsm_lower_async (n > 4096: the leading half of the solve runs on a
-    third stream while the factorisation finishes) gives the factor and L^-1 B of the two separate calls"""
+    """gnp.cholesky_factor_solve / gpmp_potrf_trsm_lower_async, with and without the optional overlap (n > 4096: the
+    leading half of the solve on a third stream while the factorisation finishes): factor and L^-1 B of the separate calls"""
     from oracle import gp_oracle as orc
 
     rng = np.random.default_rng(n + m)
@@ -196,11 +196,19 @@ def test_factor_and_solve_in_one_call(gnp, n, m):
     B = rng.standard_normal((n, m))
     F0 = gnp.cholesky_factor(gnp.asarray(K))
     V0 = gnp.to_np(F0.solve_lower(gnp.asarray(B)))
-    F1, V1 = gnp.cholesky_factor_solve(gnp.asarray(K), gnp.asarray(B), overwrite=False)
-    L0, L1 = np.tril(gnp.to_np(F0.L)), np.tril(gnp.to_np(F1.L))
-    assert np.array_equal(L0, L1)                      # same kernels, same order: bit-identical factor
-    assert rel_err(gnp.to_np(V1), V0) < 1e-12
-    assert rel_err(L1 @ gnp.to_np(V1), B) < 1e-9
+    import os
+
+    L0 = np.tril(gnp.to_np(F0.L))
+    for overlap in ("0", "1"):                         # the library reads the switch at every call
+        os.environ["GPMP_POTRF_SOLVE_OVERLAP"] = overlap
+        try:
+            F1, V1 = gnp.cholesky_factor_solve(gnp.asarray(K), gnp.asarray(B), overwrite=False)
+        finally:
+            os.environ.pop("GPMP_POTRF_SOLVE_OVERLAP", None)
+        L1 = np.tril(gnp.to_np(F1.L))
+        assert np.array_equal(L0, L1)                  # same kernels, same order: bit-identical factor
+        assert rel_err(gnp.to_np(V1), V0) < 1e-12
+        assert rel_err(L1 @ gnp.to_np(V1), B) < 1e-9
     # the factor object returned by the fused call serves further solves
     z = rng.standard_normal(n)
     np.testing.assert_allclose(gnp.to_np(F1.solve(gnp.asarray(z))), gnp.to_np(F0.solve(gnp.asarray(z))), rtol=1e-10, atol=1e-12)
