@@ -60,7 +60,8 @@ def _chol_worker(rank, world, port, pr, pc, n, nb, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("pr,pc,n,nb", [(1, 2, 700, 128), (2, 1, 700, 128), (2, 2, 1000, 128), (2, 2, 1100, 256), (1, 4, 900, 128)])
+@pytest.mark.parametrize("pr,pc,n,nb", [(1, 2, 700, 128), (2, 1, 700, 128), (2, 2, 1000, 128), (2, 2, 1100, 256), (1, 4, 900, 128),
+                                         (2, 4, 1900, 128)])   # the last one is the grid of BASELINE config 5 (8 ranks)
 def test_block_cyclic_cholesky_and_nll(tmp_path, pr, pc, n, nb):
     world = pr * pc
     out = str(tmp_path / "L.npy")
