@@ -77,6 +77,64 @@ def cpu_baseline(n, m, d, threads):
             "sample": f"oracle predict+NLL at n={n}, m={m}, d={d} (config 2 size; {dt:.1f} s), BLAS threads={threads}"}
 
 
+DIST_N = {2: 65536, 4: 90112, 8: 131072}     # about 17 GB of local matrix per GPU; 8 GPUs = BASELINE.json configs[4]
+
+
+def dist_potrf_extra(world, rank, res):
+    """OUTSIDE the timed region, N > 1 only: the 2-D block-cyclic Cholesky (+ NLL) of BASELINE.json configs[4]
+    (n = 131072 on the 2 x 4 grid of 8 GPUs; n scaled to the same memory per GPU on 2 / 4 GPUs) with RCCL panel
+    broadcasts, once per transport.  Fills ``res`` progressively so that a watchdog can still report what finished."""
+    import torch
+    import torch.distributed as dist
+
+    import gpmp_amd.num as gnp
+    from gpmp_amd.dist import BlockCyclicCholesky, ProcessGrid
+    from gpmp_amd.kernel import MaternCovariance
+
+    pr, pc = ProcessGrid.default_shape(world)
+    n = DIST_N.get(world, max(1024, int(46000 * math.sqrt(world)) // 1024 * 1024))
+    d, nb = 8, 1024
+    res.update({"n": n, "d": d, "grid": f"{pr}x{pc}", "block": nb, "noise_variance": 1e-4,
+                "note": "outside the timed region; flops = n^3/3 over wall time of factor() (max over ranks)"})
+    rng = np.random.default_rng(1234)
+    x = rng.random((n, d))
+    z = np.sin(2 * np.pi * x[:, 0]) + x[:, 1:].sum(axis=1)
+    theta = np.concatenate(([0.0], -np.log(0.5 * (1.0 + np.arange(d) / d))))
+    xd = gnp.asarray(x)
+    grid = ProcessGrid(pr, pc)
+    torch.cuda.empty_cache()
+
+    def tmax(v):
+        t = torch.tensor([v], dtype=torch.float64, device=gnp._dev())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    for transport in ("bcast", "p2p"):
+        for rep in ("warm", "timed"):
+            ch = BlockCyclicCholesky(grid, n, nb=nb, transport=transport)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ch.build_local_gram(MaternCovariance(2), xd, theta, 1e-4)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            info = ch.factor()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            gram_s, potrf_s = tmax(t1 - t0), tmax(t2 - t1)
+            entry = {"gram_s": gram_s, "potrf_s": potrf_s, "info": info,
+                     "potrf_tflops_aggregate": (n ** 3 / 3.0) / potrf_s / 1e12,
+                     "frac_of_aggregate_fp64_mfma_peak": (n ** 3 / 3.0) / potrf_s / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
+                     "GB_received_per_gpu_max": tmax(ch.bytes_received / 1e9)}
+            if rep == "timed":
+                t3 = time.perf_counter()
+                entry["nll"] = ch.negative_log_likelihood(z)
+                torch.cuda.synchronize()
+                entry["nll_solve_s"] = tmax(time.perf_counter() - t3)
+            res[f"{transport}_{rep}"] = entry
+            del ch
+    res["status"] = "ok"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,7 +299,44 @@ def main():
             except Exception:
                 threads = os.cpu_count() or 1
             line["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_m, d, threads)
-        print(json.dumps(line))
+
+    # ---- N > 1: the distributed Cholesky of configs[4] as an extra, guarded by a watchdog.  The headline line above is
+    # complete before it starts; whatever happens in here (a hung collective, an exception on some rank) rank 0 still
+    # prints that line, once, and every rank leaves with exit code 0.
+    # (GPMP_BENCH_DIST=0 skips it; =force runs it on a 1 x 1 grid too, which is how it is rehearsed on a one-GPU box)
+    dist_env = os.environ.get("GPMP_BENCH_DIST", "1")
+    run_dist = dist_on and dist_env != "0" and (world > 1 or dist_env == "force")
+    if run_dist:
+        import threading
+
+        res = {"status": "started"}
+        done = threading.Lock()
+
+        def finish(status):
+            if not done.acquire(blocking=False):
+                return
+            res["status"] = status if res.get("status") != "ok" else "ok"
+            if rank == 0:
+                line["extra"]["dist_potrf"] = res
+                print(json.dumps(line), flush=True)
+            if status != "ok":
+                sys.stdout.flush()
+                os._exit(0)            # collectives may be wedged: no orderly teardown
+
+        wd = threading.Timer(float(os.environ.get("GPMP_BENCH_DIST_TIMEOUT", "240")), finish, args=("timeout",))
+        wd.daemon = True
+        wd.start()
+        del out, zpm, zpv
+        try:
+            dist_potrf_extra(world, rank, res)
+            wd.cancel()
+            finish("ok")
+        except BaseException as e:     # noqa: BLE001 -- report and leave; peers are released by their own watchdogs
+            wd.cancel()
+            res["error"] = f"{type(e).__name__}: {e}"[:400]
+            finish("error")
+    elif rank == 0:
+        print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

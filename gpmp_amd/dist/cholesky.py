@@ -19,7 +19,10 @@ Collectives are point-to-point-friendly broadcasts of (n - k nb) nb / Pr resp. /
 """
 from __future__ import annotations
 
+import bisect
+import contextlib
 import math
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -120,15 +123,51 @@ def _comm_tensor(t: torch.Tensor, backend: str) -> torch.Tensor:
     return t.detach().to("cpu").contiguous()
 
 
-class BlockCyclicCholesky:
-    """K = L L^T with K 2-D block-cyclic over ``grid``; keeps the local factor for NLL evaluations."""
+class _Streams:
+    """The caller's stream ("main": bulk trailing updates) and one high-priority side stream (the panel chain and every
+    collective).  With CPU local ops (tests) both degenerate to program order."""
 
-    def __init__(self, grid: ProcessGrid, n: int, nb: int = 1024, ops=None):
+    def __init__(self, device):
+        self.on = device is not None and torch.device(device).type == "cuda"
+        if self.on:
+            self.main = torch.cuda.current_stream(device)
+            self.side = torch.cuda.Stream(device=device, priority=-1)
+
+    def side_ctx(self):
+        return torch.cuda.stream(self.side) if self.on else contextlib.nullcontext()
+
+    def record(self, side: bool):
+        if not self.on:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.side if side else self.main)
+        return ev
+
+    def wait(self, side: bool, ev):
+        if self.on and ev is not None:
+            (self.side if side else self.main).wait_event(ev)
+
+
+class BlockCyclicCholesky:
+    """K = L L^T with K 2-D block-cyclic over ``grid``; keeps the local factor for NLL evaluations.
+
+    ``transport``: "bcast" (one RCCL broadcast per message) or "p2p" (the root sends to every peer of the group in one
+    grouped send/recv batch: xGMI is point-to-point, so the copies leave the root over separate links instead of
+    following a ring).  Default from GPMP_DIST_TRANSPORT, else "bcast".
+    ``lookahead``: prepare panel k+1 (column update, diagonal factor, panel solve, all broadcasts) on a side stream
+    while the bulk of update k runs on the caller's stream."""
+
+    def __init__(self, grid: ProcessGrid, n: int, nb: int = 1024, ops=None, transport: Optional[str] = None,
+                 lookahead: bool = True):
         if nb % 128 != 0:
             raise ValueError("block size must be a multiple of 128 (the GEMM tile)")
         self.grid, self.n, self.nb = grid, n, nb
         self.ops = ops if ops is not None else HipLocalOps()
         self.backend = dist.get_backend(grid.world_group)
+        self.transport = transport or os.environ.get("GPMP_DIST_TRANSPORT", "bcast")
+        if self.transport not in ("bcast", "p2p"):
+            raise ValueError("transport must be 'bcast' or 'p2p'")
+        self.lookahead = lookahead
         self.nblocks = (n + nb - 1) // nb
         self.row_blocks = grid.local_row_blocks(self.nblocks)
         self.col_blocks = grid.local_col_blocks(self.nblocks)
@@ -136,7 +175,7 @@ class BlockCyclicCholesky:
         self.coff = self._offsets(self.col_blocks)
         self.A = None            # local matrix (rows owned x cols owned)
         self.info = 0
-        self.diag_cache = {}     # k -> (L_kk contiguous, dinv) on ranks of the owning process column
+        self.diag_cache = {}     # k -> (L_kk, dinv) on the ranks of the owning process column
         self.bytes_received = 0
 
     # ---- index helpers
@@ -163,6 +202,13 @@ class BlockCyclicCholesky:
     def global_col_index(self):
         return np.concatenate([np.arange(J * self.nb, J * self.nb + self.bs(J)) for J in self.col_blocks]) if self.col_blocks else np.zeros(0, dtype=np.int64)
 
+    def _first_row_after(self, k: int) -> int:
+        """Local index of the first owned block row I > k."""
+        return bisect.bisect_right(self.row_blocks, k)
+
+    def _first_col_after(self, k: int) -> int:
+        return bisect.bisect_right(self.col_blocks, k)
+
     # ---- build
     def build_local_gram(self, cov, x, covparam, diag_add: float):
         """Local part of K(x, x) + diag_add I: one cross-covariance call on the owned row / column points."""
@@ -177,8 +223,8 @@ class BlockCyclicCholesky:
         A = ops.gram_block(cov, xr.contiguous(), xc.contiguous(), covparam)
         # nugget / noise on the global diagonal entries this rank owns
         for li, I in enumerate(self.row_blocks):
-            if I in self.col_blocks:
-                lj = self.col_blocks.index(I)
+            if I % self.grid.pc == self.grid.c:
+                lj = I // self.grid.pc
                 blk = A[self.roff[li]:self.roff[li + 1], self.coff[lj]:self.coff[lj + 1]]
                 torch.diagonal(blk).add_(diag_add)
         self.A = A
@@ -188,107 +234,188 @@ class BlockCyclicCholesky:
         self.A = A_local
 
     # ---- communication helpers
-    def _bcast(self, t: torch.Tensor, src_rank: int, group) -> torch.Tensor:
-        """Broadcast ``t`` (already allocated with the right shape on every participant)."""
+    def _bcast(self, t: torch.Tensor, src_rank: int, group, members: List[int]) -> torch.Tensor:
+        """Root ``src_rank`` -> every rank of ``members`` (``t`` allocated with the same shape everywhere).  Enqueued on
+        the current stream with RCCL; blocking with gloo."""
         ct = _comm_tensor(t, self.backend)
-        dist.broadcast(ct, src=src_rank, group=group)
-        if dist.get_rank(self.grid.world_group) != src_rank:
+        me = self.grid.rank
+        if self.transport == "p2p":
+            if me == src_rank:
+                reqs = [dist.P2POp(dist.isend, ct, peer, group) for peer in members if peer != src_rank]
+            else:
+                reqs = [dist.P2POp(dist.irecv, ct, src_rank, group)]
+            for w in (dist.batch_isend_irecv(reqs) if reqs else []):
+                w.wait()
+        else:
+            dist.broadcast(ct, src=src_rank, group=group)
+        if me != src_rank:
             self.bytes_received += ct.numel() * 8
         if ct.data_ptr() != t.data_ptr():
             t.copy_(ct)
         return t
 
     # ---- factorisation
-    def factor(self):
-        g, ops, nb = self.grid, self.ops, self.nb
-        A = self.A
-        for k in range(self.nblocks):
-            rd, cd = g.owner_row(k), g.owner_col(k)
-            bk = self.bs(k)
-            in_col = g.c == cd
-            # local block indices of the first owned row / col block strictly after k
-            i0 = next((i for i, I in enumerate(self.row_blocks) if I > k), len(self.row_blocks))
-            j0 = next((j for j, J in enumerate(self.col_blocks) if J > k), len(self.col_blocks))
-            Mr = self.roff[-1] - self.roff[i0]
+    def _flat(self, size: int) -> torch.Tensor:
+        return self.ops.empty(1, size).reshape(-1)
 
-            # 1-2. diagonal block: factor on the owner, broadcast (L_kk, dinv) down process column cd
-            if in_col:
-                Lkk = ops.empty(bk, bk)
-                ndinv = ((bk + 127) // 128) * 128 * 128
-                dinv = torch.empty(ndinv, dtype=torch.float64, device=Lkk.device)
-                info_t = torch.zeros(1, dtype=torch.float64, device=Lkk.device)
-                if g.r == rd:
-                    li, lj = self.row_blocks.index(k), self.col_blocks.index(k)
-                    D = A[self.roff[li]:self.roff[li + 1], self.coff[lj]:self.coff[lj + 1]]
-                    dv, info = ops.potrf(D)
-                    dinv.copy_(dv[:ndinv])
-                    Lkk.copy_(D)
-                    info_t[0] = float(int(info.item()))
-                src = g.rank_of(rd, cd)
-                if g.pr > 1:
-                    self._bcast(Lkk, src, g.col_group)
-                    self._bcast(dinv, src, g.col_group)
-                    self._bcast(info_t, src, g.col_group)
-                if int(info_t.item()) != 0 and self.info == 0:
-                    self.info = k * nb + int(info_t.item())
-                self.diag_cache[k] = (Lkk, dinv)
+    def _prepare_panel(self, k: int):
+        """Steps 1-5 of block column k: diagonal factor, panel solve, row broadcast, column exchange.
+        Returns (panel, colop): the rows L_Ik of this process row (I > k) and the rows L_Jk for the owned block columns
+        J > k.  Runs on the current stream; no host synchronisation."""
+        g, ops, A = self.grid, self.ops, self.A
+        rd, cd = g.owner_row(k), g.owner_col(k)
+        bk = self.bs(k)
+        in_col = g.c == cd
+        i0, j0 = self._first_row_after(k), self._first_col_after(k)
+        Mr = self.roff[-1] - self.roff[i0]
+        Nc = self.coff[-1] - self.coff[j0]
+        col_members = [g.rank_of(rr, g.c) for rr in range(g.pr)]
+        row_members = [g.rank_of(g.r, cc) for cc in range(g.pc)]
 
-            # 3. panel solve on the owning process column
-            panel = ops.empty(Mr, bk)     # this process row's panel piece (rows of blocks I > k, I mod Pr == r)
-            if in_col and Mr > 0:
-                lj = self.col_blocks.index(k)
-                P = A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]]
-                ops.trsm_right(Lkk, dinv, P)
-                panel.copy_(P)
-            # 4. broadcast along the process row
-            if g.pc > 1 and Mr > 0:
-                self._bcast(panel, g.rank_of(g.r, cd), g.row_group)
+        # 1-2. diagonal block: factor on the owner; (L_kk | inverses of its 128-blocks | info) travel down the
+        #      process column in ONE message
+        Lkk = dinv = None
+        if in_col:
+            ldk = (bk + 15) // 16 * 16
+            ndinv = ((bk + 127) // 128) * 128 * 128
+            dbuf = self._flat(bk * ldk + ndinv + 1)
+            Lkk = dbuf[: bk * ldk].view(bk, ldk)[:, :bk]
+            dinv = dbuf[bk * ldk: bk * ldk + ndinv]
+            inf = dbuf[bk * ldk + ndinv:]
+            if g.r == rd:
+                li, lj = k // g.pr, k // g.pc
+                D = A[self.roff[li]:self.roff[li + 1], self.coff[lj]:self.coff[lj + 1]]
+                dv, info = ops.potrf(D)
+                dinv.copy_(dv[:ndinv])
+                Lkk.copy_(D)
+                inf.copy_(info.to(torch.float64))
+            if g.pr > 1:
+                self._bcast(dbuf, g.rank_of(rd, cd), g.col_group, col_members)
+            self._info_acc[k: k + 1].copy_(inf)
+            self.diag_cache[k] = (Lkk, dinv)
 
-            # 5. column operand: blocks J > k with J mod Pc == c, gathered inside the process column
+        # 3. panel solve on the owning process column, 4. broadcast along the process row
+        panel = self._panel_buf[k % 2][:Mr, :bk]
+        if in_col and Mr > 0:
+            lj = k // g.pc
+            P = A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]]
+            ops.trsm_right(Lkk, dinv, P)
+            panel.copy_(P)
+        if g.pc > 1 and Mr > 0:
+            self._bcast(panel, g.rank_of(g.r, cd), g.row_group, row_members)
+
+        # 5. column operand: blocks J > k with J mod Pc == c, exchanged inside the process column (the holder of
+        #    block row J is process row J mod Pr)
+        colop = self._colop_buf[k % 2][:Nc, :bk]
+        if Nc > 0:
             my_cols = self.col_blocks[j0:]
-            Nc = self.coff[-1] - self.coff[j0]
-            if Nc > 0:
-                colop = ops.empty(Nc, bk)
-                for rp in range(g.pr):
-                    # blocks held by process row rp (I mod Pr == rp, I > k) that this column needs
-                    blocks = [J for J in my_cols if J % g.pr == rp]
-                    if not blocks:
-                        continue
+            for rp in range(g.pr):
+                blocks = [J for J in my_cols if J % g.pr == rp]
+                if not blocks:
+                    continue
+                if g.pr == 1:
+                    piece = None
+                else:
                     rows = sum(self.bs(J) for J in blocks)
-                    piece = ops.empty(rows, bk)
-                    if g.r == rp:
-                        off = 0
-                        for J in blocks:
-                            li = self.row_blocks.index(J)
-                            src_rows = panel[self.roff[li] - self.roff[i0]: self.roff[li + 1] - self.roff[i0]]
-                            piece[off:off + self.bs(J)].copy_(src_rows)
-                            off += self.bs(J)
-                    if g.pr > 1:
-                        self._bcast(piece, g.rank_of(rp, g.c), g.col_group)
+                    piece = self._piece_buf[:rows, :bk]
+                if g.r == rp:
                     off = 0
                     for J in blocks:
-                        lj = self.col_blocks.index(J)
-                        colop[self.coff[lj] - self.coff[j0]: self.coff[lj + 1] - self.coff[j0]].copy_(piece[off:off + self.bs(J)])
+                        li = J // g.pr
+                        src_rows = panel[self.roff[li] - self.roff[i0]: self.roff[li + 1] - self.roff[i0]]
+                        lj = J // g.pc
+                        dst = colop[self.coff[lj] - self.coff[j0]: self.coff[lj + 1] - self.coff[j0]]
+                        dst.copy_(src_rows)
+                        if piece is not None:
+                            piece[off:off + self.bs(J)].copy_(src_rows)
                         off += self.bs(J)
+                if piece is not None:
+                    self._bcast(piece, g.rank_of(rp, g.c), g.col_group, col_members)
+                    if g.r != rp:
+                        off = 0
+                        for J in blocks:
+                            lj = J // g.pc
+                            colop[self.coff[lj] - self.coff[j0]: self.coff[lj + 1] - self.coff[j0]].copy_(piece[off:off + self.bs(J)])
+                            off += self.bs(J)
+        return panel, colop
 
-                # 6. trailing update of the local blocks: staircase of GEMMs over groups of up to 4 local block rows
-                #    (the few blocks above the diagonal that a group also touches are never read)
-                G = 4
-                for lg in range(i0, len(self.row_blocks), G):
-                    le = min(lg + G, len(self.row_blocks))
-                    I_last = self.row_blocks[le - 1]
-                    jmax = max((j for j, J in enumerate(self.col_blocks) if J <= I_last and J > k), default=-1)
-                    if jmax < j0:
-                        continue
-                    C = A[self.roff[lg]:self.roff[le], self.coff[j0]:self.coff[jmax + 1]]
-                    Ai = panel[self.roff[lg] - self.roff[i0]: self.roff[le] - self.roff[i0]]
-                    Bj = colop[: self.coff[jmax + 1] - self.coff[j0]]
-                    ops.gemm_nt_sub(C, Ai, Bj)
-        # agree on info
-        it = torch.tensor([float(self.info if self.info else 0)], dtype=torch.float64)
+    def _update(self, k: int, panel, colop, jlo: int, jhi: int):
+        """6. A_IJ -= L_Ik L_Jk^T for the local blocks I >= J with local column index in [jlo, jhi): a staircase of GEMMs
+        over groups of up to 4 local block rows (the few blocks above the diagonal that a group also touches are never
+        read afterwards)."""
+        if jhi <= jlo:
+            return
+        ops, A = self.ops, self.A
+        i0, j0 = self._first_row_after(k), self._first_col_after(k)
+        nrb = len(self.row_blocks)
+        G = 4
+        for lg in range(i0, nrb, G):
+            le = min(lg + G, nrb)
+            I_last = self.row_blocks[le - 1]
+            jend = min(bisect.bisect_right(self.col_blocks, I_last), jhi)     # local columns J <= I_last
+            if jend <= jlo:
+                continue
+            C = A[self.roff[lg]:self.roff[le], self.coff[jlo]:self.coff[jend]]
+            Ai = panel[self.roff[lg] - self.roff[i0]: self.roff[le] - self.roff[i0]]
+            Bj = colop[self.coff[jlo] - self.coff[j0]: self.coff[jend] - self.coff[j0]]
+            ops.gemm_nt_sub(C, Ai, Bj)
+
+    def factor(self):
+        """Right-looking factorisation with a one-step look-ahead.  While the caller's stream applies update k to the
+        block columns > k+1, the side stream applies it to block column k+1, factors that column's diagonal block, solves
+        its panel and runs every broadcast of step k+1.  Host code only enqueues; the one synchronisation is the
+        final read of the ``info`` words."""
+        g, ops, nb = self.grid, self.ops, self.nb
+        nblk, ncb = self.nblocks, len(self.col_blocks)
+        st = _Streams(getattr(ops, "device", None))
+        self._panel_buf = [ops.empty(self.local_rows(), nb) for _ in range(2)]
+        self._colop_buf = [ops.empty(self.local_cols(), nb) for _ in range(2)]
+        self._piece_buf = ops.empty(self.local_cols(), nb) if g.pr > 1 else None
+        self._info_acc = self._flat(nblk)
+        self._info_acc.zero_()
+        self.diag_cache = {}
+        ev_main_prev = None
+        start = st.record(False)
+        with st.side_ctx():
+            st.wait(True, start)
+            bufs = self._prepare_panel(0)
+            ev_side = st.record(True)
+        for k in range(nblk):
+            panel, colop = bufs
+            jrest = self._first_col_after(k)
+            if k + 1 < nblk:
+                if self.lookahead:
+                    jnext = jrest
+                    if g.c == g.owner_col(k + 1):
+                        jnext = (k + 1) // g.pc          # local index of block column k + 1
+                        jrest = jnext + 1
+                    with st.side_ctx():
+                        st.wait(True, ev_main_prev)       # update k-1 has finished with column k+1 and with the buffers
+                        self._update(k, panel, colop, jnext, jrest)
+                        nbufs = self._prepare_panel(k + 1)
+                        ev_side_next = st.record(True)
+                    st.wait(False, ev_side)
+                    self._update(k, panel, colop, jrest, ncb)
+                    ev_main_prev = st.record(False)
+                else:
+                    st.wait(False, ev_side)
+                    self._update(k, panel, colop, jrest, ncb)
+                    ev_main_prev = st.record(False)
+                    with st.side_ctx():
+                        st.wait(True, ev_main_prev)
+                        nbufs = self._prepare_panel(k + 1)
+                        ev_side_next = st.record(True)
+                bufs, ev_side = nbufs, ev_side_next
+        st.wait(False, ev_side)
+        self._panel_buf = self._colop_buf = self._piece_buf = None
+        # agree on info: the first failing block column wins
+        mine = math.inf
+        for k, v in enumerate(self._info_acc.cpu().tolist()):
+            if v != 0:
+                mine = k * nb + int(v)
+                break
+        it = torch.tensor([mine], dtype=torch.float64)
         it = it.to("cuda") if self.backend == "nccl" else it
-        if self.info == 0:
-            it[0] = float("inf")
         dist.all_reduce(it, op=dist.ReduceOp.MIN, group=g.world_group)
         self.info = 0 if math.isinf(float(it.item())) else int(it.item())
         return self.info

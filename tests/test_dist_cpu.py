@@ -30,7 +30,7 @@ def _cov(x, y, t, pairwise=False):
     return orc.maternp_covariance_it(np.asarray(x), np.asarray(y), 2, t, pairwise)
 
 
-def _chol_worker(rank, world, port, pr, pc, n, nb, out):
+def _chol_worker(rank, world, port, pr, pc, n, nb, out, transport="bcast", lookahead=True):
     _init(rank, world, port)
     try:
         from gpmp_amd.dist import BlockCyclicCholesky, ProcessGrid
@@ -40,7 +40,7 @@ def _chol_worker(rank, world, port, pr, pc, n, nb, out):
         th = theta_aniso(3, scale=0.4)
         nugget = 1e-6
         grid = ProcessGrid(pr, pc)
-        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=CpuLocalOps())
+        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=CpuLocalOps(), transport=transport, lookahead=lookahead)
         ch.build_local_gram(_cov, x, th, nugget)
         info = ch.factor()
         nll = ch.negative_log_likelihood(z)
@@ -60,12 +60,16 @@ def _chol_worker(rank, world, port, pr, pc, n, nb, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("pr,pc,n,nb", [(1, 2, 700, 128), (2, 1, 700, 128), (2, 2, 1000, 128), (2, 2, 1100, 256), (1, 4, 900, 128),
-                                         (2, 4, 1900, 128)])   # the last one is the grid of BASELINE config 5 (8 ranks)
-def test_block_cyclic_cholesky_and_nll(tmp_path, pr, pc, n, nb):
+@pytest.mark.parametrize("pr,pc,n,nb,transport,lookahead", [
+    (1, 2, 700, 128, "bcast", True), (2, 1, 700, 128, "bcast", True), (2, 2, 1000, 128, "bcast", True),
+    (2, 2, 1100, 256, "p2p", True), (1, 4, 900, 128, "p2p", True), (2, 2, 1000, 128, "bcast", False),
+    (2, 2, 200, 128, "p2p", False),      # fewer blocks than the grid is wide: some ranks own nothing in a column
+    (2, 4, 1900, 128, "bcast", True),    # the grid of BASELINE config 5 (8 ranks) ...
+    (2, 4, 1900, 128, "p2p", True)])     # ... with the root fanning out over separate links
+def test_block_cyclic_cholesky_and_nll(tmp_path, pr, pc, n, nb, transport, lookahead):
     world = pr * pc
     out = str(tmp_path / "L.npy")
-    mp.spawn(_chol_worker, args=(world, _free_port(), pr, pc, n, nb, out), nprocs=world, join=True)
+    mp.spawn(_chol_worker, args=(world, _free_port(), pr, pc, n, nb, out, transport, lookahead), nprocs=world, join=True)
     L = np.load(out)
     info, nll, recv = np.load(out + ".meta.npy")
     x, z = make_xz(n, 3, 7)

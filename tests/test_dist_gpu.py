@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, pr, pc, n, nb, out):
+def _worker(rank, world, port, pr, pc, n, nb, out, transport, lookahead):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
@@ -36,7 +36,7 @@ def _worker(rank, world, port, pr, pc, n, nb, out):
         cov = MaternCovariance(2)
         nugget = 10.0 * math.exp(th[0]) * gnp.eps
         grid = ProcessGrid(pr, pc)
-        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=HipLocalOps())
+        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=HipLocalOps(), transport=transport, lookahead=lookahead)
         ch.build_local_gram(cov, x, th, nugget)
         info = ch.factor()
         nll = ch.negative_log_likelihood(z)
@@ -54,15 +54,17 @@ def _worker(rank, world, port, pr, pc, n, nb, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("pr,pc,n,nb", [(1, 1, 1500, 512), (1, 2, 1500, 256), (2, 2, 2000, 256)])
-def test_block_cyclic_cholesky_hip(tmp_path, pr, pc, n, nb):
+@pytest.mark.parametrize("pr,pc,n,nb,transport,lookahead", [(1, 1, 1500, 512, "bcast", True), (1, 2, 1500, 256, "bcast", True),
+                                                             (2, 2, 2000, 256, "p2p", True), (2, 2, 2000, 256, "bcast", False),
+                                                             (1, 1, 4096, 512, "bcast", True)])
+def test_block_cyclic_cholesky_hip(tmp_path, pr, pc, n, nb, transport, lookahead):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
 
     world = pr * pc
     out = str(tmp_path / "L.npy")
-    mp.spawn(_worker, args=(world, _free_port(), pr, pc, n, nb, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), pr, pc, n, nb, out, transport, lookahead), nprocs=world, join=True)
     L = np.load(out)
     info, nll = np.load(out + ".meta.npy")
     x, z = make_xz(n, 4, 11)

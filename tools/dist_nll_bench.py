@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--block", type=int, default=1024)
     ap.add_argument("--grid", type=str, default="")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--transport", default=None, help="bcast | p2p (default: GPMP_DIST_TRANSPORT or bcast)")
+    ap.add_argument("--no-lookahead", action="store_true")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -51,7 +53,7 @@ def main():
     xd = gnp.asarray(x)
     torch.cuda.synchronize(); dist.barrier()
     t0 = time.perf_counter()
-    ch = BlockCyclicCholesky(grid, n, nb=a.block, ops=HipLocalOps())
+    ch = BlockCyclicCholesky(grid, n, nb=a.block, ops=HipLocalOps(), transport=a.transport, lookahead=not a.no_lookahead)
     ch.build_local_gram(cov, xd, theta, nugget)
     torch.cuda.synchronize(); dist.barrier()
     t1 = time.perf_counter()
@@ -65,7 +67,7 @@ def main():
     dist.all_reduce(recv, op=dist.ReduceOp.MAX)
     if rank == 0:
         line = {"metric": "distributed NLL (2-D block-cyclic Cholesky)", "n": n, "d": d, "grid": f"{pr}x{pc}", "block": a.block,
-                "n_gpus": world, "info": info, "nll": nll, "gram_s": t1 - t0, "potrf_s": t2 - t1, "nll_solve_s": t3 - t2,
+                "n_gpus": world, "transport": ch.transport, "lookahead": ch.lookahead, "info": info, "nll": nll, "gram_s": t1 - t0, "potrf_s": t2 - t1, "nll_solve_s": t3 - t2,
                 "potrf_tflops_aggregate": (n ** 3 / 3.0) / (t2 - t1) / 1e12,
                 "frac_of_aggregate_fp64_mfma_peak": (n ** 3 / 3.0) / (t2 - t1) / 1e12 / (78.6 * world),
                 "max_bytes_received_per_gpu": float(recv.item())}

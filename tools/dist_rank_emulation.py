@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""One rank's share of the block-cyclic Cholesky of BASELINE config 5 (n = 131072 on a 2 x 4 grid) on ONE GPU.
+
+The collectives are replaced by no-ops, so a rank outside the owning process column works on whatever its receive
+buffers hold: the numbers are meaningless, but every local kernel runs with exactly the shapes, leading dimensions and
+offsets it has in the 8-GPU run (local matrix 65536 x 32768 = 17 GB).  Purpose: (1) a fault check of the local kernels
+at shapes the single-GPU path never sees (> 4 GB operands, 64 K-row panels), (2) the compute-only time of a rank, i.e.
+the lower bound that communication is overlapped against.
+
+    python tools/dist_rank_emulation.py --size-n 131072 --grid 2x4 --coords 0,0
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size-n", dest="n", type=int, default=131072)
+    ap.add_argument("--block", type=int, default=1024)
+    ap.add_argument("--grid", default="2x4")
+    ap.add_argument("--coords", default="0,0")
+    ap.add_argument("--no-lookahead", action="store_true")
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    import gpmp_amd.num as gnp
+    from gpmp_amd.dist import BlockCyclicCholesky, HipLocalOps, ProcessGrid
+    from gpmp_amd.kernel import MaternCovariance
+
+    pr, pc = (int(v) for v in a.grid.split("x"))
+    r, c = (int(v) for v in a.coords.split(","))
+    grid = ProcessGrid.__new__(ProcessGrid)
+    grid.world, grid.rank, grid.pr, grid.pc, grid.r, grid.c = pr * pc, r * pc + c, pr, pc, r, c
+    grid.row_groups, grid.col_groups, grid.world_group = [None] * pr, [None] * pc, None
+
+    class Emulated(BlockCyclicCholesky):
+        def _bcast(self, t, src_rank, group, members):      # noqa: D401 -- no communication: shapes only
+            if self.grid.rank != src_rank:
+                self.bytes_received += t.numel() * 8
+            return t
+
+    n, d = a.n, 8
+    rng = np.random.default_rng(1234)
+    x = gnp.asarray(rng.random((n, d)))
+    theta = np.concatenate(([0.0], -np.log(0.5 * (1.0 + np.arange(d) / d))))
+    ch = Emulated(grid, n, nb=a.block, ops=HipLocalOps(), lookahead=not a.no_lookahead)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ch.build_local_gram(MaternCovariance(2), x, theta, 1e-4)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    # factor() ends with a world all-reduce of info: the 1-rank gloo group serves it
+    ch.factor()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    share = (n ** 3 / 3.0) / (pr * pc)
+    print(json.dumps({"tool": "dist_rank_emulation", "n": n, "grid": a.grid, "coords": a.coords, "block": a.block,
+                      "local_shape": [ch.local_rows(), ch.local_cols()], "lookahead": not a.no_lookahead,
+                      "gram_s": t1 - t0, "factor_s": t2 - t1, "rank_share_tflops": share / (t2 - t1) / 1e12,
+                      "frac_of_fp64_mfma_peak": share / (t2 - t1) / 1e12 / 78.6,
+                      "bytes_received_GB": ch.bytes_received / 1e9,
+                      "note": "collectives stubbed: timing and fault check only, values are not a factorisation"}))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
