@@ -24,18 +24,6 @@ struct MaternSpec {
   double s[GPMP_MAX_P + 1];      // (dK/dh)/h = (2c)^2 exp(-t/2) sum_{k>=1} s[k] t^(k-1)   (p >= 1)
 };
 
-struct GramParams {
-  const double* x;
-  const double* y;
-  double* K;
-  long ldk;
-  int n, m, d;
-  int same, lower_only, aligned;
-  int mode;                      // 0: covariance, 1: distance only
-  double sigma2, diag_add;
-  double invrho[GPMP_MAX_DIM];
-  MaternSpec ms;
-};
 
 __device__ __forceinline__ double matern_eval(const MaternSpec& ms, double h) {
   // maternp_kernel, gpmp/kernel/matern.py:54-64 (Horner form of the same polynomial).
@@ -65,59 +53,42 @@ __device__ __forceinline__ double matern_dispatch(const MaternSpec& ms, double h
   }
 }
 
-// ---- fp64 helpers tuned for this kernel (VALU-bound: fp64 exp + sqrt dominate the per-entry cost) ----
-// exp(-x) for x >= 0: k = rint(x log2 e), r = k ln2 - x in [-0.347, 0.347], degree-12 Taylor (remainder
-// 0.347^13 / 13! = 1.7e-16), scale by 2^-k.  < 1 ulp of libm on the tested range; exact 1 at x = 0.
-__device__ __forceinline__ double exp_neg(double x) {
-  const double kf = rint(x * 1.4426950408889634);
-  double r = fma(kf, 6.93147180369123816490e-01, -x);
-  r = fma(kf, 1.90821492927058770002e-10, r);
-  double p = 2.08767569878680989792e-09;            // 1/12!
-  p = fma(p, r, 2.50521083854417187751e-08);        // 1/11!
-  p = fma(p, r, 2.75573192239858906526e-07);
-  p = fma(p, r, 2.75573192239858906526e-06);
-  p = fma(p, r, 2.48015873015873015873e-05);
-  p = fma(p, r, 1.98412698412698412698e-04);
-  p = fma(p, r, 1.38888888888888888889e-03);
-  p = fma(p, r, 8.33333333333333333333e-03);
-  p = fma(p, r, 4.16666666666666666667e-02);
-  p = fma(p, r, 1.66666666666666666667e-01);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  const int k = (kf > 1100.0) ? 1100 : (int)kf;     // exp(-x) underflows to 0 well before
-  return ldexp(p, -k);
-}
-// sqrt(a) for a >= 0 from the hardware 1/sqrt estimate + one coupled Newton step + a residual correction.
-__device__ __forceinline__ double sqrt_pos(double a) {
-  const double y0 = __builtin_amdgcn_rsq(a);
-  double g = a * y0, h = 0.5 * y0;
-  const double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  const double d = fma(-g, g, a);
-  g = fma(d, h, g);
-  return (a > 0.0) ? g : 0.0;    // a == 0: rsq = inf -> NaN above
-}
+// ---- fp64 helpers tuned for this kernel (VALU-bound: every instruction per entry counts) ---------------------------
+// All constants below travel in the kernel-argument struct: they are then loaded once into SGPRs and used as the
+// scalar operand of v_fma_f64.  As C++ literals the compiler re-materialised them into VGPRs next to every use
+// (22 v_mov per entry in the previous version of this kernel: a quarter of its VALU work).
+struct FastExp {
+  double nl2e_half;        // -log2(e) / 2
+  double ln2x2_hi, ln2x2_lo;  // 2 ln 2 split so that k * hi is exact for |k| < 2^20
+  double c[13];            // c[j] = 1 / (2^j j!)  -- exp(r/2) = sum_j c[j] r^j
+  double tiny;             // 1e-280, added to the rsq argument (a no-op for every normal a, keeps a == 0 finite)
+};
 
-template <int P>
-__device__ __forceinline__ double matern_fast(const MaternSpec& ms, double h) {
-  const double t = 2.0 * ms.c * h;
-  double poly;
-  if constexpr (P >= 0) {
-    poly = ms.q[P];
-#pragma unroll
-    for (int k = P - 1; k >= 0; --k) poly = poly * t + ms.q[k];
-  } else {
-    poly = ms.q[ms.p];
-    for (int k = ms.p - 1; k >= 0; --k) poly = poly * t + ms.q[k];
-  }
-  return exp_neg(ms.c * h) * poly;
-}
+// Per entry (inlined in the kernel, four entries in lock step):
+//  * sqrt(a), a >= 0: hardware 1/sqrt estimate of a + tiny (a == 0 then gives 0 without a select; NaN / inf still
+//    propagate through a), one coupled Newton step, one residual correction;
+//  * exp(-t/2), t >= 0: k = rint(t log2(e) / 2), r = 2 k ln2 - t in [-0.694, 0.694], exp(r/2) by a degree-12 Taylor
+//    polynomial in r (remainder 0.347^13 / 13! = 1.7e-16), scaled by 2^-k: < 1 ulp of libm on [0, 745], exact 1 at 0.
+struct GramParams {
+  const double* x;
+  const double* y;
+  double* K;
+  long ldk;
+  int n, m, d;
+  int same, lower_only, aligned;
+  int mode;                      // 0: covariance, 1: distance only
+  int p;
+  double diag_add;
+  double scale[GPMP_MAX_DIM];    // mode 0: 2 c / rho_j (the tile accumulates t^2 = (2 c h)^2); mode 1: 1 / rho_j
+  double q[GPMP_MAX_P + 1];      // sigma^2 q_k:  K(h) = exp(-t/2) sum_k q_k t^k
+  FastExp fe;
+};
 
 // 128 x 64 output tile per 256-thread workgroup, 8 x 4 outputs per thread.
-template <int P>
-__global__ void __launch_bounds__(256) gram_kernel_v2(GramParams p) {
+// Per entry: 2 d VALU instructions of distance + 9 (sqrt) + 19 (exp) + P + 1 (Matern polynomial, sigma^2 folded in).
+// MODE 0: covariance, 1: scaled distance only (gnp.scaled_distance).
+template <int P, int MODE>
+__global__ void __launch_bounds__(256) gram_kernel_v3(GramParams p) {
   __shared__ __attribute__((aligned(16))) double xs[DC][128];
   __shared__ __attribute__((aligned(16))) double ys[DC][GT];
   const int tj = blockIdx.x, ti = blockIdx.y;
@@ -135,15 +106,15 @@ __global__ void __launch_bounds__(256) gram_kernel_v2(GramParams p) {
   for (int k0 = 0; k0 < p.d; k0 += DC) {
     if (k0) __syncthreads();
     const int kc = (p.d - k0) < DC ? (p.d - k0) : DC;
-    // stage 128 rows of x and 64 rows of y (kc dims), scaled by 1/rho; consecutive threads walk k first
+    // stage 128 rows of x and 64 rows of y (kc dims), scaled; consecutive threads walk k first
     // (global reads contiguous along k), LDS stores scatter over rows
     for (int idx = t; idx < 128 * kc; idx += 256) {
       const int r = idx / kc, k = idx - r * kc;
-      xs[k][r] = (row0 + r < p.n) ? p.invrho[k0 + k] * p.x[(long)(row0 + r) * p.d + k0 + k] : 0.0;
+      xs[k][r] = (row0 + r < p.n) ? p.scale[k0 + k] * p.x[(long)(row0 + r) * p.d + k0 + k] : 0.0;
     }
     for (int idx = t; idx < GT * kc; idx += 256) {
       const int r = idx / kc, k = idx - r * kc;
-      ys[k][r] = (col0 + r < p.m) ? p.invrho[k0 + k] * yp[(long)(col0 + r) * p.d + k0 + k] : 0.0;
+      ys[k][r] = (col0 + r < p.m) ? p.scale[k0 + k] * yp[(long)(col0 + r) * p.d + k0 + k] : 0.0;
     }
     __syncthreads();
     for (int k = 0; k < kc; ++k) {
@@ -166,22 +137,72 @@ __global__ void __launch_bounds__(256) gram_kernel_v2(GramParams p) {
   }
 
   const bool full = p.aligned && (row0 + 128 <= p.n) && (col0 + GT <= p.m);
+  // tiles crossed by the diagonal (ii path): only they test row == col
+  const bool diag_tile = p.same && (col0 < row0 + 128) && (col0 + GT > row0);
+  double* __restrict__ out = p.K + (long)(row0 + ty * 8) * p.ldk + col0 + 2 * tx;
+  // leading coefficients of the two Horner chains live in VGPRs (their first fma would otherwise need two SGPR operands
+  // and the compiler copies one of them next to every use)
+  const int pdeg = (P >= 0) ? P : p.p;
+  double qtop = p.q[pdeg], c12 = p.fe.c[12];
+  asm volatile("" : "+v"(qtop), "+v"(c12));
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
+  for (int a = 0; a < 8; ++a, out += p.ldk) {
     const int row = row0 + ty * 8 + a;
     double v[4];
+    // the four entries of a row advance in lock step: every line below is four independent instructions, so one wave
+    // keeps the fp64 pipe fed across the ~26-deep dependent chain of an entry (measured with entry-after-entry code:
+    // 2.5 waves per SIMD resident, each waiting half of the time, VALU 60 % busy)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int col = col0 + (b >> 1) * 32 + 2 * tx + (b & 1);
-      const double h = sqrt_pos(acc[a][b]);
-      double val = h;
-      if (p.mode == 0) {
-        val = p.sigma2 * matern_fast<P>(p.ms, h);
-        if (p.same && row == col) val += p.diag_add;
+    for (int b = 0; b < 4; ++b) v[b] = __builtin_amdgcn_rsq(acc[a][b] + p.fe.tiny);
+    double g[4], h[4], r[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { g[b] = acc[a][b] * v[b]; h[b] = 0.5 * v[b]; }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) r[b] = fma(-h[b], g[b], 0.5);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { g[b] = fma(g[b], r[b], g[b]); h[b] = fma(h[b], r[b], h[b]); }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) r[b] = fma(-g[b], g[b], acc[a][b]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) g[b] = fma(r[b], h[b], g[b]);          // g = t = 2 c h (mode 0) or h (mode 1)
+    if constexpr (MODE == 0) {
+      double nk[4], e[4], poly[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) nk[b] = rint(g[b] * p.fe.nl2e_half);   // -k
+#pragma unroll
+      for (int b = 0; b < 4; ++b) r[b] = fma(-nk[b], p.fe.ln2x2_hi, -g[b]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) r[b] = fma(-nk[b], p.fe.ln2x2_lo, r[b]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { e[b] = c12; poly[b] = qtop; }
+      if constexpr (P >= 0) {
+#pragma unroll
+        for (int k = P - 1; k >= 0; --k)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) poly[b] = fma(poly[b], g[b], p.q[k]);
+      } else {
+        for (int k = pdeg - 1; k >= 0; --k)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) poly[b] = fma(poly[b], g[b], p.q[k]);
       }
-      v[b] = val;
+#pragma unroll
+      for (int j = 11; j >= 0; --j)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) e[b] = fma(e[b], r[b], p.fe.c[j]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int k = (int)nk[b];                                        // saturating v_cvt_i32_f64
+        v[b] = ldexp(e[b], k < -1100 ? -1100 : k) * poly[b];             // exp underflows to 0 well before 2^-1100
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v[b] = g[b];
     }
-    double* out = p.K + (long)row * p.ldk + col0 + 2 * tx;
+    if (diag_tile) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (row == col0 + (b >> 1) * 32 + 2 * tx + (b & 1)) v[b] += p.diag_add;
+    }
     if (full) {
       *reinterpret_cast<d2*>(out) = (d2){v[0], v[1]};
       *reinterpret_cast<d2*>(out + 32) = (d2){v[2], v[3]};
@@ -189,20 +210,36 @@ __global__ void __launch_bounds__(256) gram_kernel_v2(GramParams p) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int cc = (b >> 1) * 32 + 2 * tx + (b & 1);
-        if (col0 + cc < p.m) p.K[(long)row * p.ldk + col0 + cc] = v[b];
+        if (col0 + cc < p.m) out[cc - 2 * tx] = v[b];
       }
     }
   }
 }
 
+static void fill_fast_exp(FastExp& fe) {
+  fe.nl2e_half = -0.5 * 1.4426950408889634;
+  fe.ln2x2_hi = 2.0 * 6.93147180369123816490e-01;
+  fe.ln2x2_lo = 2.0 * 1.90821492927058770002e-10;
+  fe.tiny = 1e-280;
+  double f = 1.0;
+  for (int j = 0; j <= 12; ++j) {
+    if (j) f *= 2.0 * j;         // 2^j j!  (exact in fp64 up to j = 12: 1.96e12)
+    fe.c[j] = 1.0 / f;
+  }
+}
+
 static int launch_gram(const GramParams& gp, hipStream_t st) {
   dim3 grid((gp.m + GT - 1) / GT, (gp.n + 127) / 128);
-  switch (gp.mode == 0 ? gp.ms.p : 0) {
-    case 0: hipLaunchKernelGGL(gram_kernel_v2<0>, grid, dim3(256), 0, st, gp); break;
-    case 1: hipLaunchKernelGGL(gram_kernel_v2<1>, grid, dim3(256), 0, st, gp); break;
-    case 2: hipLaunchKernelGGL(gram_kernel_v2<2>, grid, dim3(256), 0, st, gp); break;
-    case 3: hipLaunchKernelGGL(gram_kernel_v2<3>, grid, dim3(256), 0, st, gp); break;
-    default: hipLaunchKernelGGL(gram_kernel_v2<-1>, grid, dim3(256), 0, st, gp); break;
+  if (gp.mode != 0) {
+    hipLaunchKernelGGL((gram_kernel_v3<0, 1>), grid, dim3(256), 0, st, gp);
+    return 0;
+  }
+  switch (gp.p) {
+    case 0: hipLaunchKernelGGL((gram_kernel_v3<0, 0>), grid, dim3(256), 0, st, gp); break;
+    case 1: hipLaunchKernelGGL((gram_kernel_v3<1, 0>), grid, dim3(256), 0, st, gp); break;
+    case 2: hipLaunchKernelGGL((gram_kernel_v3<2, 0>), grid, dim3(256), 0, st, gp); break;
+    case 3: hipLaunchKernelGGL((gram_kernel_v3<3, 0>), grid, dim3(256), 0, st, gp); break;
+    default: hipLaunchKernelGGL((gram_kernel_v3<-1, 0>), grid, dim3(256), 0, st, gp); break;
   }
   return 0;
 }
@@ -500,11 +537,15 @@ extern "C" int gpmp_matern_gram(const double* x, const double* y, int n, int m, 
   gp.same = (y == nullptr); gp.lower_only = (y == nullptr) ? lower_only : 0;
   gp.aligned = ((reinterpret_cast<uintptr_t>(K) & 15) == 0) && ((ldk & 1) == 0);
   gp.mode = 0;
-  gp.sigma2 = std::exp(theta_host[0]);
+  gp.p = p;
   gp.diag_add = diag_add;
+  MaternSpec ms;
+  fill_matern(ms, p);
+  const double sigma2 = std::exp(theta_host[0]);
   const int off = noise ? 2 : 1;
-  for (int k = 0; k < d; ++k) gp.invrho[k] = std::exp(theta_host[off + k]);
-  fill_matern(gp.ms, p);
+  for (int k = 0; k < d; ++k) gp.scale[k] = 2.0 * ms.c * std::exp(theta_host[off + k]);
+  for (int k = 0; k <= GPMP_MAX_P; ++k) gp.q[k] = sigma2 * ms.q[k];
+  fill_fast_exp(gp.fe);
   {
     // work = algorithmic bytes written (8 per entry; lower_only writes about half)
     ProfScope ps(PK_GRAM, as_stream(stream), 8.0 * (double)n * (double)m * (gp.lower_only ? 0.5 : 1.0));
@@ -526,9 +567,10 @@ extern "C" int gpmp_scaled_distance(const double* x, const double* y, int n, int
   gp.n = n; gp.m = m; gp.d = d;
   gp.same = 0; gp.lower_only = 0;
   gp.aligned = ((reinterpret_cast<uintptr_t>(D) & 15) == 0) && ((ldd & 1) == 0);
-  gp.mode = 1; gp.sigma2 = 1.0; gp.diag_add = 0.0;
-  for (int k = 0; k < d; ++k) gp.invrho[k] = std::exp(loginvrho_host[k]);
-  fill_matern(gp.ms, 0);
+  gp.mode = 1; gp.p = 0; gp.diag_add = 0.0;
+  for (int k = 0; k < d; ++k) gp.scale[k] = std::exp(loginvrho_host[k]);
+  for (int k = 0; k <= GPMP_MAX_P; ++k) gp.q[k] = 0.0;
+  fill_fast_exp(gp.fe);
   launch_gram(gp, as_stream(stream));
   GPMP_HIP_TRY(hipGetLastError());
   return 0;

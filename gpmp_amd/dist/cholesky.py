@@ -439,6 +439,7 @@ class BlockCyclicCholesky:
         g, ops, nb = self.grid, self.ops, self.nb
         dev = "cuda" if self.backend == "nccl" else "cpu"
         w = torch.as_tensor(np.asarray(z, dtype=np.float64)).to(dev).clone()
+        gri = torch.as_tensor(self.global_row_index(), dtype=torch.int64, device=dev)    # global row of every local row
         for k in range(self.nblocks):
             rd, cd = g.owner_row(k), g.owner_col(k)
             bk = self.bs(k)
@@ -446,7 +447,7 @@ class BlockCyclicCholesky:
             wk = w[k0:k0 + bk].clone()
             if g.r == rd and g.c == cd:
                 Lkk, dinv = self.diag_cache[k]
-                wk = ops.solve_lower_vec(Lkk, dinv, ops.asarray(w[k0:k0 + bk]) if hasattr(ops, "asarray") else w[k0:k0 + bk]).to(dev)
+                wk = ops.solve_lower_vec(Lkk, dinv, ops.asarray(w[k0:k0 + bk])).to(dev)
             wk = wk.contiguous()
             dist.broadcast(wk, src=g.rank_of(rd, cd), group=g.world_group)
             w[k0:k0 + bk] = wk
@@ -455,15 +456,12 @@ class BlockCyclicCholesky:
                 continue
             delta = torch.zeros(rest, dtype=torch.float64, device=dev)
             if g.c == cd:
-                i0 = next((i for i, I in enumerate(self.row_blocks) if I > k), len(self.row_blocks))
+                i0 = self._first_row_after(k)
                 if i0 < len(self.row_blocks):
-                    lj = self.col_blocks.index(k)
+                    lj = k // g.pc
                     P = self.A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]]
                     upd = ops.matvec(P, ops.asarray(wk)).to(dev)
-                    for li in range(i0, len(self.row_blocks)):
-                        I = self.row_blocks[li]
-                        a, b = self.roff[li] - self.roff[i0], self.roff[li + 1] - self.roff[i0]
-                        delta[I * nb - (k0 + bk): I * nb - (k0 + bk) + (b - a)] = upd[a:b]
+                    delta[gri[self.roff[i0]:] - (k0 + bk)] = upd
             dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=g.world_group)
             w[k0 + bk:] -= delta
         return w
