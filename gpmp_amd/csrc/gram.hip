@@ -5,9 +5,10 @@
 // (gpmp/kernel/matern.py:54-64) and the dense "+ nugget * eye(n)" (matern.py:94).  The distance
 // matrix is never stored: algorithmic HBM traffic is the 8 n m bytes of K written.
 //
-// Tiling: 64 x 64 output tile per 256-thread workgroup, 4 x 4 outputs per thread.  The x / y row
-// blocks are pre-scaled by 1/rho while staged into LDS ([k][64] images, 16 dimensions per chunk);
-// each lane then writes 4 x 32 contiguous bytes per row (coalesced 512 B per 16 lanes).
+// Tiling (gram_kernel_v3): 128 x 64 output tile per 256-thread workgroup, 8 x 4 outputs per thread.  The x / y
+// row blocks are pre-scaled (2c / rho for the covariance, 1 / rho for the plain distance) while staged into LDS
+// ([k][128] and [k][64] images, 16 dimensions per chunk); each thread owns column pairs, so every store is 16 bytes
+// and the 16 lanes of a row write 256 contiguous bytes.  The gradient-trace pass keeps 64 x 64 tiles (GT).
 #include "common.h"
 #include <cmath>
 
