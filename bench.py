@@ -111,7 +111,7 @@ def dist_potrf_extra(world, rank, res):
 
     for transport in ("bcast", "p2p"):
         for rep in ("warm", "timed"):
-            ch = BlockCyclicCholesky(grid, n, nb=nb, transport=transport)
+            ch = BlockCyclicCholesky(grid, n, nb=nb, transport=transport, profile=(rep == "timed"))
             torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
             t0 = time.perf_counter()
             ch.build_local_gram(MaternCovariance(2), xd, theta, 1e-4)
@@ -126,6 +126,9 @@ def dist_potrf_extra(world, rank, res):
                      "frac_of_aggregate_fp64_mfma_peak": (n ** 3 / 3.0) / potrf_s / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
                      "GB_received_per_gpu_max": tmax(ch.bytes_received / 1e9)}
             if rep == "timed":
+                # summed HIP-event spans per phase on rank 0: side stream = diag / trsm / row_bcast / col_exchange /
+                # lookahead_update (the panel chain and every collective), caller's stream = update
+                entry["phases_ms_rank0"] = {k_: round(v_, 2) for k_, v_ in ch.phase_times().items()}
                 t3 = time.perf_counter()
                 entry["nll"] = ch.negative_log_likelihood(z)
                 torch.cuda.synchronize()

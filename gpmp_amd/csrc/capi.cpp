@@ -1,6 +1,7 @@
 // Error plumbing and ABI version of libgpmp_hip.so.
 #include "common.h"
 #include <cstdarg>
+#include <cstdint>
 #include <vector>
 #include <cstdlib>
 
@@ -75,6 +76,27 @@ extern "C" int gpmp_profile_end(double* table_host) {
   if (dump) fclose(dump);
   for (auto& r : gpmp::g_recs) { gpmp::g_pool.push_back(r.a); gpmp::g_pool.push_back(r.b); }
   gpmp::g_recs.clear();
+  return 0;
+}
+
+// Stream whose kernels may use every CU except `reserve_cus` of them (spread over the XCDs: the driver deals the bits of
+// a CU mask round-robin over XCDs and shader engines, so clearing the lowest bits takes one CU per XCD first).
+extern "C" int gpmp_stream_create_reserving_cus(int reserve_cus, gpmp_stream_t* stream_out) {
+  GPMP_ARG(stream_out != nullptr, 2, "stream_out is NULL");
+  int dev = 0, ncu = 0;
+  GPMP_HIP_TRY(hipGetDevice(&dev));
+  GPMP_HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  GPMP_ARG(reserve_cus >= 0 && reserve_cus < ncu, 1, "reserve_cus outside [0, number of CUs)");
+  const int words = (ncu + 31) / 32;
+  std::vector<uint32_t> mask(words, 0u);
+  for (int i = reserve_cus; i < ncu; ++i) mask[i / 32] |= (1u << (i % 32));
+  hipStream_t st = nullptr;
+  GPMP_HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()));
+  *stream_out = (gpmp_stream_t)st;
+  return 0;
+}
+extern "C" int gpmp_stream_destroy(gpmp_stream_t stream) {
+  if (stream != nullptr) GPMP_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
   return 0;
 }
 

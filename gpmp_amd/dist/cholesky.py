@@ -124,14 +124,40 @@ def _comm_tensor(t: torch.Tensor, backend: str) -> torch.Tensor:
 
 
 class _Streams:
-    """The caller's stream ("main": bulk trailing updates) and one high-priority side stream (the panel chain and every
-    collective).  With CPU local ops (tests) both degenerate to program order."""
+    """The stream of the bulk trailing updates ("main") and one high-priority side stream (the panel chain and every
+    collective).  With ``reserve_cus`` > 0 the bulk updates run on a CU-masked stream of their own, fenced against the
+    caller's stream at both ends, so that the small kernels of the panel chain always find a free CU.  With CPU local
+    ops (tests) everything degenerates to program order."""
 
-    def __init__(self, device):
+    def __init__(self, device, reserve_cus: int = 0, lib=None):
         self.on = device is not None and torch.device(device).type == "cuda"
+        self.caller = None
+        self._masked = None
         if self.on:
-            self.main = torch.cuda.current_stream(device)
+            self.caller = self.main = torch.cuda.current_stream(device)
             self.side = torch.cuda.Stream(device=device, priority=-1)
+            if reserve_cus > 0 and lib is not None:
+                import ctypes
+
+                h = ctypes.c_void_p()
+                rc = lib.gpmp_stream_create_reserving_cus(int(reserve_cus), ctypes.byref(h))
+                if rc != 0:
+                    raise RuntimeError(f"gpmp_stream_create_reserving_cus failed ({rc})")
+                self._masked, self._lib = h, lib
+                self.main = torch.cuda.ExternalStream(h.value, device=device)
+                self.main.wait_stream(self.caller)
+
+    def main_ctx(self):
+        return torch.cuda.stream(self.main) if self.on else contextlib.nullcontext()
+
+    def close(self):
+        """Join the masked stream into the caller's stream and release it."""
+        if self._masked is not None:
+            self.caller.wait_stream(self.main)
+            self.main.synchronize()          # the stream object goes away: nothing of ours may still be queued on it
+            self._lib.gpmp_stream_destroy(self._masked)
+            self._masked = None
+            self.main = self.caller
 
     def side_ctx(self):
         return torch.cuda.stream(self.side) if self.on else contextlib.nullcontext()
@@ -147,6 +173,14 @@ class _Streams:
         if self.on and ev is not None:
             (self.side if side else self.main).wait_event(ev)
 
+    def stamp(self):
+        """Timing event on the CURRENT stream (None off-GPU)."""
+        if not self.on:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
 
 class BlockCyclicCholesky:
     """K = L L^T with K 2-D block-cyclic over ``grid``; keeps the local factor for NLL evaluations.
@@ -155,10 +189,15 @@ class BlockCyclicCholesky:
     grouped send/recv batch: xGMI is point-to-point, so the copies leave the root over separate links instead of
     following a ring).  Default from GPMP_DIST_TRANSPORT, else "bcast".
     ``lookahead``: prepare panel k+1 (column update, diagonal factor, panel solve, all broadcasts) on a side stream
-    while the bulk of update k runs on the caller's stream."""
+    while the bulk of update k runs on the caller's stream.
+    ``profile``: bracket the phases of every step with HIP events (no synchronisation); ``phase_times()`` then returns
+    the summed milliseconds per phase on this rank -- diag (factor + column broadcast), trsm, row_bcast, col_exchange
+    and lookahead_update on the side stream, update on the caller's stream.
+    ``reserve_cus``: run the bulk updates on a stream that leaves this many CUs (one per XCD first) to the panel chain
+    (default GPMP_DIST_RESERVE_CUS, else 0)."""
 
     def __init__(self, grid: ProcessGrid, n: int, nb: int = 1024, ops=None, transport: Optional[str] = None,
-                 lookahead: bool = True):
+                 lookahead: bool = True, profile: bool = False, reserve_cus: Optional[int] = None):
         if nb % 128 != 0:
             raise ValueError("block size must be a multiple of 128 (the GEMM tile)")
         self.grid, self.n, self.nb = grid, n, nb
@@ -168,6 +207,10 @@ class BlockCyclicCholesky:
         if self.transport not in ("bcast", "p2p"):
             raise ValueError("transport must be 'bcast' or 'p2p'")
         self.lookahead = lookahead
+        self.reserve_cus = int(os.environ.get("GPMP_DIST_RESERVE_CUS", "0")) if reserve_cus is None else int(reserve_cus)
+        self.profile = profile       # record per-phase HIP events in factor(); read them with phase_times()
+        self._marks = []             # (phase, start event, end event)
+        self._st = None
         self.nblocks = (n + nb - 1) // nb
         self.row_blocks = grid.local_row_blocks(self.nblocks)
         self.col_blocks = grid.local_col_blocks(self.nblocks)
@@ -255,6 +298,26 @@ class BlockCyclicCholesky:
         return t
 
     # ---- factorisation
+    @contextlib.contextmanager
+    def _phase(self, name: str):
+        """Bracket a phase with timing events on the current stream when profiling."""
+        if not (self.profile and self._st is not None and self._st.on):
+            yield
+            return
+        a = self._st.stamp()
+        yield
+        self._marks.append((name, a, self._st.stamp()))
+
+    def phase_times(self):
+        """Summed milliseconds per phase of the last factor() on this rank (synchronises)."""
+        if not self._marks:
+            return {}
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self._marks:
+            out[name] = out.get(name, 0.0) + a.elapsed_time(b)
+        return out
+
     def _flat(self, size: int) -> torch.Tensor:
         return self.ops.empty(1, size).reshape(-1)
 
@@ -276,68 +339,78 @@ class BlockCyclicCholesky:
         #      process column in ONE message
         Lkk = dinv = None
         if in_col:
-            ldk = (bk + 15) // 16 * 16
-            ndinv = ((bk + 127) // 128) * 128 * 128
-            dbuf = self._flat(bk * ldk + ndinv + 1)
-            Lkk = dbuf[: bk * ldk].view(bk, ldk)[:, :bk]
-            dinv = dbuf[bk * ldk: bk * ldk + ndinv]
-            inf = dbuf[bk * ldk + ndinv:]
-            if g.r == rd:
-                li, lj = k // g.pr, k // g.pc
-                D = A[self.roff[li]:self.roff[li + 1], self.coff[lj]:self.coff[lj + 1]]
-                dv, info = ops.potrf(D)
-                dinv.copy_(dv[:ndinv])
-                Lkk.copy_(D)
-                inf.copy_(info.to(torch.float64))
-            if g.pr > 1:
-                self._bcast(dbuf, g.rank_of(rd, cd), g.col_group, col_members)
-            self._info_acc[k: k + 1].copy_(inf)
-            self.diag_cache[k] = (Lkk, dinv)
+            with self._phase("diag"):
+                Lkk, dinv = self._diagonal_block(k, rd, cd, bk, col_members)
 
         # 3. panel solve on the owning process column, 4. broadcast along the process row
         panel = self._panel_buf[k % 2][:Mr, :bk]
         if in_col and Mr > 0:
             lj = k // g.pc
             P = A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]]
-            ops.trsm_right(Lkk, dinv, P)
-            panel.copy_(P)
+            with self._phase("trsm"):
+                ops.trsm_right(Lkk, dinv, P)
+                panel.copy_(P)
         if g.pc > 1 and Mr > 0:
-            self._bcast(panel, g.rank_of(g.r, cd), g.row_group, row_members)
+            with self._phase("row_bcast"):
+                self._bcast(panel, g.rank_of(g.r, cd), g.row_group, row_members)
 
         # 5. column operand: blocks J > k with J mod Pc == c, exchanged inside the process column (the holder of
         #    block row J is process row J mod Pr)
         colop = self._colop_buf[k % 2][:Nc, :bk]
         if Nc > 0:
-            my_cols = self.col_blocks[j0:]
-            for rp in range(g.pr):
-                blocks = [J for J in my_cols if J % g.pr == rp]
-                if not blocks:
-                    continue
-                if g.pr == 1:
-                    piece = None
-                else:
-                    rows = sum(self.bs(J) for J in blocks)
-                    piece = self._piece_buf[:rows, :bk]
-                if g.r == rp:
+            with self._phase("col_exchange"):
+                self._column_exchange(k, panel, colop, i0, j0, bk, col_members)
+        return panel, colop
+
+    def _diagonal_block(self, k, rd, cd, bk, col_members):
+        g, ops, A = self.grid, self.ops, self.A
+        ldk = (bk + 15) // 16 * 16
+        ndinv = ((bk + 127) // 128) * 128 * 128
+        dbuf = self._flat(bk * ldk + ndinv + 1)
+        Lkk = dbuf[: bk * ldk].view(bk, ldk)[:, :bk]
+        dinv = dbuf[bk * ldk: bk * ldk + ndinv]
+        inf = dbuf[bk * ldk + ndinv:]
+        if g.r == rd:
+            li, lj = k // g.pr, k // g.pc
+            D = A[self.roff[li]:self.roff[li + 1], self.coff[lj]:self.coff[lj + 1]]
+            dv, info = ops.potrf(D)
+            dinv.copy_(dv[:ndinv])
+            Lkk.copy_(D)
+            inf.copy_(info.to(torch.float64))
+        if g.pr > 1:
+            self._bcast(dbuf, g.rank_of(rd, cd), g.col_group, col_members)
+        self._info_acc[k: k + 1].copy_(inf)
+        self.diag_cache[k] = (Lkk, dinv)
+        return Lkk, dinv
+
+    def _column_exchange(self, k, panel, colop, i0, j0, bk, col_members):
+        g = self.grid
+        my_cols = self.col_blocks[j0:]
+        for rp in range(g.pr):
+            blocks = [J for J in my_cols if J % g.pr == rp]
+            if not blocks:
+                continue
+            piece = None
+            if g.pr > 1:
+                rows = sum(self.bs(J) for J in blocks)
+                piece = self._piece_buf[:rows, :bk]
+            if g.r == rp:
+                off = 0
+                for J in blocks:
+                    li, lj = J // g.pr, J // g.pc
+                    src_rows = panel[self.roff[li] - self.roff[i0]: self.roff[li + 1] - self.roff[i0]]
+                    colop[self.coff[lj] - self.coff[j0]: self.coff[lj + 1] - self.coff[j0]].copy_(src_rows)
+                    if piece is not None:
+                        piece[off:off + self.bs(J)].copy_(src_rows)
+                    off += self.bs(J)
+            if piece is not None:
+                self._bcast(piece, g.rank_of(rp, g.c), g.col_group, col_members)
+                if g.r != rp:
                     off = 0
                     for J in blocks:
-                        li = J // g.pr
-                        src_rows = panel[self.roff[li] - self.roff[i0]: self.roff[li + 1] - self.roff[i0]]
                         lj = J // g.pc
-                        dst = colop[self.coff[lj] - self.coff[j0]: self.coff[lj + 1] - self.coff[j0]]
-                        dst.copy_(src_rows)
-                        if piece is not None:
-                            piece[off:off + self.bs(J)].copy_(src_rows)
+                        colop[self.coff[lj] - self.coff[j0]: self.coff[lj + 1] - self.coff[j0]].copy_(piece[off:off + self.bs(J)])
                         off += self.bs(J)
-                if piece is not None:
-                    self._bcast(piece, g.rank_of(rp, g.c), g.col_group, col_members)
-                    if g.r != rp:
-                        off = 0
-                        for J in blocks:
-                            lj = J // g.pc
-                            colop[self.coff[lj] - self.coff[j0]: self.coff[lj + 1] - self.coff[j0]].copy_(piece[off:off + self.bs(J)])
-                            off += self.bs(J)
-        return panel, colop
 
     def _update(self, k: int, panel, colop, jlo: int, jhi: int):
         """6. A_IJ -= L_Ik L_Jk^T for the local blocks I >= J with local column index in [jlo, jhi): a staircase of GEMMs
@@ -367,13 +440,15 @@ class BlockCyclicCholesky:
         final read of the ``info`` words."""
         g, ops, nb = self.grid, self.ops, self.nb
         nblk, ncb = self.nblocks, len(self.col_blocks)
-        st = _Streams(getattr(ops, "device", None))
+        self._marks = []
         self._panel_buf = [ops.empty(self.local_rows(), nb) for _ in range(2)]
         self._colop_buf = [ops.empty(self.local_cols(), nb) for _ in range(2)]
         self._piece_buf = ops.empty(self.local_cols(), nb) if g.pr > 1 else None
         self._info_acc = self._flat(nblk)
         self._info_acc.zero_()
         self.diag_cache = {}
+        # (created after the buffers above were queued on the caller's stream: a masked update stream starts behind them)
+        st = self._st = _Streams(getattr(ops, "device", None), self.reserve_cus if self.lookahead else 0, getattr(ops, "lib", None))
         ev_main_prev = None
         start = st.record(False)
         with st.side_ctx():
@@ -391,15 +466,18 @@ class BlockCyclicCholesky:
                         jrest = jnext + 1
                     with st.side_ctx():
                         st.wait(True, ev_main_prev)       # update k-1 has finished with column k+1 and with the buffers
-                        self._update(k, panel, colop, jnext, jrest)
+                        with self._phase("lookahead_update"):
+                            self._update(k, panel, colop, jnext, jrest)
                         nbufs = self._prepare_panel(k + 1)
                         ev_side_next = st.record(True)
                     st.wait(False, ev_side)
-                    self._update(k, panel, colop, jrest, ncb)
+                    with st.main_ctx(), self._phase("update"):
+                        self._update(k, panel, colop, jrest, ncb)
                     ev_main_prev = st.record(False)
                 else:
                     st.wait(False, ev_side)
-                    self._update(k, panel, colop, jrest, ncb)
+                    with st.main_ctx(), self._phase("update"):
+                        self._update(k, panel, colop, jrest, ncb)
                     ev_main_prev = st.record(False)
                     with st.side_ctx():
                         st.wait(True, ev_main_prev)
@@ -407,6 +485,7 @@ class BlockCyclicCholesky:
                         ev_side_next = st.record(True)
                 bufs, ev_side = nbufs, ev_side_next
         st.wait(False, ev_side)
+        st.close()
         self._panel_buf = self._colop_buf = self._piece_buf = None
         # agree on info: the first failing block column wins
         mine = math.inf

@@ -53,6 +53,13 @@ int gpmp_profile_begin(void);
 int gpmp_profile_begin_kinds(unsigned kinds);
 int gpmp_profile_end(double* table_host);
 
+/* A stream whose kernels run on every CU except `reserve_cus` of them (taken one per XCD first).  The distributed
+ * Cholesky (gpmp_amd/dist) runs its bulk trailing updates on such a stream so that the latency-bound panel chain on its
+ * high-priority stream always finds a free CU instead of queueing behind 218-us MFMA workgroups.  The caller owns the
+ * stream (gpmp_stream_destroy).  No counterpart in the reference (it has no device code). */
+int gpmp_stream_create_reserving_cus(int reserve_cus, gpmp_stream_t* stream_out);
+int gpmp_stream_destroy(gpmp_stream_t stream);
+
 /* ---- Matern kernels ------------------------------------------------------------------------ */
 
 /* K[i,j] = sigma2 * Matern_p( || invrho * (x_i - y_j) || )  (+ diag_add on i == j when y == NULL).

@@ -53,13 +53,16 @@ def main():
     xd = gnp.asarray(x)
     torch.cuda.synchronize(); dist.barrier()
     t0 = time.perf_counter()
-    ch = BlockCyclicCholesky(grid, n, nb=a.block, ops=HipLocalOps(), transport=a.transport, lookahead=not a.no_lookahead)
+    ch = BlockCyclicCholesky(grid, n, nb=a.block, ops=HipLocalOps(), transport=a.transport, lookahead=not a.no_lookahead, profile=True)
     ch.build_local_gram(cov, xd, theta, nugget)
     torch.cuda.synchronize(); dist.barrier()
     t1 = time.perf_counter()
     info = ch.factor()
     torch.cuda.synchronize(); dist.barrier()
     t2 = time.perf_counter()
+    phases = ch.phase_times()
+    torch.cuda.synchronize(); dist.barrier()
+    t2b = time.perf_counter()
     nll = ch.negative_log_likelihood(z)
     torch.cuda.synchronize(); dist.barrier()
     t3 = time.perf_counter()
@@ -67,7 +70,7 @@ def main():
     dist.all_reduce(recv, op=dist.ReduceOp.MAX)
     if rank == 0:
         line = {"metric": "distributed NLL (2-D block-cyclic Cholesky)", "n": n, "d": d, "grid": f"{pr}x{pc}", "block": a.block,
-                "n_gpus": world, "transport": ch.transport, "lookahead": ch.lookahead, "info": info, "nll": nll, "gram_s": t1 - t0, "potrf_s": t2 - t1, "nll_solve_s": t3 - t2,
+                "n_gpus": world, "transport": ch.transport, "lookahead": ch.lookahead, "info": info, "nll": nll, "gram_s": t1 - t0, "potrf_s": t2 - t1, "nll_solve_s": t3 - t2b, "phases_ms_rank0": {k: round(v, 2) for k, v in phases.items()},
                 "potrf_tflops_aggregate": (n ** 3 / 3.0) / (t2 - t1) / 1e12,
                 "frac_of_aggregate_fp64_mfma_peak": (n ** 3 / 3.0) / (t2 - t1) / 1e12 / (78.6 * world),
                 "max_bytes_received_per_gpu": float(recv.item())}

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--grid", default="2x4")
     ap.add_argument("--coords", default="0,0")
     ap.add_argument("--no-lookahead", action="store_true")
+    ap.add_argument("--reserve-cus", type=int, default=None)
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -54,7 +55,7 @@ def main():
     rng = np.random.default_rng(1234)
     x = gnp.asarray(rng.random((n, d)))
     theta = np.concatenate(([0.0], -np.log(0.5 * (1.0 + np.arange(d) / d))))
-    ch = Emulated(grid, n, nb=a.block, ops=HipLocalOps(), lookahead=not a.no_lookahead)
+    ch = Emulated(grid, n, nb=a.block, ops=HipLocalOps(), lookahead=not a.no_lookahead, profile=True, reserve_cus=a.reserve_cus)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ch.build_local_gram(MaternCovariance(2), x, theta, 1e-4)
@@ -66,10 +67,11 @@ def main():
     t2 = time.perf_counter()
     share = (n ** 3 / 3.0) / (pr * pc)
     print(json.dumps({"tool": "dist_rank_emulation", "n": n, "grid": a.grid, "coords": a.coords, "block": a.block,
-                      "local_shape": [ch.local_rows(), ch.local_cols()], "lookahead": not a.no_lookahead,
+                      "local_shape": [ch.local_rows(), ch.local_cols()], "lookahead": not a.no_lookahead, "reserve_cus": ch.reserve_cus,
                       "gram_s": t1 - t0, "factor_s": t2 - t1, "rank_share_tflops": share / (t2 - t1) / 1e12,
                       "frac_of_fp64_mfma_peak": share / (t2 - t1) / 1e12 / 78.6,
                       "bytes_received_GB": ch.bytes_received / 1e9,
+                      "phases_ms": {k: round(v, 2) for k, v in ch.phase_times().items()},
                       "note": "collectives stubbed: timing and fault check only, values are not a factorisation"}))
     dist.destroy_process_group()
 
