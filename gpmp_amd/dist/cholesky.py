@@ -136,6 +136,7 @@ class _Streams:
         if self.on:
             self.caller = self.main = torch.cuda.current_stream(device)
             self.side = torch.cuda.Stream(device=device, priority=-1)
+            self.diag = torch.cuda.Stream(device=device, priority=-1)
             if reserve_cus > 0 and lib is not None:
                 import ctypes
 
@@ -158,6 +159,20 @@ class _Streams:
             self._lib.gpmp_stream_destroy(self._masked)
             self._masked = None
             self.main = self.caller
+
+    def diag_ctx(self):
+        return torch.cuda.stream(self.diag) if self.on else contextlib.nullcontext()
+
+    def wait_diag(self, ev):
+        if self.on and ev is not None:
+            self.diag.wait_event(ev)
+
+    def record_diag(self):
+        if not self.on:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.diag)
+        return ev
 
     def side_ctx(self):
         return torch.cuda.stream(self.side) if self.on else contextlib.nullcontext()
@@ -321,8 +336,9 @@ class BlockCyclicCholesky:
     def _flat(self, size: int) -> torch.Tensor:
         return self.ops.empty(1, size).reshape(-1)
 
-    def _prepare_panel(self, k: int):
-        """Steps 1-5 of block column k: diagonal factor, panel solve, row broadcast, column exchange.
+    def _prepare_panel(self, k: int, diag=None):
+        """Steps 1-5 of block column k: diagonal factor (unless ``diag`` = (L_kk, dinv) was prepared ahead on the
+        diagonal stream), panel solve, row broadcast, column exchange.
         Returns (panel, colop): the rows L_Ik of this process row (I > k) and the rows L_Jk for the owned block columns
         J > k.  Runs on the current stream; no host synchronisation."""
         g, ops, A = self.grid, self.ops, self.A
@@ -338,7 +354,9 @@ class BlockCyclicCholesky:
         # 1-2. diagonal block: factor on the owner; (L_kk | inverses of its 128-blocks | info) travel down the
         #      process column in ONE message
         Lkk = dinv = None
-        if in_col:
+        if in_col and diag is not None:
+            Lkk, dinv = diag
+        elif in_col:
             with self._phase("diag"):
                 Lkk, dinv = self._diagonal_block(k, rd, cd, bk, col_members)
 
@@ -361,6 +379,25 @@ class BlockCyclicCholesky:
             with self._phase("col_exchange"):
                 self._column_exchange(k, panel, colop, i0, j0, bk, col_members)
         return panel, colop
+
+    def _diagonal_ahead(self, k: int, panel, colop):
+        """Critical path first: on the ranks of the process column that owns block column k+1, apply update k to the ONE
+        diagonal block (k+1, k+1), factor it and send it down the column -- on the diagonal stream, while the side stream
+        is still updating the rest of that block column.  Returns (L, dinv) of block k+1, or None on other ranks."""
+        g, ops, A = self.grid, self.ops, self.A
+        j = k + 1
+        rd, cd = g.owner_row(j), g.owner_col(j)
+        if g.c != cd:
+            return None
+        with self._phase("diag"):
+            if g.r == rd:
+                i0, j0 = self._first_row_after(k), self._first_col_after(k)
+                li, lj = j // g.pr, j // g.pc
+                D = A[self.roff[li]:self.roff[li + 1], self.coff[lj]:self.coff[lj + 1]]
+                Ai = panel[self.roff[li] - self.roff[i0]: self.roff[li + 1] - self.roff[i0]]
+                Bj = colop[self.coff[lj] - self.coff[j0]: self.coff[lj + 1] - self.coff[j0]]
+                ops.gemm_nt_sub(D, Ai, Bj)
+            return self._diagonal_block(j, rd, cd, self.bs(j), [g.rank_of(rr, g.c) for rr in range(g.pr)])
 
     def _diagonal_block(self, k, rd, cd, bk, col_members):
         g, ops, A = self.grid, self.ops, self.A
@@ -412,7 +449,7 @@ class BlockCyclicCholesky:
                         colop[self.coff[lj] - self.coff[j0]: self.coff[lj + 1] - self.coff[j0]].copy_(piece[off:off + self.bs(J)])
                         off += self.bs(J)
 
-    def _update(self, k: int, panel, colop, jlo: int, jhi: int):
+    def _update(self, k: int, panel, colop, jlo: int, jhi: int, rows_after: Optional[int] = None):
         """6. A_IJ -= L_Ik L_Jk^T for the local blocks I >= J with local column index in [jlo, jhi): a staircase of GEMMs
         over groups of up to 4 local block rows (the few blocks above the diagonal that a group also touches are never
         read afterwards)."""
@@ -422,7 +459,8 @@ class BlockCyclicCholesky:
         i0, j0 = self._first_row_after(k), self._first_col_after(k)
         nrb = len(self.row_blocks)
         G = 4
-        for lg in range(i0, nrb, G):
+        first = i0 if rows_after is None else self._first_row_after(rows_after)   # skip block rows <= rows_after
+        for lg in range(first, nrb, G):
             le = min(lg + G, nrb)
             I_last = self.row_blocks[le - 1]
             jend = min(bisect.bisect_right(self.col_blocks, I_last), jhi)     # local columns J <= I_last
@@ -464,11 +502,18 @@ class BlockCyclicCholesky:
                     if g.c == g.owner_col(k + 1):
                         jnext = (k + 1) // g.pc          # local index of block column k + 1
                         jrest = jnext + 1
+                    with st.diag_ctx():                   # critical path first: the next diagonal block
+                        st.wait_diag(ev_main_prev)
+                        st.wait_diag(ev_side)
+                        dnext = self._diagonal_ahead(k, panel, colop)
+                        ev_diag = st.record_diag()
                     with st.side_ctx():
                         st.wait(True, ev_main_prev)       # update k-1 has finished with column k+1 and with the buffers
                         with self._phase("lookahead_update"):
-                            self._update(k, panel, colop, jnext, jrest)
-                        nbufs = self._prepare_panel(k + 1)
+                            # (the diagonal block (k+1, k+1) has been updated on the diagonal stream)
+                            self._update(k, panel, colop, jnext, jrest, rows_after=k + 1 if dnext is not None and g.r == g.owner_row(k + 1) else None)
+                        st.wait(True, ev_diag)
+                        nbufs = self._prepare_panel(k + 1, diag=dnext)
                         ev_side_next = st.record(True)
                     st.wait(False, ev_side)
                     with st.main_ctx(), self._phase("update"):
