@@ -420,34 +420,44 @@ class BlockCyclicCholesky:
         self.diag_cache[k] = (Lkk, dinv)
         return Lkk, dinv
 
-    def _column_exchange(self, k, panel, colop, i0, j0, bk, col_members):
-        g = self.grid
-        my_cols = self.col_blocks[j0:]
+    def _exchange_maps(self, device):
+        """Static index maps of the column exchange, built once per factorisation: for every process row rp, the local
+        row index (in this rank's row space) and the local column-space index of every row of the blocks J with
+        J mod Pc == c and J mod Pr == rp, ordered by J -- a step uses the suffix J > k."""
+        g, nb = self.grid, self.nb
+        maps = []
         for rp in range(g.pr):
-            blocks = [J for J in my_cols if J % g.pr == rp]
-            if not blocks:
+            blocks = [J for J in self.col_blocks if J % g.pr == rp]
+            src = [np.arange(self.roff[J // g.pr], self.roff[J // g.pr] + self.bs(J)) for J in blocks] if g.r == rp else []
+            dst = [np.arange(self.coff[J // g.pc], self.coff[J // g.pc] + self.bs(J)) for J in blocks]
+            cat = lambda parts: torch.as_tensor(np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64), dtype=torch.int64, device=device)  # noqa: E731
+            maps.append((blocks, cat(src), cat(dst)))
+        return maps
+
+    def _column_exchange(self, k, panel, colop, i0, j0, bk, col_members):
+        """colop rows of block J (J > k, J mod Pc == c) = panel rows of block J held by process row J mod Pr: one gather on
+        the holder, one broadcast inside the process column, one scatter on the receivers per process row."""
+        g, nb = self.grid, self.nb
+        for rp, (blocks, src_idx, dst_idx) in enumerate(self._xmaps):
+            first = bisect.bisect_right(blocks, k)            # blocks[first:] are the J > k
+            if first >= len(blocks):
                 continue
-            piece = None
-            if g.pr > 1:
-                rows = sum(self.bs(J) for J in blocks)
-                piece = self._piece_buf[:rows, :bk]
+            off = first * nb                                   # only the globally last block can be short
+            dst = dst_idx[off:] - self.coff[j0]
+            rows = int(dst.shape[0])
             if g.r == rp:
-                off = 0
-                for J in blocks:
-                    li, lj = J // g.pr, J // g.pc
-                    src_rows = panel[self.roff[li] - self.roff[i0]: self.roff[li + 1] - self.roff[i0]]
-                    colop[self.coff[lj] - self.coff[j0]: self.coff[lj + 1] - self.coff[j0]].copy_(src_rows)
-                    if piece is not None:
-                        piece[off:off + self.bs(J)].copy_(src_rows)
-                    off += self.bs(J)
-            if piece is not None:
-                self._bcast(piece, g.rank_of(rp, g.c), g.col_group, col_members)
-                if g.r != rp:
-                    off = 0
-                    for J in blocks:
-                        lj = J // g.pc
-                        colop[self.coff[lj] - self.coff[j0]: self.coff[lj + 1] - self.coff[j0]].copy_(piece[off:off + self.bs(J)])
-                        off += self.bs(J)
+                src = src_idx[off:] - self.roff[i0]
+                if g.pr == 1:
+                    colop.index_copy_(0, dst, panel.index_select(0, src))
+                    continue
+                piece = self._piece_buf[:rows, :bk]
+                torch.index_select(panel, 0, src, out=piece)
+                colop.index_copy_(0, dst, piece)
+            else:
+                piece = self._piece_buf[:rows, :bk]
+            self._bcast(piece, g.rank_of(rp, g.c), g.col_group, col_members)
+            if g.r != rp:
+                colop.index_copy_(0, dst, piece)
 
     def _update(self, k: int, panel, colop, jlo: int, jhi: int, rows_after: Optional[int] = None):
         """6. A_IJ -= L_Ik L_Jk^T for the local blocks I >= J with local column index in [jlo, jhi): a staircase of GEMMs
@@ -484,6 +494,7 @@ class BlockCyclicCholesky:
         self._piece_buf = ops.empty(self.local_cols(), nb) if g.pr > 1 else None
         self._info_acc = self._flat(nblk)
         self._info_acc.zero_()
+        self._xmaps = self._exchange_maps(self._info_acc.device)
         self.diag_cache = {}
         # (created after the buffers above were queued on the caller's stream: a masked update stream starts behind them)
         st = self._st = _Streams(getattr(ops, "device", None), self.reserve_cus if self.lookahead else 0, getattr(ops, "lib", None))
