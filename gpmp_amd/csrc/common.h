@@ -57,6 +57,8 @@ struct GemmOpts {
   int kend_row = 0;
   int kstart_col = 0;       // B(l, j) = 0 for l < j - kstart_col_off (B lower triangular after an offset)
   int kstart_col_off = 0;
+  int lean = 0;             // NT products with K <= 512 issued next to a machine-filling GEMM on another stream: take the
+                            // small-footprint kernel that starts beside the two resident workgroups of that GEMM on every CU
 };
 int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, long lda,
                 const double* B, long ldb, double beta, double* C, long ldc, const GemmOpts& o,

@@ -41,6 +41,7 @@ struct GemmParams {
   int tiles_m, tiles_n, ntiles;
   int aligned;  // 16-byte loads allowed on A and B
   int cspread;  // v2: read C inside the first 16 k-tiles instead of up front
+  int lean;     // NT, K <= 512: small-footprint kernel (see gemm_nt_lean_kernel)
 };
 
 __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& ti, int& tj) {
@@ -862,6 +863,94 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmParams p) {
     }
 }
 
+// ---- small-footprint NT kernel (K <= 512): the helper-stream products of the look-ahead Cholesky ------------------
+// While the trailing update fills the machine, every CU holds two workgroups of gemm_f64_kernel_v2: 2 x 64 KB of LDS
+// and 2 x 232 VGPRs per SIMD lane.  A kernel of the ordinary kind (73 KB / 230 VGPRs) launched on the helper stream
+// then waits for one of them to retire -- about one 218 us tile time per launch, whatever its size
+// (tools/coresident_probe.hip: 131 us per dependent launch, 20 us for a kernel that fits into what is left: 32 KB of
+// LDS and 48 VGPRs).  This kernel fits: 32 x 128 tiles (a workgroup reads its 32 rows completely before it writes
+// them, so the in-place panel scaling stays race-free), operands HBM -> LDS by LDS-DMA (no staging registers) into
+// ONE 20 KB buffer with the swizzle of the v2 kernel, 32 accumulator VGPRs per wave.  It trades the deep prefetch of
+// gemm_nt_small_kernel (one exposed load latency per launch) for starting at once beside the big GEMM.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(10, 10))) gemm_nt_lean_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) double sA[SBM * BK];
+  __shared__ __attribute__((aligned(16))) double sB[SBN * BK];
+  const int row0 = blockIdx.y * SBM, col0 = blockIdx.x * SBN;
+  if (p.lower_only && col0 > row0 + SBM - 1) return;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wn = wave * 32;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int rows_v = (p.M - row0) < SBM ? (p.M - row0) : SBM;
+  const int cols_v = (p.N - col0) < SBN ? (p.N - col0) : SBN;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  // per-lane source offsets (bytes): lane l of a 1 KiB piece fills 16-byte slot (l & 7) of image row 8 q + (l >> 3);
+  // that slot holds k pair (l & 7) ^ ((row >> 1) & 7).  The buffer descriptors end with the last valid row of the
+  // tile, so pieces that reach past the edge of the matrix read zeros (they only feed outputs that are never stored).
+  const int ra = wave * 8 + (lane >> 3);
+  const int voffA = (ra * (int)p.lda + 2 * ((lane & 7) ^ ((ra >> 1) & 7))) * 8;
+  // B: the four pieces of a wave are rows 32 w + 8 s + (l >> 3); s and s + 2 share a swizzle, 16 rows apart
+  int voffB[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int rb = wave * 32 + s * 8 + (lane >> 3);
+    voffB[s] = (rb * (int)p.ldb + 2 * ((lane & 7) ^ ((rb >> 1) & 7))) * 8;
+  }
+  const int ldb16 = 16 * (int)p.ldb * 8;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.A + (long)row0 * p.lda), 0,
+                                                                        (int)((long)rows_v * p.lda * 8), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.B + (long)col0 * p.ldb), 0,
+                                                                        (int)((long)cols_v * p.ldb * 8), 0x00020000);
+
+  d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const int nk = p.K / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int k0 = kt * BK;
+    if (kt) __syncthreads();        // every wave has finished reading the previous images
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(sA + wave * 8 * 16), 16, voffA, k0 * 8, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(sB + (wave * 32 + s * 8) * 16), 16, voffB[s & 1],
+                                               k0 * 8 + (s >> 1) * ldb16, 0, 0);
+    __syncthreads();                // vmcnt(0) of every wave: both images have landed
+#pragma unroll 1                     // one k-step of fragments live at a time: the kernel must stay within 48 VGPRs
+    for (int ks = 0; ks < 4; ++ks) {
+      double fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = sA[v2_frag_addr<true>(16 * i + lr, 4 * ks + lk)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = sB[v2_frag_addr<true>(wn + 16 * j + lr, 4 * ks + lk)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  const double alpha = p.alpha, beta = p.beta;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 16 * i + 4 * r + lk;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = col0 + wn + 16 * j + lr;
+        if (row < p.M && col < p.N) {
+          double* cp = p.C + (long)row * p.ldc + col;
+          double v = alpha * acc[i][j][r];
+          if (beta != 0.0) v += beta * *cp;
+          *cp = v;
+        }
+      }
+    }
+}
+
 template <bool AKC, bool BKC, bool CACC>
 int launch_t(const GemmParams& p, hipStream_t st) {
   static bool attr_done = false;
@@ -888,14 +977,20 @@ int launch_t(const GemmParams& p, hipStream_t st) {
     const char* e = getenv("GPMP_GEMM_SMALL_NT"); use_small = e ? atoi(e) : 1;
     const char* m = getenv("GPMP_GEMM_SMALL_NT_MAX"); if (m) small_max = atoi(m);
   }
-  const bool small_nt = AKC && BKC && use_small && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
+  static int use_lean = -1;
+  if (use_lean < 0) { const char* e = getenv("GPMP_GEMM_LEAN"); use_lean = e ? atoi(e) : 1; }
+  const bool lean_nt = AKC && BKC && p.lean && use_lean && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
+                       !(p.kstart_row | p.kend_row | p.kstart_col) && ((long)SBN * p.ldb * 8 + (long)p.K * 8 < 0x7FFFFFFFL) &&
+                       ((long)SBM * p.lda * 8 + (long)p.K * 8 < 0x7FFFFFFFL);
+  const bool small_nt = !lean_nt && AKC && BKC && use_small && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
                         p.ntiles <= (p.K >= 512 ? 384 : small_max) && !(p.kstart_row | p.kend_row | p.kstart_col);
   {
     // executed flops of this launch (tiles actually visited, k range actually swept)
     const double kavg = (p.kstart_row || p.kend_row || p.kstart_col) ? 0.5 * p.K : (double)p.K;
     ProfScope ps((AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN)) + ((v2ok && !small_nt) ? 8 : 0), st,
                  2.0 * (double)p.ntiles * BM * BN * kavg);
-    if (small_nt) hipLaunchKernelGGL(gemm_nt_small_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
+    if (lean_nt) hipLaunchKernelGGL(gemm_nt_lean_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
+    else if (small_nt) hipLaunchKernelGGL(gemm_nt_small_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
     else if (v2ok) hipLaunchKernelGGL((gemm_f64_kernel_v2<AKC, BKC, CACC>), dim3(p.ntiles), dim3(256), lds2, st, p);
     else hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC, CACC>), dim3(p.ntiles), dim3(256), lds, st, p);
   }
@@ -957,6 +1052,7 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   static int cspread = -1;
   if (cspread < 0) { const char* e = getenv("GPMP_GEMM_CSPREAD"); cspread = e ? atoi(e) : 1; }
   p.cspread = cspread;
+  p.lean = o.lean;
   p.aligned = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0) &&
               ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((ldb & 1) == 0);
   if (a_kc && b_kc) return launch_c<true, true>(p, st);

@@ -200,9 +200,12 @@ LookAhead g_la;
 
 // Factor the panel of columns [p0, p1) (p0, p1 multiples of NB; rows p0 .. n): diagonal blocks in LDS,
 // panel scaling, rank-128 updates inside 512-column sub-panels and rank-512 updates between them.
-int factor_panel(double* A, int n, long lda, double* dinv, int* info_dev, int p0, int p1, hipStream_t st) {
+int factor_panel(double* A, int n, long lda, double* dinv, int* info_dev, int p0, int p1, hipStream_t st, int lean = 0) {
+  // lean: a machine-filling trailing update is running on the other stream -- the K = 128 products take the
+  // small-footprint kernel that starts beside its resident workgroups instead of queueing for a slot
   GemmOpts lower, plain;
   lower.lower_only = 1;
+  lower.lean = plain.lean = lean;
   const int sub = OUTER_BLOCKS * NB;
   for (int s0 = p0; s0 < p1; s0 += sub) {
     const int s1 = imin(s0 + sub, p1);   // sub-panel [s0, s1)
@@ -254,8 +257,9 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   // panel boundaries: 1024-wide panels while the trailing matrix is large (rank-1024 updates run at
   // ~89 % of the MFMA peak against ~84 % for rank-512, and the longer panel still hides behind them),
   // 512-wide afterwards (shorter latency-bound tail)
-  static int wide_thresh = -1;
-  if (wide_thresh < 0) { const char* e = getenv("GPMP_POTRF_WIDE_ABOVE"); wide_thresh = e ? atoi(e) : 12288; }
+  static int wide_thresh = -1, lean_above = -1;
+  if (wide_thresh < 0) { const char* e = getenv("GPMP_POTRF_WIDE_ABOVE"); wide_thresh = e ? atoi(e) : 4096; }
+  if (lean_above < 0) { const char* e = getenv("GPMP_POTRF_LEAN_ABOVE"); lean_above = e ? atoi(e) : 4096; }
   std::vector<int> pb;
   for (int p = 0; p < n;) {
     pb.push_back(p);
@@ -298,7 +302,9 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     rc = launch_gemm(true, true, n - p1, p2 - p1, w, -1.0, A + (long)p1 * lda + p0, lda, A + (long)p1 * lda + p0, lda,
                      1.0, A + (long)p1 * lda + p1, lda, lower, s1);
     if (rc) return rc;
-    rc = factor_panel(A, n, lda, dinv, info_dev, p1, p2, s1);
+    // (the main stream's update of this iteration covers (n - p2)^2 / 2: with at least two rounds of tiles it holds every
+    //  workgroup slot of the machine while this panel is factored)
+    rc = factor_panel(A, n, lda, dinv, info_dev, p1, p2, s1, (n - p2 >= lean_above) ? 1 : 0);
     if (rc) return rc;
     hipEvent_t e_f_next = g_la.next();
     GPMP_HIP_TRY(hipEventRecord(e_f_next, s1));
@@ -505,6 +511,7 @@ extern "C" int gpmp_dgemm(int ta, int tb, int M, int N, int K, double alpha, con
   GPMP_ARG(ldb >= (tb ? K : N), 10, "ldb too small");
   GPMP_ARG(ldc >= N, 13, "ldc < N");
   GemmOpts o;
-  o.lower_only = lower_only;
+  o.lower_only = lower_only & 1;
+  o.lean = (lower_only >> 1) & 1;
   return launch_gemm(ta == 0, tb != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, o, as_stream(stream));
 }

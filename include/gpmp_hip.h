@@ -146,7 +146,10 @@ int gpmp_tril(double* A, int n, long lda, gpmp_stream_t stream);
 int gpmp_symmetrize_from_lower(double* A, int n, long lda, gpmp_stream_t stream);
 
 /* C = alpha * op(A) op(B) + beta * C on the fp64 MFMA GEMM used by all the blocked routines
- * (exported for tests).  ta/tb: 0 = as stored, 1 = transposed; all row-major. */
+ * (exported for tests).  ta/tb: 0 = as stored, 1 = transposed; all row-major.
+ * lower_only: bit 0 = compute tiles on / below the diagonal only; bit 1 = for NT products with K <= 512 (ta = 0, tb = 1),
+ * take the small-footprint kernel (20 KB of LDS, 48 VGPRs) that the look-ahead Cholesky uses for its panel products
+ * while a trailing update fills the machine (it starts beside that GEMM's resident workgroups). */
 int gpmp_dgemm(int ta, int tb, int M, int N, int K, double alpha, const double* A, long lda,
                const double* B, long ldb, double beta, double* C, long ldc, int lower_only,
                gpmp_stream_t stream);

@@ -106,6 +106,43 @@ def test_dgemm_lower_only_skips_upper_tiles(gnp):
     assert np.array_equal(got[tile < 0], C0[tile < 0])  # untouched
 
 
+@pytest.mark.parametrize("M,N,K,lower", [(32, 128, 16, 0), (4000, 128, 128, 0), (1000, 384, 128, 0), (333, 70, 48, 0), (2, 130, 512, 0),
+                                          (900, 900, 128, 1), (515, 259, 256, 1)])
+def test_dgemm_lean_kernel(gnp, M, N, K, lower):
+    """flag bit 1: the small-footprint NT kernel of the look-ahead Cholesky (LDS-DMA loads bounded by the buffer
+    descriptor at ragged edges, 32 x 128 tiles), alone and with the lower-only tile skip"""
+    from gpmp_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(M + 7 * N + K)
+    A, B, C0 = rng.standard_normal((M, K)), rng.standard_normal((N, K)), rng.standard_normal((M, N))
+    At, Bt, Ct = (gnp.as_matrix(gnp.asarray(a), copy=True) for a in (A, B, C0))
+    _lib.check(lib.gpmp_dgemm(0, 1, M, N, K, -1.5, gnp._ptr(At), gnp._ld(At), gnp._ptr(Bt), gnp._ld(Bt), 0.5, gnp._ptr(Ct), gnp._ld(Ct),
+                              2 | lower, gnp._stream()), "gpmp_dgemm")
+    got, ref = gnp.to_np(Ct), -1.5 * A @ B.T + 0.5 * C0
+    if lower:
+        # 32 x 128 tiles strictly above the diagonal are skipped
+        skipped = (np.arange(N)[None, :] // 128) * 128 > (np.arange(M)[:, None] // 32) * 32 + 31
+        assert rel_err(got[~skipped], ref[~skipped]) < 1e-13
+        assert np.array_equal(got[skipped], C0[skipped])
+    else:
+        assert rel_err(got, ref) < 1e-13
+
+
+def test_dgemm_lean_kernel_in_place_panel_scaling(gnp):
+    """A <- A D^T with C aliasing A (N = K = 128): a workgroup reads its 32 rows completely before it writes them"""
+    from gpmp_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    M = 5000
+    A, D = rng.standard_normal((M, 128)), np.tril(rng.standard_normal((128, 128)))
+    At, Dt = gnp.as_matrix(gnp.asarray(A), copy=True), gnp.as_matrix(gnp.asarray(D), copy=True)
+    _lib.check(lib.gpmp_dgemm(0, 1, M, 128, 128, 1.0, gnp._ptr(At), gnp._ld(At), gnp._ptr(Dt), gnp._ld(Dt), 0.0, gnp._ptr(At), gnp._ld(At),
+                              2, gnp._stream()), "gpmp_dgemm")
+    assert rel_err(gnp.to_np(At), A @ D.T) < 1e-13
+
+
 def test_dgemm_lower_only_ragged_large_k(gnp):
     """syrk-shaped update whose last tile row / column is partial (edge tiles of the LDS-direct kernel)"""
     from gpmp_amd import _lib
