@@ -100,5 +100,12 @@ extern "C" int gpmp_stream_destroy(gpmp_stream_t stream) {
   return 0;
 }
 
+namespace gpmp { extern int g_machine_busy; }
+extern "C" int gpmp_hint_machine_busy(int on) {
+  const int prev = gpmp::g_machine_busy;
+  gpmp::g_machine_busy = on ? 1 : 0;
+  return prev;
+}
+
 extern "C" int gpmp_hip_abi_version(void) { return 1; }
 extern "C" const char* gpmp_last_error(void) { return gpmp::g_err; }

@@ -20,6 +20,8 @@
 
 namespace gpmp {
 
+int g_machine_busy = 0;   // gpmp_hint_machine_busy: small NT products take the small-footprint kernel
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16;
@@ -1052,7 +1054,7 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   static int cspread = -1;
   if (cspread < 0) { const char* e = getenv("GPMP_GEMM_CSPREAD"); cspread = e ? atoi(e) : 1; }
   p.cspread = cspread;
-  p.lean = o.lean;
+  p.lean = o.lean | g_machine_busy;
   p.aligned = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0) &&
               ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((ldb & 1) == 0);
   if (a_kc && b_kc) return launch_c<true, true>(p, st);

@@ -482,6 +482,17 @@ class BlockCyclicCholesky:
             ops.gemm_nt_sub(C, Ai, Bj)
 
     def factor(self):
+        """See _factor.  While it runs with look-ahead, the panel chain works beside this rank's own bulk updates, so the
+        library is told to use its small-footprint kernel for the chain's small products (gpmp_hint_machine_busy)."""
+        lib = getattr(self.ops, "lib", None)
+        prev = lib.gpmp_hint_machine_busy(1) if (lib is not None and self.lookahead) else None
+        try:
+            return self._factor()
+        finally:
+            if prev is not None:
+                lib.gpmp_hint_machine_busy(prev)
+
+    def _factor(self):
         """Right-looking factorisation with a one-step look-ahead.  While the caller's stream applies update k to the
         block columns > k+1, the side stream applies it to block column k+1, factors that column's diagonal block, solves
         its panel and runs every broadcast of step k+1.  Host code only enqueues; the one synchronisation is the

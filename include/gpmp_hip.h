@@ -59,6 +59,10 @@ int gpmp_profile_end(double* table_host);
  * stream (gpmp_stream_destroy).  No counterpart in the reference (it has no device code). */
 int gpmp_stream_create_reserving_cus(int reserve_cus, gpmp_stream_t* stream_out);
 int gpmp_stream_destroy(gpmp_stream_t stream);
+/* Hint for callers that enqueue latency-bound work (panel solves, small factorisations) on one stream while THEIR OWN
+ * machine-filling GEMM runs on another (gpmp_amd/dist does): while the hint is on, NT products with K <= 512 take the
+ * small-footprint kernel that starts beside that GEMM's resident workgroups (see gpmp_dgemm).  Returns the previous value. */
+int gpmp_hint_machine_busy(int on);
 
 /* ---- Matern kernels ------------------------------------------------------------------------ */
 
