@@ -16,6 +16,7 @@ namespace gpmp {
 namespace {
 
 inline int imin(int a, int b) { return a < b ? a : b; }
+inline int imax(int a, int b) { return a > b ? a : b; }
 
 // Blocked (two-level) leaf of the recursive factorisation; row0 = global index of A[0][0] (for info).
 int potrf_blocked(double* A, int n, long lda, double* dinv, int* info_dev, int row0, hipStream_t st) {
@@ -250,6 +251,10 @@ struct SolveAlong {
   int m = 0;
   long ldb = 0;
   double* gws = nullptr;
+  // every_panel: chain-bound sizes (n <= 8192: the factorisation leaves most of the machine idle).  The rows of every
+  // panel are solved as soon as that panel is factored -- a left-looking block solve B_p <- L_pp^-1 (B_p - L_p,<p X_<p) on
+  // the solve stream -- so only the last panel's rows are left when the factorisation ends.
+  int every_panel = 0;
 };
 hipStream_t g_solve_stream = nullptr;
 
@@ -260,6 +265,8 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   static int wide_thresh = -1, lean_above = -1;
   if (wide_thresh < 0) { const char* e = getenv("GPMP_POTRF_WIDE_ABOVE"); wide_thresh = e ? atoi(e) : 4096; }
   if (lean_above < 0) { const char* e = getenv("GPMP_POTRF_LEAN_ABOVE"); lean_above = e ? atoi(e) : 4096; }
+  static int along_lean = -1;
+  if (along_lean < 0) { const char* e = getenv("GPMP_POTRF_ALONG_LEAN"); along_lean = e ? atoi(e) : 0; }
   std::vector<int> pb;
   for (int p = 0; p < n;) {
     pb.push_back(p);
@@ -294,6 +301,13 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     GPMP_HIP_TRY(hipEventRecord(eb, s0));
     GPMP_HIP_TRY(hipStreamWaitEvent(g_solve_stream, eb, 0));
   }
+  hipEvent_t e_rows = nullptr;                  // last piece of the panel-by-panel solve (on g_solve_stream)
+  if (sa != nullptr && sa->every_panel) {
+    GPMP_HIP_TRY(hipStreamWaitEvent(g_solve_stream, e_f, 0));
+    rc = trsm_forward(A, pb[1], lda, dinv, sa->B, sa->m, sa->ldb, 0, 0, sa->gws, g_solve_stream);
+    if (rc) return rc;
+    n1_solved = pb[1];
+  }
   for (int k = 0; k + 1 < np; ++k) {
     const int p0 = pb[k], p1 = pb[k + 1], p2 = pb[k + 2];   // panel k = [p0, p1), next panel = [p1, p2)
     const int w = p1 - p0;
@@ -304,11 +318,31 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     if (rc) return rc;
     // (the main stream's update of this iteration covers (n - p2)^2 / 2: with at least two rounds of tiles it holds every
     //  workgroup slot of the machine while this panel is factored)
-    rc = factor_panel(A, n, lda, dinv, info_dev, p1, p2, s1, (n - p2 >= lean_above) ? 1 : 0);
+    // (with the panel-by-panel solve the solve stream's GEMMs hold the slots instead)
+    rc = factor_panel(A, n, lda, dinv, info_dev, p1, p2, s1, (n - p2 >= lean_above || (sa != nullptr && sa->every_panel && along_lean)) ? 1 : 0);
     if (rc) return rc;
     hipEvent_t e_f_next = g_la.next();
     GPMP_HIP_TRY(hipEventRecord(e_f_next, s1));
-    if (sa != nullptr && !half_launched && p2 >= n / 2 && p2 < n && p2 % (OUTER_BLOCKS * NB) == 0) {
+    if (sa != nullptr && sa->every_panel) {
+      // rows [r0, p2) of B (one or more panels, GPMP_POTRF_ALONG_ROWS): subtract the part already solved, then the
+      // diagonal part -- behind the factorisation of the last of these panels
+      // (a quarter of the matrix at a time measured best: 2048 -> 512, 4096 -> 1024, 8192 -> 2048 rows per piece)
+      static int along_env = -1;
+      if (along_env < 0) { const char* e = getenv("GPMP_POTRF_ALONG_ROWS"); along_env = e ? atoi(e) : 0; }
+      const int along_rows = along_env > 0 ? along_env : imax(OUTER_BLOCKS * NB, (n / 4) / (OUTER_BLOCKS * NB) * (OUTER_BLOCKS * NB));
+      const int r0 = n1_solved;
+      if (p2 - r0 >= along_rows || p2 == n) {
+        GPMP_HIP_TRY(hipStreamWaitEvent(g_solve_stream, e_f_next, 0));
+        GemmOpts plain;
+        rc = launch_gemm(true, false, p2 - r0, sa->m, r0, -1.0, A + (long)r0 * lda, lda, sa->B, sa->ldb, 1.0,
+                         sa->B + (long)r0 * sa->ldb, sa->ldb, plain, g_solve_stream);
+        if (rc) return rc;
+        rc = trsm_forward(A + (long)r0 * lda + r0, p2 - r0, lda, dinv + (size_t)(r0 / NB) * NB * NB, sa->B + (long)r0 * sa->ldb,
+                          sa->m, sa->ldb, 0, 0, sa->gws, g_solve_stream);
+        if (rc) return rc;
+        n1_solved = p2;
+      }
+    } else if (sa != nullptr && !half_launched && p2 >= n / 2 && p2 < n && p2 % (OUTER_BLOCKS * NB) == 0) {
       // columns [0, p2) of L are final once e_f_next has fired: solve the first p2 rows of B behind it
       half_launched = true;
       n1_solved = p2;
@@ -330,6 +364,12 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     e_f = e_f_next;
   }
   GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_f, 0));  // join: everything visible to the caller's stream
+  if (sa != nullptr && sa->every_panel) {
+    e_rows = g_la.next();
+    GPMP_HIP_TRY(hipEventRecord(e_rows, g_solve_stream));
+    GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_rows, 0));
+    return 0;                                      // n1_solved == n: every panel's rows were solved behind its factorisation
+  }
   if (sa != nullptr) {
     if (!half_launched) return trsm_forward(A, n, lda, dinv, sa->B, sa->m, sa->ldb, 0, 0, sa->gws, s0);
     // B2 -= L21 X1, then the trailing rows, on the caller's stream
@@ -430,6 +470,15 @@ extern "C" int gpmp_potrf_trsm_lower_async(double* A, int n, long lda, double* d
   // depend on what the factorisation is doing; read at every call so that tests can exercise both schedules.
   const char* ov = getenv("GPMP_POTRF_SOLVE_OVERLAP");
   const int overlap = ov ? atoi(ov) : 0;
+  // Chain-bound sizes: the factorisation of n <= 8192 leaves most of the machine idle (3.2 ms for 0.33 ms of MFMA work at
+  // n = 4096), so the rows of every panel are solved behind that panel's factorisation on a third stream.
+  const char* al = getenv("GPMP_POTRF_SOLVE_ALONG_BELOW");
+  const int along_below = al ? atoi(al) : 8192;
+  if (m > 4 && n > 2 * OUTER_BLOCKS * NB && n <= along_below) {
+    SolveAlong sa;
+    sa.B = B; sa.m = m; sa.ldb = ldb; sa.gws = gws; sa.every_panel = 1;
+    return potrf_lookahead(A, n, lda, dinv, info_dev, st, &sa);
+  }
   if (!overlap || m <= 4 || n <= 8 * OUTER_BLOCKS * NB) {
     int rc = (n <= 2 * OUTER_BLOCKS * NB) ? potrf_blocked(A, n, lda, dinv, info_dev, 0, st) : potrf_lookahead(A, n, lda, dinv, info_dev, st);
     if (rc || m == 0) return rc;
