@@ -223,8 +223,9 @@ def test_cholesky_backward_error_ill_conditioned(gnp, n, rho):
 
 @pytest.mark.parametrize("n,m", [(5120, 700), (4736, 1030), (1300, 200), (6000, 3)])
 def test_factor_and_solve_in_one_call(gnp, n, m):
-    """gnp.cholesky_factor_solve / gpmp_potrf_trsm_lower_async, with and without the optional overlap (n > 4096: the
-    leading half of the solve on a third stream while the factorisation finishes): factor and L^-1 B of the separate calls"""
+    """gnp.cholesky_factor_solve / gpmp_potrf_trsm_lower_async under its three schedules -- solve after the factorisation,
+    leading half of the solve on a third stream while the factorisation finishes (optional, n > 4096), and the default of
+    chain-bound sizes (n <= 8192: a quarter of the rows at a time behind the panels): factor and L^-1 B of the separate calls"""
     from oracle import gp_oracle as orc
 
     rng = np.random.default_rng(n + m)
@@ -236,12 +237,15 @@ def test_factor_and_solve_in_one_call(gnp, n, m):
     import os
 
     L0 = np.tril(gnp.to_np(F0.L))
-    for overlap in ("0", "1"):                         # the library reads the switch at every call
-        os.environ["GPMP_POTRF_SOLVE_OVERLAP"] = overlap
+    schedules = ({"GPMP_POTRF_SOLVE_ALONG_BELOW": "0", "GPMP_POTRF_SOLVE_OVERLAP": "0"},
+                 {"GPMP_POTRF_SOLVE_ALONG_BELOW": "0", "GPMP_POTRF_SOLVE_OVERLAP": "1"}, {})
+    for env in schedules:                              # the library reads the switches at every call
+        os.environ.update(env)
         try:
             F1, V1 = gnp.cholesky_factor_solve(gnp.asarray(K), gnp.asarray(B), overwrite=False)
         finally:
-            os.environ.pop("GPMP_POTRF_SOLVE_OVERLAP", None)
+            for k_ in env:
+                os.environ.pop(k_, None)
         L1 = np.tril(gnp.to_np(F1.L))
         assert np.array_equal(L0, L1)                  # same kernels, same order: bit-identical factor
         assert rel_err(gnp.to_np(V1), V0) < 1e-12
