@@ -10,6 +10,8 @@
 // Every thread walks a contiguous piece of one row of L (16-byte loads), x_k is broadcast from LDS;
 // no cross-lane reductions on the critical path.
 #include "common.h"
+#include <cstdlib>
+#include <cstdint>
 
 namespace gpmp {
 namespace {
@@ -154,6 +156,193 @@ __global__ void __launch_bounds__(256) trsv_kernel(const double* __restrict__ L,
   (void)nblk;
 }
 
+
+// ---- one-launch variant: persistent workgroups, block hand-off through device memory ---------------------------
+// The chain of launches above costs one kernel boundary (10-13 us) per 128-row block.  Here ONE launch of at most
+// one workgroup per CU sweeps the whole triangle: workgroups draw row blocks in solve order from a ticket counter
+// (a block only ever waits for blocks with smaller tickets, which have started: no deadlock whatever the dispatch
+// order or residency), stream their 128 x 128 tiles of L as the x_k they need appear, and publish x_j for the later
+// blocks.  Hand-off between workgroups (other CUs, other XCDs: per-CU L1 and per-XCD L2 are not coherent) follows the
+// publish / consume recipe for gfx950: payload stored with agent-scope atomic stores (write-through), drained, ONE
+// lane stores the flag with an agent-scope atomic; the consumer polls the flag with agent-scope atomic loads (bounded),
+// then reads the payload with agent-scope atomic loads (they bypass the stale L1), so no acquire fence is needed.
+// The tile of L that multiplies x_k is requested BEFORE the wait for x_k, and inv(L_jj) when the block starts, so the
+// critical path per block is: flag -> 1 KB of x -> 2 small mat-vecs from registers -> store -> flag.
+typedef __attribute__((address_space(1))) unsigned int gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+#define GPMP_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+constexpr int TRSV_MAXBLK = 4096;                 // n <= 524288
+constexpr int TRSV_RING = 4;                      // concurrent calls on different streams use different state blocks
+// state block: [0] ticket, [1] abort, [2..3] pad, [4 + k] flag of row block k.  Zeroed by hipMemsetAsync before a launch.
+__device__ __attribute__((aligned(16))) unsigned int g_trsv_state[TRSV_RING][4 + TRSV_MAXBLK];
+
+struct TrsvP {
+  const double* L;
+  long ldl;
+  const double* dinv;
+  double* B;
+  long ldb;
+  int n, m, nblk;
+  unsigned int* state;
+};
+
+template <int R, bool TRANS>
+__global__ void __launch_bounds__(256) trsv_persist_kernel(TrsvP p) {
+  __shared__ double xs[NB][R];
+  __shared__ double part[NB][R];
+  __shared__ int s_blk;
+  gu32* st = (gu32*)p.state;
+  const int t = threadIdx.x, i = t & 127, half = t >> 7;
+  const bool vec_ok = ((p.ldl & 1) == 0) && ((reinterpret_cast<uintptr_t>(p.L) & 15) == 0);
+  for (;;) {
+    if (t == 0) s_blk = (int)__hip_atomic_fetch_add(st, 1u, GPMP_RLX_AGENT);
+    __syncthreads();
+    const int blk = s_blk;
+    __syncthreads();                       // s_blk is overwritten in the next round
+    if (blk >= p.nblk) return;
+    const int j = TRANS ? p.nblk - 1 - blk : blk;
+    const int j0 = j * NB;
+    const int rb = (p.n - j0) < NB ? (p.n - j0) : NB;
+    // inv(L_jj): this thread's half row (forward) / half column (transposed), held until the block's final mat-vec
+    double dv[64];
+    {
+      const double* D = p.dinv + (size_t)j * NB * NB;
+#pragma unroll
+      for (int l = 0; l < 64; ++l) dv[l] = TRANS ? D[(half * 64 + l) * NB + i] : D[i * NB + half * 64 + l];
+    }
+    double acc[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) acc[c] = 0.0;
+    const int nt = TRANS ? (p.nblk - 1 - j) : j;
+    bool dead = false;
+    for (int q = 0; q < nt; ++q) {
+      const int k = TRANS ? p.nblk - 1 - q : q;
+      const int k0 = k * NB;
+      const int kb = (p.n - k0) < NB ? (p.n - k0) : NB;
+      // this thread's 64 entries of the tile that multiplies x_k (requested before x_k is waited for)
+      double a[64];
+      const int lmax = (kb - half * 64) < 64 ? (kb - half * 64) : 64;
+      if (i < rb) {
+        if (!TRANS) {
+          const double* row = p.L + (long)(j0 + i) * p.ldl + k0 + half * 64;
+          if (lmax == 64 && vec_ok) {
+#pragma unroll
+            for (int l = 0; l < 64; l += 2) {
+              const d2 v2 = *reinterpret_cast<const d2*>(row + l);
+              a[l] = v2[0]; a[l + 1] = v2[1];
+            }
+          } else {
+#pragma unroll
+            for (int l = 0; l < 64; ++l) a[l] = (l < lmax) ? row[l] : 0.0;
+          }
+        } else {
+          // (L^T)[j0 + i, k0 + l] = L[k0 + l][j0 + i]: coalesced across i
+          const double* col = p.L + (long)(k0 + half * 64) * p.ldl + j0 + i;
+#pragma unroll
+          for (int l = 0; l < 64; ++l) a[l] = (l < lmax) ? col[(long)l * p.ldl] : 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int l = 0; l < 64; ++l) a[l] = 0.0;
+      }
+      // wait for x_k: one lane polls (bounded), everybody else sits at the barrier
+      if (t == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(st + 4 + k, GPMP_RLX_AGENT) == 0u) {
+          if (__hip_atomic_load(st + 1, GPMP_RLX_AGENT) != 0u || ++spins > (1u << 26)) {
+            __hip_atomic_store(st + 1, 1u, GPMP_RLX_AGENT);   // give up everywhere: the result is poisoned below
+            s_blk = -1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+      if (s_blk < 0) { dead = true; break; }
+      // x_k (kb x m, zero padded) -> LDS with agent-scope atomic loads: they bypass this CU's L1, which may hold stale lines
+      for (int idx = t; idx < NB * R; idx += 256) {
+        const int l = idx / R, c = idx % R;
+        double v = 0.0;
+        if (l < kb && c < p.m) {
+          const unsigned long long bits = __hip_atomic_load((gu64*)(p.B + (long)(k0 + l) * p.ldb + c), GPMP_RLX_AGENT);
+          v = __builtin_bit_cast(double, bits);
+        }
+        xs[l][c] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int l = 0; l < 64; ++l)
+#pragma unroll
+        for (int c = 0; c < R; ++c) acc[c] = fma(a[l], xs[half * 64 + l][c], acc[c]);
+      __syncthreads();                     // xs is rewritten by the next tile
+    }
+    if (dead) {
+      if (t == 0) p.B[0] = __builtin_nan("");   // visible downstream: the solve did not complete
+      return;
+    }
+    // b_j - sum: the two half-row partial sums meet in LDS; the block's own rows of B hold the right-hand side
+    if (half == 1) {
+#pragma unroll
+      for (int c = 0; c < R; ++c) part[i][c] = acc[c];
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int c = 0; c < R; ++c) {
+        double v = 0.0;
+        if (i < rb && c < p.m) v = p.B[(long)(j0 + i) * p.ldb + c] - (acc[c] + part[i][c]);
+        xs[i][c] = v;
+      }
+    }
+    __syncthreads();
+    // x_j = op(inv(L_jj)) v from the registers loaded at the start
+#pragma unroll
+    for (int c = 0; c < R; ++c) acc[c] = 0.0;
+#pragma unroll
+    for (int l = 0; l < 64; ++l)
+#pragma unroll
+      for (int c = 0; c < R; ++c) acc[c] = fma(dv[l], xs[half * 64 + l][c], acc[c]);
+    if (half == 1) {
+#pragma unroll
+      for (int c = 0; c < R; ++c) part[i][c] = acc[c];
+    }
+    __syncthreads();
+    if (half == 0 && i < rb) {
+#pragma unroll
+      for (int c = 0; c < R; ++c)
+        if (c < p.m) {
+          const double v = acc[c] + part[i][c];
+          __hip_atomic_store((gu64*)(p.B + (long)(j0 + i) * p.ldb + c), __builtin_bit_cast(unsigned long long, v), GPMP_RLX_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its payload stores
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(st + 4 + j, 1u, GPMP_RLX_AGENT);
+  }
+}
+
+template <int R>
+int run_persist(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int trans, hipStream_t st) {
+  static int ring = 0;
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    GPMP_HIP_TRY(hipGetDevice(&dev));
+    GPMP_HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const int nblk = (n + NB - 1) / NB;
+  unsigned int* state = nullptr;
+  GPMP_HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&state), HIP_SYMBOL(g_trsv_state)));
+  state += (size_t)(ring++ % TRSV_RING) * (4 + TRSV_MAXBLK);
+  GPMP_HIP_TRY(hipMemsetAsync(state, 0, sizeof(unsigned int) * (size_t)((4 + nblk + 3) / 4 * 4), st));
+  TrsvP p{L, ldl, dinv, B, ldb, n, m, nblk, state};
+  const int grid = nblk < ncu ? nblk : ncu;
+  if (!trans) hipLaunchKernelGGL((trsv_persist_kernel<R, false>), dim3(grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((trsv_persist_kernel<R, true>), dim3(grid), dim3(256), 0, st, p);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 template <int R>
 int run(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int trans, hipStream_t st) {
   const int nblk = (n + NB - 1) / NB;
@@ -175,6 +364,15 @@ int run(const double* L, int n, long ldl, const double* dinv, double* B, int m, 
 // In-place op(L)^-1 B for an n x m B with m <= 4.
 int trsv_few(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int trans,
              hipStream_t st) {
+  // one persistent launch from a few blocks up (GPMP_TRSV_PERSIST=0: the launch-per-block chain)
+  const char* pe = getenv("GPMP_TRSV_PERSIST");     // read at every call (tests compare both routes)
+  const int persist = pe ? atoi(pe) : 1;
+  const int nblk = (n + NB - 1) / NB;
+  if (persist && nblk >= 3 && nblk <= TRSV_MAXBLK) {
+    if (m <= 1) return run_persist<1>(L, n, ldl, dinv, B, m, ldb, trans, st);
+    if (m <= 2) return run_persist<2>(L, n, ldl, dinv, B, m, ldb, trans, st);
+    return run_persist<4>(L, n, ldl, dinv, B, m, ldb, trans, st);
+  }
   if (m <= 1) return run<1>(L, n, ldl, dinv, B, m, ldb, trans, st);
   if (m <= 2) return run<2>(L, n, ldl, dinv, B, m, ldb, trans, st);
   return run<4>(L, n, ldl, dinv, B, m, ldb, trans, st);

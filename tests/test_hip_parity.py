@@ -255,6 +255,66 @@ def test_factor_and_solve_in_one_call(gnp, n, m):
     np.testing.assert_allclose(gnp.to_np(F1.solve(gnp.asarray(z))), gnp.to_np(F0.solve(gnp.asarray(z))), rtol=1e-10, atol=1e-12)
 
 
+@pytest.mark.parametrize("n", [300, 1000, 4101, 9000])
+@pytest.mark.parametrize("r", [1, 2, 3, 4])
+def test_single_vector_solves_persistent_vs_chain(gnp, n, r):
+    """op(L)^-1 B for <= 4 right-hand sides: the one-launch kernel (workgroups hand x_k over through device memory) against
+    the launch-per-block chain and against SciPy, forward and transposed, ragged last block included"""
+    import os
+    import scipy.linalg as sla
+    from oracle import gp_oracle as orc
+
+    rng = np.random.default_rng(n + r)
+    x = rng.random((n, 3))
+    K = orc.maternp_covariance(x, None, 2, np.array([0.0, 1.0, 0.7, 1.3])) + 1e-5 * np.eye(n)
+    F = gnp.cholesky_factor(gnp.asarray(K))
+    L = np.tril(gnp.to_np(F.L))
+    B = rng.standard_normal((n, r)) if r > 1 else rng.standard_normal(n)
+    for trans in (False, True):
+        ref = sla.solve_triangular(L, B, lower=True, trans=1 if trans else 0)
+        got = {}
+        for mode in ("0", "1"):
+            os.environ["GPMP_TRSV_PERSIST"] = mode
+            try:
+                got[mode] = gnp.to_np(F.solve_lower(gnp.asarray(B), trans=trans))
+            finally:
+                os.environ.pop("GPMP_TRSV_PERSIST", None)
+        scale = np.max(np.abs(ref))
+        assert np.max(np.abs(got["1"] - ref)) < 1e-9 * scale
+        assert np.max(np.abs(got["1"] - got["0"])) < 1e-11 * scale
+
+
+def test_single_vector_solve_persistent_under_load(gnp):
+    """the hand-off between workgroups must not depend on which of them are resident: run it while a machine-filling GEMM
+    occupies the workgroup slots on another stream, repeatedly, on a buffer whose lines were just read by plain loads"""
+    import torch
+    from gpmp_amd import _lib
+    from oracle import gp_oracle as orc
+
+    lib = _lib.load()
+    n = 8192
+    rng = np.random.default_rng(1)
+    x = rng.random((n, 4))
+    K = orc.maternp_covariance(x, None, 2, np.array([0.0, 1.0, 0.7, 1.3, 0.9])) + 1e-5 * np.eye(n)
+    F = gnp.cholesky_factor(gnp.asarray(K))
+    z = gnp.asarray(rng.standard_normal(n))
+    ref_f, ref_b = F.solve_lower(z).clone(), F.solve_lower(z, trans=True).clone()
+    A = gnp.alloc_matrix(16384, 1024, zero=True)
+    C = gnp.alloc_matrix(16384, 16384, zero=True)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            _lib.check(lib.gpmp_dgemm(0, 1, 16384, 16384, 1024, -1.0, gnp._ptr(A), gnp._ld(A), gnp._ptr(A), gnp._ld(A), 1.0, gnp._ptr(C),
+                                      gnp._ld(C), 1, gnp._stream()), "gpmp_dgemm")
+        w = z.clone()
+        _ = float(w.sum())                       # plain loads of the lines about to be handed over
+        got_f = F.solve_lower(w)
+        got_b = F.solve_lower(w, trans=True)
+        assert torch.equal(got_f, ref_f) and torch.equal(got_b, ref_b)   # same arithmetic order: bit-identical
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("n,m", [(1536, 700), (2048, 1024), (1280, 514), (1500, 900)])
 def test_forward_solve_many_rhs_fused_leaves(gnp, n, m):
     """L^-1 B with the factor's scratch area (n > 1024): fused 512-row leaves incl. a narrow last column strip;
