@@ -57,6 +57,8 @@ struct GemmOpts {
   int kend_row = 0;
   int kstart_col = 0;       // B(l, j) = 0 for l < j - kstart_col_off (B lower triangular after an offset)
   int kstart_col_off = 0;
+  int batch = 1;            // independent products of one shape: operand / result pointers advance by the strides below
+  long stride_a = 0, stride_b = 0, stride_c = 0;   // (elements) per batch index (blockIdx.y)
   int lean = 0;             // NT products with K <= 512 issued next to a machine-filling GEMM on another stream: take the
                             // small-footprint kernel that starts beside the two resident workgroups of that GEMM on every CU
 };
@@ -84,5 +86,6 @@ int trsv_few(const double* L, int n, long ldl, const double* dinv, double* B, in
 int launch_tril(double* A, int n, long lda, hipStream_t st);
 int launch_symmetrize(double* A, int n, long lda, hipStream_t st);
 int launch_set_identity_lower(double* T, int n, long ldt, hipStream_t st);
+int launch_diag_blocks(double* T, int n, long ldt, const double* dinv, hipStream_t st);
 
 }  // namespace gpmp

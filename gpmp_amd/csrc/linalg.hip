@@ -430,6 +430,44 @@ int trsm_backward(const double* L, int n, long ldl, const double* dinv, double* 
   return trsm_backward(L, n1, ldl, dinv, B, m, ldb, st);
 }
 
+// T = L^-1 by doubling: the diagonal 128-blocks come from dinv; at level s = 128, 256, ... every pair of adjacent
+// blocks [T11 0; T21 T22] of sizes (s, len2 <= s) gets T21 = -T22 (L21 T11).  All pairs of a level have the same shape
+// (except a ragged last one), so a level is TWO batched launches whatever n is: 2 log2(n / 128) launches in total instead
+// of the 31 large + 224 small ones of the forward solve on the identity at n = 16384.  The intermediate W = L21 T11 is
+// kept transposed in the pair's T12 block (s x len2: always fits), which is otherwise zero; the triangular structure of
+// T11 (first product, as the transposed left operand) and of T22 (second product) is skipped tile-wise, so the W blocks
+// above the diagonal are never read as part of a triangle; they are zeroed at the end.
+int trtri_doubling(const double* L, int n, long ldl, const double* dinv, double* T, long ldt, hipStream_t st) {
+  int rc = launch_diag_blocks(T, n, ldt, dinv, st);
+  if (rc) return rc;
+  for (long s = NB; s < n; s *= 2) {
+    const int npairs = (int)(n / (2 * s));                  // pairs with two full halves
+    const long tail0 = (long)npairs * 2 * s;                // a ragged pair starts here if tail0 + s < n
+    for (int part = 0; part < 2; ++part) {
+      const long o = part == 0 ? 0 : tail0;
+      const int len2 = part == 0 ? (int)s : (int)(n - (tail0 + s));
+      const int batch = part == 0 ? npairs : 1;
+      if (batch <= 0 || len2 <= 0) continue;
+      const double* T11 = T + o * ldt + o;
+      const double* L21 = L + (o + s) * ldl + o;
+      double* Wt = T + o * ldt + (o + s);                    // s x len2, W^T = T11^T L21^T
+      double* T21 = T + (o + s) * ldt + o;
+      const double* T22 = T + (o + s) * ldt + (o + s);
+      GemmOpts g1;
+      g1.kstart_row = 1;                                     // (T11^T)(i, l) = T11(l, i) = 0 for l < i
+      g1.batch = batch; g1.stride_a = 2 * s * (ldt + 1); g1.stride_b = 2 * s * (ldl + 1); g1.stride_c = 2 * s * (ldt + 1);
+      rc = launch_gemm(false, true, (int)s, len2, (int)s, 1.0, T11, ldt, L21, ldl, 0.0, Wt, ldt, g1, st);
+      if (rc) return rc;
+      GemmOpts g2;
+      g2.kend_row = 1;                                       // T22(i, l) = 0 for l > i
+      g2.batch = batch; g2.stride_a = g2.stride_b = g2.stride_c = 2 * s * (ldt + 1);
+      rc = launch_gemm(true, true, len2, (int)s, len2, -1.0, T22, ldt, Wt, ldt, 0.0, T21, ldt, g2, st);
+      if (rc) return rc;
+    }
+  }
+  return launch_tril(T, n, ldt, st);
+}
+
 }  // namespace
 }  // namespace gpmp
 
@@ -536,6 +574,8 @@ extern "C" int gpmp_trtri_lower(const double* L, int n, long ldl, const double* 
   GPMP_ARG(T != nullptr && ldt >= n, 5, "T is NULL or ldt < n");
   if (n <= 0) return 0;
   hipStream_t st = as_stream(stream);
+  const char* e = getenv("GPMP_TRTRI_DOUBLING");        // read at every call (tests compare both routes)
+  if (e == nullptr || atoi(e) != 0) return trtri_doubling(L, n, ldl, dinv, T, ldt, st);
   int rc = launch_set_identity_lower(T, n, ldt, st);
   if (rc) return rc;
   return trsm_forward(L, n, ldl, dinv, T, n, ldt, 1, 0, nullptr, st);

@@ -98,6 +98,17 @@ __global__ void __launch_bounds__(256) symmetrize_kernel(double* __restrict__ A,
   }
 }
 
+// T's diagonal 128 x 128 blocks <- the block inverses (dinv: [block][128][128], identity-padded last block)
+__global__ void diag_blocks_kernel(double* __restrict__ T, int n, long ldt, const double* __restrict__ dinv) {
+  const int b = blockIdx.x, b0 = b * NB;
+  const int jb = (n - b0) < NB ? (n - b0) : NB;
+  const double* D = dinv + (size_t)b * NB * NB;
+  for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) {
+    const int i = idx >> 7, j = idx & (NB - 1);
+    if (i < jb && j < jb) T[(long)(b0 + i) * ldt + b0 + j] = D[idx];
+  }
+}
+
 __global__ void identity_kernel(double* __restrict__ T, int n, long ldt) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
@@ -116,6 +127,12 @@ int launch_symmetrize(double* A, int n, long lda, hipStream_t st) {
   if (n <= 1) return 0;
   const int nb = (n + 31) / 32;
   hipLaunchKernelGGL(symmetrize_kernel, dim3(nb, nb), dim3(256), 0, st, A, n, lda);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+int launch_diag_blocks(double* T, int n, long ldt, const double* dinv, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(diag_blocks_kernel, dim3((n + NB - 1) / NB), dim3(256), 0, st, T, n, ldt, dinv);
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }

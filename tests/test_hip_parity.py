@@ -255,6 +255,33 @@ def test_factor_and_solve_in_one_call(gnp, n, m):
     np.testing.assert_allclose(gnp.to_np(F1.solve(gnp.asarray(z))), gnp.to_np(F0.solve(gnp.asarray(z))), rtol=1e-10, atol=1e-12)
 
 
+@pytest.mark.parametrize("n", [100, 129, 300, 1000, 1500, 2049, 3333, 5000])
+def test_trtri_doubling_vs_forward_solve_and_numpy(gnp, n):
+    """T = L^-1: the doubling scheme (two batched launches per level, W^T parked in the zero half of T) against the forward
+    solve on the identity and NumPy; sizes with ragged last blocks, ragged last pairs and a single block"""
+    import os
+    from oracle import gp_oracle as orc
+
+    rng = np.random.default_rng(n)
+    x = rng.random((n, 3))
+    K = orc.maternp_covariance(x, None, 2, np.array([0.0, 1.0, 0.7, 1.3])) + 1e-4 * np.eye(n)
+    F = gnp.cholesky_factor(gnp.asarray(K))
+    L = np.tril(gnp.to_np(F.L))
+    ref = np.linalg.inv(L)
+    got = {}
+    for mode in ("0", "1"):
+        os.environ["GPMP_TRTRI_DOUBLING"] = mode
+        try:
+            got[mode] = gnp.to_np(F.inverse_factor())
+        finally:
+            os.environ.pop("GPMP_TRTRI_DOUBLING", None)
+    for mode in got:
+        assert np.array_equal(np.triu(got[mode], 1), np.zeros((n, n)))          # strict upper triangle exactly zero
+        assert np.max(np.abs(got[mode] @ L - np.eye(n))) < 1e-9
+    assert np.max(np.abs(got["1"] - ref)) < 1e-9 * np.max(np.abs(ref))
+    assert np.max(np.abs(got["1"] - got["0"])) < 1e-10 * np.max(np.abs(ref))
+
+
 @pytest.mark.parametrize("n", [300, 1000, 4101, 9000])
 @pytest.mark.parametrize("r", [1, 2, 3, 4])
 def test_single_vector_solves_persistent_vs_chain(gnp, n, r):
