@@ -70,6 +70,26 @@ struct FastExp {
 //    propagate through a), one coupled Newton step, one residual correction;
 //  * exp(-t/2), t >= 0: k = rint(t log2(e) / 2), r = 2 k ln2 - t in [-0.694, 0.694], exp(r/2) by a degree-12 Taylor
 //    polynomial in r (remainder 0.347^13 / 13! = 1.7e-16), scaled by 2^-k: < 1 ulp of libm on [0, 745], exact 1 at 0.
+__device__ __forceinline__ double fast_sqrt_pos(double a, double tiny) {
+  const double y0 = __builtin_amdgcn_rsq(a + tiny);
+  double g = a * y0, h = 0.5 * y0;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double d = fma(-g, g, a);
+  return fma(d, h, g);
+}
+__device__ __forceinline__ double fast_exp_neg_half(const FastExp& fe, double t) {
+  const double nk = rint(t * fe.nl2e_half);                 // -k
+  double r = fma(-nk, fe.ln2x2_hi, -t);
+  r = fma(-nk, fe.ln2x2_lo, r);
+  double e = fe.c[12];
+#pragma unroll
+  for (int j = 11; j >= 0; --j) e = fma(e, r, fe.c[j]);
+  const int k = (int)nk;
+  return ldexp(e, k < -1100 ? -1100 : k);
+}
+
 struct GramParams {
   const double* x;
   const double* y;
@@ -299,8 +319,9 @@ struct GradParams {
   int ntiles_side, ntiles;
   double sigma2;
   double* partial;  // [gridDim.x][DT + 2]
-  double invrho[GPMP_MAX_DIM];
+  double invrho[GPMP_MAX_DIM];   // 2 c / rho_j: the tile accumulates t^2 = (2 c h)^2 and the weights are per (2 c delta_j)^2
   MaternSpec ms;
+  FastExp fe;
 };
 
 __device__ __forceinline__ double matern_dk_over_h(const MaternSpec& ms, double h, double& kval) {
@@ -393,8 +414,20 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
         if (row < p.n && col < p.n) wt = col < row ? 2.0 : (col == row ? 1.0 : 0.0);
         double mval = 0.0;
         if (wt != 0.0) mval = wt * (p.Kinv[(long)row * p.ldk + col] - w[a][b]);
-        double kval;
-        const double dk = matern_dk_over_h(p.ms, sqrt(h2[a][b]), kval);
+        // K(h) = e^{-t/2} sum q_k t^k and (K'(h)/h) / (2c)^2 = e^{-t/2} sum_{k>=1} s_k t^{k-1} (p >= 1), t = 2 c h
+        const double tt = fast_sqrt_pos(h2[a][b], p.fe.tiny);
+        const double e = fast_exp_neg_half(p.fe, tt);
+        double poly = p.ms.q[p.ms.p];
+        for (int k = p.ms.p - 1; k >= 0; --k) poly = fma(poly, tt, p.ms.q[k]);
+        const double kval = e * poly;
+        double dk;
+        if (p.ms.p == 0) {
+          dk = tt > 0.0 ? -0.5 * e / tt : 0.0;
+        } else {
+          double sp = p.ms.s[p.ms.p];
+          for (int k = p.ms.p - 1; k >= 1; --k) sp = fma(sp, tt, p.ms.s[k]);
+          dk = e * sp;
+        }
         g0 = fma(mval, kval, g0);
         if (row == col) gtr += mval;
         w[a][b] = mval * dk;  // weight of (delta_j)^2 for every dimension j
@@ -654,8 +687,9 @@ extern "C" int gpmp_matern_grad_trace(const double* Kinv, long ldk, const double
   gp.sigma2 = std::exp(theta_host[0]);
   gp.partial = ws;
   const int off = noise ? 2 : 1;
-  for (int k = 0; k < d; ++k) gp.invrho[k] = std::exp(theta_host[off + k]);
   fill_matern(gp.ms, p);
+  for (int k = 0; k < d; ++k) gp.invrho[k] = 2.0 * gp.ms.c * std::exp(theta_host[off + k]);
+  fill_fast_exp(gp.fe);
   const int nblocks = gp.ntiles < GRAD_BLOCKS ? gp.ntiles : GRAD_BLOCKS;
   const int dt = grad_tier(d);
   int rc = 0;

@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) trsv_persist_kernel(TrsvP p) {
       if (t == 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(st + 4 + k, GPMP_RLX_AGENT) == 0u) {
-          if (__hip_atomic_load(st + 1, GPMP_RLX_AGENT) != 0u || ++spins > (1u << 26)) {
+          if (__hip_atomic_load(st + 1, GPMP_RLX_AGENT) != 0u || ++spins > (1u << 22)) {
             __hip_atomic_store(st + 1, 1u, GPMP_RLX_AGENT);   // give up everywhere: the result is poisoned below
             s_blk = -1;
             break;
@@ -331,9 +331,9 @@ int run_persist(const double* L, int n, long ldl, const double* dinv, double* B,
     GPMP_HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
   }
   const int nblk = (n + NB - 1) / NB;
-  unsigned int* state = nullptr;
-  GPMP_HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&state), HIP_SYMBOL(g_trsv_state)));
-  state += (size_t)(ring++ % TRSV_RING) * (4 + TRSV_MAXBLK);
+  static unsigned int* state_base = nullptr;
+  if (state_base == nullptr) GPMP_HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&state_base), HIP_SYMBOL(g_trsv_state)));
+  unsigned int* state = state_base + (size_t)(ring++ % TRSV_RING) * (4 + TRSV_MAXBLK);
   GPMP_HIP_TRY(hipMemsetAsync(state, 0, sizeof(unsigned int) * (size_t)((4 + nblk + 3) / 4 * 4), st));
   TrsvP p{L, ldl, dinv, B, ldb, n, m, nblk, state};
   const int grid = nblk < ncu ? nblk : ncu;
