@@ -109,6 +109,21 @@ def dist_potrf_extra(world, rank, res):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    # ---- values first: a small problem through the same grid / collectives against the single-GPU path on rank 0
+    n_chk = 8192
+    chk = BlockCyclicCholesky(grid, n_chk, nb=nb, transport="bcast")
+    chk.build_local_gram(MaternCovariance(2), xd[:n_chk].contiguous(), theta, 1e-4)
+    info_chk = chk.factor()
+    nll_dist = chk.negative_log_likelihood(z[:n_chk])
+    del chk
+    if rank == 0:
+        import gpmp_amd as gp
+
+        th2 = np.concatenate(([theta[0], math.log(1e-4)], theta[1:]))
+        ref = float(gp.Model(None, MaternCovariance(2, noise=True), None, th2, "zero").negative_log_likelihood_zero_mean(th2, x[:n_chk], z[:n_chk]))
+        res["check_n8192"] = {"info": info_chk, "nll_block_cyclic": nll_dist, "nll_single_gpu": ref,
+                              "rel_diff": abs(nll_dist - ref) / abs(ref)}
+
     for transport in ("bcast", "p2p"):
         for rep in ("warm", "timed"):
             ch = BlockCyclicCholesky(grid, n, nb=nb, transport=transport, profile=(rep == "timed"))
