@@ -57,6 +57,8 @@ struct GemmOpts {
   int kend_row = 0;
   int kstart_col = 0;       // B(l, j) = 0 for l < j - kstart_col_off (B lower triangular after an offset)
   int kstart_col_off = 0;
+  int kend_col = 0;         // B(l, j) = 0 for l > j (B upper triangular as K x N, e.g. the transpose of a lower T given as N x K): tile
+                            // column j only needs l < col0(j) + 128
   int batch = 1;            // independent products of one shape: operand / result pointers advance by the strides below
   long stride_a = 0, stride_b = 0, stride_c = 0;   // (elements) per batch index (blockIdx.y)
   int lean = 0;             // NT products with K <= 512 issued next to a machine-filling GEMM on another stream: take the

@@ -38,7 +38,7 @@ struct GemmParams {
   long lda, ldb, ldc;
   int M, N, K;
   double alpha, beta;
-  int lower_only, kstart_row, kend_row;
+  int lower_only, kstart_row, kend_row, kend_col;
   int kstart_col, kstart_col_off;   // k loop of tile column j starts at max(0, col0(j) - off)
   int tiles_m, tiles_n, ntiles;
   int aligned;  // 16-byte loads allowed on A and B
@@ -57,7 +57,7 @@ __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& t
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   // tiles of unequal cost (triangular k ranges) are dealt round-robin instead: a contiguous chunk per
   // XCD would hand one XCD all the long tiles (measured on lauum: 29 -> 50+ TFLOP/s)
-  const int v = (p.kstart_row | p.kend_row | p.kstart_col) ? bid : base + bid / NXCD;
+  const int v = (p.kstart_row | p.kend_row | p.kstart_col | p.kend_col) ? bid : base + bid / NXCD;
   if (p.lower_only) {
     const int tn = p.tiles_n < p.tiles_m ? p.tiles_n : p.tiles_m;
     const int t1 = tn * (tn + 1) / 2;
@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmParams p) {
   }
   int kend = p.K;
   if (p.kend_row && row0 + BM < kend) kend = row0 + BM;
+  if (p.kend_col && col0 + BN < kend) kend = col0 + BN;
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
   const bool full_mn = p.aligned && (row0 + BM <= p.M) && (col0 + BN <= p.N);
 
@@ -382,6 +383,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
   }
   int kend = p.K;
   if (p.kend_row && row0 + BM < kend) kend = row0 + BM;
+  if (p.kend_col && col0 + BN < kend) kend = col0 + BN;
   const int nk = kend > kbeg ? (kend - kbeg) / BK : 0;
 
   // ---- accumulators (start from (beta/alpha) C, see v1)
@@ -990,13 +992,13 @@ int launch_t(const GemmParams& p, hipStream_t st) {
   static int use_lean = -1;
   if (use_lean < 0) { const char* e = getenv("GPMP_GEMM_LEAN"); use_lean = e ? atoi(e) : 1; }
   const bool lean_nt = p.batch == 1 && AKC && BKC && p.lean && use_lean && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
-                       !(p.kstart_row | p.kend_row | p.kstart_col) && ((long)SBN * p.ldb * 8 + (long)p.K * 8 < 0x7FFFFFFFL) &&
+                       !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col) && ((long)SBN * p.ldb * 8 + (long)p.K * 8 < 0x7FFFFFFFL) &&
                        ((long)SBM * p.lda * 8 + (long)p.K * 8 < 0x7FFFFFFFL);
   const bool small_nt = !lean_nt && p.batch == 1 && AKC && BKC && use_small && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
-                        p.ntiles <= (p.K >= 512 ? 384 : small_max) && !(p.kstart_row | p.kend_row | p.kstart_col);
+                        p.ntiles <= (p.K >= 512 ? 384 : small_max) && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col);
   {
     // executed flops of this launch (tiles actually visited, k range actually swept)
-    const double kavg = (p.kstart_row || p.kend_row || p.kstart_col) ? 0.5 * p.K : (double)p.K;
+    const double kavg = (p.kstart_row || p.kend_row || p.kstart_col || p.kend_col) ? 0.5 * p.K : (double)p.K;
     ProfScope ps((AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN)) + ((v2ok && !small_nt) ? 8 : 0), st,
                  2.0 * (double)p.ntiles * BM * BN * kavg * p.batch);
     if (lean_nt) hipLaunchKernelGGL(gemm_nt_lean_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
@@ -1049,7 +1051,7 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K;
   p.alpha = alpha; p.beta = beta;
-  p.lower_only = o.lower_only; p.kstart_row = o.kstart_row; p.kend_row = o.kend_row;
+  p.lower_only = o.lower_only; p.kstart_row = o.kstart_row; p.kend_row = o.kend_row; p.kend_col = o.kend_col;
   p.kstart_col = o.kstart_col; p.kstart_col_off = o.kstart_col_off;
   p.tiles_m = (M + BM - 1) / BM;
   p.tiles_n = (N + BN - 1) / BN;
@@ -1079,7 +1081,7 @@ int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const d
   if (M <= 0 || N <= 0) return 0;
   // The LDS-direct kernel needs even M and N (16-byte clipping at the edges): peel an odd last row / column off a
   // large rectangular product so that everything else runs on it.
-  const bool plain = !o.lower_only && !o.kstart_row && !o.kend_row && !o.kstart_col && o.batch <= 1;
+  const bool plain = !o.lower_only && !o.kstart_row && !o.kend_row && !o.kstart_col && !o.kend_col && o.batch <= 1;
   const int Nr = N % 2, Mr = M % 2;
   if (plain && (Nr || Mr) && (K % BK == 0) && K >= 512 && (M >= 4 * BM || N >= 4 * BN) && C != A && C != B) {
     const int Mf = M - Mr, Nf = N - Nr;

@@ -602,5 +602,6 @@ extern "C" int gpmp_dgemm(int ta, int tb, int M, int N, int K, double alpha, con
   GemmOpts o;
   o.lower_only = lower_only & 1;
   o.lean = (lower_only >> 1) & 1;
+  o.kend_col = (lower_only >> 2) & 1;
   return launch_gemm(ta == 0, tb != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, o, as_stream(stream));
 }

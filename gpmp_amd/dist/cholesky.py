@@ -79,6 +79,17 @@ class HipLocalOps:
         self._lib.check(self.lib.gpmp_trsm_right_lower(g._ptr(L), L.shape[0], g._ld(L), g._ptr(dinv), g._ptr(B), B.shape[0],
                                                        g._ld(B), g._stream()), "gpmp_trsm_right_lower")
 
+    def trsm_right_via_inverse(self, L, dinv, B, out):
+        """out <- B L^-T as ONE product with T = L^-1 (doubling from the 128-block inverses): out = B T^T, the k loop of each
+        tile column stopping at the diagonal.  Under a machine-filling GEMM on another stream every launch of the panel chain
+        waits for a workgroup slot, so 7 small launches + 1 large beat the 15 of the substitution."""
+        g = self.gnp
+        k = L.shape[0]
+        T = g.alloc_matrix(k, k)
+        self._lib.check(self.lib.gpmp_trtri_lower(g._ptr(L), k, g._ld(L), g._ptr(dinv), g._ptr(T), g._ld(T), g._stream()), "gpmp_trtri_lower")
+        self._lib.check(self.lib.gpmp_dgemm(0, 1, B.shape[0], k, k, 1.0, g._ptr(B), g._ld(B), g._ptr(T), g._ld(T), 0.0, g._ptr(out),
+                                            g._ld(out), 4, g._stream()), "gpmp_dgemm")
+
     def gemm_nt_sub(self, C, A, B):
         """C -= A B^T  (C: M x N view, A: M x K, B: N x K)."""
         g = self.gnp
@@ -222,6 +233,7 @@ class BlockCyclicCholesky:
         if self.transport not in ("bcast", "p2p"):
             raise ValueError("transport must be 'bcast' or 'p2p'")
         self.lookahead = lookahead
+        self.panel_via_inverse = os.environ.get("GPMP_DIST_PANEL_INVERSE", "1") != "0"
         self.reserve_cus = int(os.environ.get("GPMP_DIST_RESERVE_CUS", "0")) if reserve_cus is None else int(reserve_cus)
         self.profile = profile       # record per-phase HIP events in factor(); read them with phase_times()
         self._marks = []             # (phase, start event, end event)
@@ -366,8 +378,12 @@ class BlockCyclicCholesky:
             lj = k // g.pc
             P = A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]]
             with self._phase("trsm"):
-                ops.trsm_right(Lkk, dinv, P)
-                panel.copy_(P)
+                if self.panel_via_inverse and hasattr(ops, "trsm_right_via_inverse") and bk % 128 == 0:
+                    ops.trsm_right_via_inverse(Lkk, dinv, P, panel)
+                    P.copy_(panel)
+                else:
+                    ops.trsm_right(Lkk, dinv, P)
+                    panel.copy_(P)
         if g.pc > 1 and Mr > 0:
             with self._phase("row_bcast"):
                 self._bcast(panel, g.rank_of(g.r, cd), g.row_group, row_members)

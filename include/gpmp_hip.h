@@ -153,7 +153,9 @@ int gpmp_symmetrize_from_lower(double* A, int n, long lda, gpmp_stream_t stream)
  * (exported for tests).  ta/tb: 0 = as stored, 1 = transposed; all row-major.
  * lower_only: bit 0 = compute tiles on / below the diagonal only; bit 1 = for NT products with K <= 512 (ta = 0, tb = 1),
  * take the small-footprint kernel (20 KB of LDS, 48 VGPRs) that the look-ahead Cholesky uses for its panel products
- * while a trailing update fills the machine (it starts beside that GEMM's resident workgroups). */
+ * while a trailing update fills the machine (it starts beside that GEMM's resident workgroups); bit 2 = op(B) is upper
+ * triangular (op(B)(l, j) = 0 for l > j, e.g. tb = 1 with B a lower-triangular T: C = A T^T): the k loop of a tile column
+ * stops at its last non-zero row. */
 int gpmp_dgemm(int ta, int tb, int M, int N, int K, double alpha, const double* A, long lda,
                const double* B, long ldb, double beta, double* C, long ldc, int lower_only,
                gpmp_stream_t stream);
