@@ -129,6 +129,26 @@ def test_dgemm_lean_kernel(gnp, M, N, K, lower):
         assert rel_err(got, ref) < 1e-13
 
 
+@pytest.mark.parametrize("M,K", [(700, 1024), (260, 384), (130, 130)])
+def test_dgemm_upper_triangular_right_operand(gnp, M, K):
+    """flag bit 2: C = A T^T with T lower triangular (the k loop of a tile column stops at the diagonal); the strict upper
+    part of T holds garbage that must not be read tile-wise beyond the diagonal tiles -- here NaN above the diagonal TILES"""
+    from gpmp_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(M + K)
+    A = rng.standard_normal((M, K))
+    T = np.tril(rng.standard_normal((K, K)))
+    Tg = T.copy()
+    tile = np.arange(K) // 128
+    Tg[tile[:, None] < tile[None, :]] = np.nan             # tiles strictly above the diagonal tiles: never read
+    At, Tt = gnp.as_matrix(gnp.asarray(A), copy=True), gnp.as_matrix(gnp.asarray(Tg), copy=True)
+    Ct = gnp.alloc_matrix(M, K)
+    _lib.check(lib.gpmp_dgemm(0, 1, M, K, K, 1.0, gnp._ptr(At), gnp._ld(At), gnp._ptr(Tt), gnp._ld(Tt), 0.0, gnp._ptr(Ct), gnp._ld(Ct),
+                              4, gnp._stream()), "gpmp_dgemm")
+    assert rel_err(gnp.to_np(Ct), A @ T.T) < 1e-13
+
+
 def test_dgemm_lean_kernel_in_place_panel_scaling(gnp):
     """A <- A D^T with C aliasing A (N = K = 128): a workgroup reads its 32 rows completely before it writes them"""
     from gpmp_amd import _lib
