@@ -45,6 +45,7 @@ struct GemmParams {
   int cspread;  // v2: read C inside the first 16 k-tiles instead of up front
   int lean;     // NT, K <= 512: small-footprint kernel (see gemm_nt_lean_kernel)
   int batch;    // gridDim.y independent products
+  int pair16;   // v2 epilogue: 16-byte stores after a lane-pair exchange
   long sa, sb, sc;   // element strides of A, B, C per batch index
 };
 
@@ -348,6 +349,13 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmParams p) {
 // Full tiles only (M, N multiples of 128, k range a multiple of 16, 16-byte aligned operands).
 constexpr int V2_TILE = 2048;   // doubles per operand image (unpadded)
 
+__device__ __forceinline__ double swap_lane_xor1(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 template <bool KC>
 __device__ __forceinline__ int v2_frag_addr(int idx, int k) {
   if constexpr (KC) return idx * 16 + 2 * ((k >> 1) ^ ((idx >> 1) & 7)) + (k & 1);
@@ -388,6 +396,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
 
   // ---- accumulators (start from (beta/alpha) C, see v1)
   const double alpha = p.alpha, beta = p.beta;
+  const bool pair_stores = p.pair16 != 0;
   double* __restrict__ cbase = p.C + (long)row0 * p.ldc + col0;
   const unsigned lane_off = (unsigned)((wm + lk) * (int)p.ldc + wn + lr);
   d4 acc[4][4];
@@ -554,7 +563,25 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
     for (; kt < nk; ++kt) ktile(kt, kt + 1 < nk, nothing);
   }
 
-  if (!edge) {
+  if (!edge && (CACC || beta == 0.0) && pair_stores) {
+    // Pure store of a full tile with 16-byte stores: in the MFMA layout a lane holds ONE column of four rows (4 apart), so
+    // neighbouring lanes (columns c, c + 1) swap half of their registers (DPP quad_perm [1,0,3,2]): the even lane then owns
+    // rows r = 0, 1 of both columns, the odd lane rows r = 2, 3 -- 32 store instructions per thread instead of 64.
+    const bool odd = lane & 1;
+    const unsigned off2 = lane_off - (odd ? 1u : 0u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double a0 = alpha * acc[i][j][0], a1 = alpha * acc[i][j][1], a2 = alpha * acc[i][j][2], a3 = alpha * acc[i][j][3];
+        const double g0 = swap_lane_xor1(odd ? a0 : a2), g1 = swap_lane_xor1(odd ? a1 : a3);
+        const d2 v0 = odd ? (d2){g0, a2} : (d2){a0, g0};
+        const d2 v1 = odd ? (d2){g1, a3} : (d2){a1, g1};
+        double* rp0 = cbase + (long)(i * 16 + (odd ? 8 : 0)) * p.ldc + off2 + j * 16;
+        *reinterpret_cast<d2*>(rp0) = v0;
+        *reinterpret_cast<d2*>(rp0 + 4 * p.ldc) = v1;
+      }
+  } else if (!edge) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1064,6 +1091,9 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   static int cspread = -1;
   if (cspread < 0) { const char* e = getenv("GPMP_GEMM_CSPREAD"); cspread = e ? atoi(e) : 1; }
   p.cspread = cspread;
+  static int pair16 = -1;
+  if (pair16 < 0) { const char* e = getenv("GPMP_GEMM_PAIR16"); pair16 = e ? atoi(e) : 1; }
+  p.pair16 = pair16;
   p.lean = o.lean | g_machine_busy;
   p.batch = o.batch > 1 ? o.batch : 1;
   p.sa = o.stride_a; p.sb = o.stride_b; p.sc = o.stride_c;
