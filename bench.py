@@ -51,7 +51,13 @@ def pmc_traffic_per_launch(kernel_substr):
     tot = 0.0
     n_disp = None
     for name, factor in (("fetch", 2.0), ("write", 1.0)):
-        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"bench_v*_pmc_{name}_size_by_kernel.csv")))
+        import re
+
+        def version(path):      # (round, profile version), numerically: v10 comes after v9
+            m = re.search(r"r(\d+)[/\\]bench_v(\d+)_pmc", path)
+            return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+
+        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"bench_v*_pmc_{name}_size_by_kernel.csv")), key=version)
         if not found:
             return None
         path = found[-1]   # the latest committed pass
