@@ -100,6 +100,34 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
 
   PF_MARK(1);
   if (do_factor) {
+    // A3(j): trailing update on MFMA, A_ik -= L_ij L_kj^T for the sub-blocks j < gk <= gi < 8, enumerated b = 0, 1, ...
+    // with b = 0 the NEXT diagonal block (j+1, j+1).  Wave 0 does b = 0 right after A2(j) and goes on to factor that block
+    // (A1(j+1)); the other seven waves do the rest meanwhile, so the update hides behind the register factorisation.
+    auto a3_blocks = [&](int j, int b_first, int b_step, int b_end_excl) {
+      const int rem = NSB - 1 - j;
+      const int nblk = rem * (rem + 1) / 2;
+      const int bend = b_end_excl < nblk ? b_end_excl : nblk;
+      for (int b = b_first; b < bend; b += b_step) {
+        int bi = 0, acc_cnt = 0;
+        while (acc_cnt + bi + 1 <= b) { acc_cnt += bi + 1; ++bi; }
+        const int bk = b - acc_cnt;
+        const int gi = j + 1 + bi, gk = j + 1 + bk;                       // global sub-block indices, gi >= gk
+        double* Cik = S + ((gi * (gi + 1) / 2 + gk) << 8);
+        const double* Lij = S + ((gi * (gi + 1) / 2 + j) << 8);
+        const double* Lkj = S + ((gk * (gk + 1) / 2 + j) << 8);
+        d4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Cik[sidx(lk + 4 * r, lr)];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double af = -Lij[sidx(lr, 4 * s + lk)];   // -L_ij[row][k]
+          const double bf = Lkj[sidx(lr, 4 * s + lk)];    // L_kj[col][k] = (L_kj^T)[k][col]
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cik[sidx(lk + 4 * r, lr)] = acc[r];
+      }
+    };
     for (int j = 0; j < NSB; ++j) {
       const int j0 = j * SB;
       double* Djj = S + ((j * (j + 1) / 2 + j) << 8);   // diagonal sub-block image
@@ -130,6 +158,8 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
 #pragma unroll
           for (int c = 0; c < SB; ++c) Djj[sidx(lr, c)] = (c <= lane) ? a[c] : 0.0;
         }
+      } else if (j >= 1) {
+        a3_blocks(j - 1, wave, THREADS / 64 - 1, 1 << 30);   // b = 1, 2, ... of A3(j-1) over waves 1..7 (b = 0 was wave 0's)
       }
       __syncthreads();
       PF_MARK(8 + 3 * j);
@@ -153,32 +183,8 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
       }
       __syncthreads();
       PF_MARK(9 + 3 * j);
-      // ---- A3: trailing update on MFMA: blocks (bi, bk), j < bk <= bi < 8
-      {
-        const int rem = NSB - 1 - j;
-        const int nblk = rem * (rem + 1) / 2;
-        for (int b = wave; b < nblk; b += THREADS / 64) {
-          int bi = 0, acc_cnt = 0;
-          while (acc_cnt + bi + 1 <= b) { acc_cnt += bi + 1; ++bi; }
-          const int bk = b - acc_cnt;
-          const int gi = j + 1 + bi, gk = j + 1 + bk;                       // global sub-block indices, gi >= gk
-          double* Cik = S + ((gi * (gi + 1) / 2 + gk) << 8);
-          const double* Lij = S + ((gi * (gi + 1) / 2 + j) << 8);
-          const double* Lkj = S + ((gk * (gk + 1) / 2 + j) << 8);
-          d4 acc;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = Cik[sidx(lk + 4 * r, lr)];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const double af = -Lij[sidx(lr, 4 * s + lk)];   // -L_ij[row][k]
-            const double bf = Lkj[sidx(lr, 4 * s + lk)];    // L_kj[col][k] = (L_kj^T)[k][col]
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Cik[sidx(lk + 4 * r, lr)] = acc[r];
-        }
-      }
-      __syncthreads();
+      // ---- A3(j), first block only: wave 0 updates the next diagonal block and goes straight on to factor it
+      if (wave == 0) a3_blocks(j, 0, 1, 1);
       PF_MARK(10 + 3 * j);
     }
     PF_MARK(2);
