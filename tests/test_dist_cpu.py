@@ -104,6 +104,30 @@ def _nonpd_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _profile_worker(rank, world, port, out):
+    _init(rank, world, port)
+    try:
+        from gpmp_amd.dist import BlockCyclicCholesky, ProcessGrid
+        from tests.cpu_local_ops import CpuLocalOps
+
+        x, z = make_xz(400, 3, 7)
+        ch = BlockCyclicCholesky(ProcessGrid(1, 2), 400, nb=128, ops=CpuLocalOps(), profile=True, reserve_cus=8)
+        ch.build_local_gram(_cov, x, theta_aniso(3, scale=0.4), 1e-6)
+        info = ch.factor()
+        if rank == 0:
+            np.save(out, np.array([info, len(ch.phase_times())]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_profile_and_reserve_options_are_inert_without_a_gpu(tmp_path):
+    """profile=True / reserve_cus only act on HIP streams; with CPU local ops they must neither fail nor report phases"""
+    out = str(tmp_path / "p.npy")
+    mp.spawn(_profile_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    info, nphases = np.load(out)
+    assert info == 0 and nphases == 0
+
+
 def test_block_cyclic_not_positive_definite(tmp_path):
     out = str(tmp_path / "r.npy")
     mp.spawn(_nonpd_worker, args=(2, _free_port(), out), nprocs=2, join=True)
