@@ -117,9 +117,11 @@ def dist_potrf_extra(world, rank, res):
 
     # ---- values first: a small problem through the same grid / collectives against the single-GPU path on rank 0
     n_chk = 8192
+    res["phase"] = "check_n8192: build + factor (bcast)"
     chk = BlockCyclicCholesky(grid, n_chk, nb=nb, transport="bcast")
     chk.build_local_gram(MaternCovariance(2), xd[:n_chk].contiguous(), theta, 1e-4)
     info_chk = chk.factor()
+    res["phase"] = "check_n8192: nll (world broadcast + all-reduce per block column)"
     nll_dist = chk.negative_log_likelihood(z[:n_chk])
     del chk
     if rank == 0:
@@ -132,6 +134,7 @@ def dist_potrf_extra(world, rank, res):
 
     for transport in ("bcast", "p2p"):
         for rep in ("warm", "timed"):
+            res["phase"] = f"{transport}_{rep}: gram + factor at n={n}"
             ch = BlockCyclicCholesky(grid, n, nb=nb, transport=transport, profile=(rep == "timed"))
             torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -151,12 +154,13 @@ def dist_potrf_extra(world, rank, res):
                 # lookahead_update (the panel chain and every collective), caller's stream = update
                 entry["phases_ms_rank0"] = {k_: round(v_, 2) for k_, v_ in ch.phase_times().items()}
                 t3 = time.perf_counter()
+                res["phase"] = f"{transport}_{rep}: nll solve at n={n}"
                 entry["nll"] = ch.negative_log_likelihood(z)
                 torch.cuda.synchronize()
                 entry["nll_solve_s"] = tmax(time.perf_counter() - t3)
             res[f"{transport}_{rep}"] = entry
             del ch
-    res["status"] = "ok"
+    res["phase"] = "done"
 
 
 def main():
@@ -324,28 +328,34 @@ def main():
                 threads = os.cpu_count() or 1
             line["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_m, d, threads)
 
-    # ---- N > 1: the distributed Cholesky of configs[4] as an extra, guarded by a watchdog.  The headline line above is
-    # complete before it starts; whatever happens in here (a hung collective, an exception on some rank) rank 0 still
-    # prints that line, once, and every rank leaves with exit code 0.
-    # (GPMP_BENCH_DIST=0 skips it; =force runs it on a 1 x 1 grid too, which is how it is rehearsed on a one-GPU box)
-    dist_env = os.environ.get("GPMP_BENCH_DIST", "1")
-    run_dist = dist_on and dist_env != "0" and (world > 1 or dist_env == "force")
+    # ---- N > 1, OPT-IN (GPMP_BENCH_DIST=1; =force also runs it on a 1 x 1 grid): the distributed Cholesky of configs[4]
+    # as an extra after the headline measurement.  Off by default: its RCCL path with more than one rank has not run on
+    # hardware yet (this pool gives one GPU per box), and an unproven collective schedule must not be able to turn the
+    # headline run into a failure.  When it is on, a watchdog bounds it: on a timeout or an error rank 0 still prints
+    # the headline line (with what finished and the phase that was in flight), and then EVERY rank leaves with a
+    # non-zero exit code -- 3 for a timeout, 4 for an error -- so the run is recorded as failed, never as rc 0.
+    dist_env = os.environ.get("GPMP_BENCH_DIST", "0")
+    run_dist = dist_on and dist_env not in ("0", "") and (world > 1 or dist_env == "force")
     if run_dist:
         import threading
 
-        res = {"status": "started"}
+        res = {"status": "started", "phase": "setup"}
         done = threading.Lock()
+        EXIT = {"ok": 0, "timeout": 3, "error": 4}
 
         def finish(status):
             if not done.acquire(blocking=False):
                 return
-            res["status"] = status if res.get("status") != "ok" else "ok"
+            res["status"] = status
             if rank == 0:
                 line["extra"]["dist_potrf"] = res
                 print(json.dumps(line), flush=True)
             if status != "ok":
+                sys.stderr.write(f"[bench rank {rank}] distributed extra: {status} in phase {res.get('phase')!r}"
+                                 f" {res.get('error', '')}\n")
                 sys.stdout.flush()
-                os._exit(0)            # collectives may be wedged: no orderly teardown
+                sys.stderr.flush()
+                os._exit(EXIT[status])   # collectives may be wedged: no orderly teardown, and never exit code 0
 
         wd = threading.Timer(float(os.environ.get("GPMP_BENCH_DIST_TIMEOUT", "240")), finish, args=("timeout",))
         wd.daemon = True
@@ -355,7 +365,7 @@ def main():
             dist_potrf_extra(world, rank, res)
             wd.cancel()
             finish("ok")
-        except BaseException as e:     # noqa: BLE001 -- report and leave; peers are released by their own watchdogs
+        except BaseException as e:     # noqa: BLE001 -- report, then leave with exit code 4 (peers: their own watchdogs, 3)
             wd.cancel()
             res["error"] = f"{type(e).__name__}: {e}"[:400]
             finish("error")

@@ -6,18 +6,35 @@ from GPMP_LOG_LEVEL (gpmp/config.py:111-117).  The only backend here is "hip".
 """
 import logging
 import os
+import re
+
+
+_WIDTH = re.compile(r"(?:float|f|fp)?(16|32|64|128)$|f(2|4|8|16)$")
 
 
 def _normalize_dtype_spec(dtype) -> str:
-    """gpmp/config.py:59-78 -- anything that is not float64 is an error."""
+    """Only IEEE double is a legal working precision (the reference's rule, gpmp/config.py:59-78: single
+    precision is refused with its own message, anything that is not recognisably double is refused too).
+    Accepts the spellings users pass around: "float64", "torch.float64", numpy / torch dtype objects, "double",
+    "f8", the Python ``float`` type, or None (= default)."""
     if dtype is None or dtype is float:
         return "float64"
-    s = dtype.lower() if isinstance(dtype, str) else str(dtype).lower()
-    if "float32" in s or s.endswith("f4") or s.endswith("32"):
+    name = (dtype if isinstance(dtype, str) else str(dtype)).strip().lower().rsplit(".", 1)[-1]
+    name = name.strip("<>'\" ")
+    bits = None
+    if name == "double":
+        bits = 64
+    elif name in ("single", "half"):
+        bits = 32 if name == "single" else 16
+    else:
+        m = _WIDTH.search(name)
+        if m:
+            bits = int(m.group(1)) if m.group(1) else 8 * int(m.group(2))
+    if bits == 32:
         raise ValueError("GPmp supports float64 only (float32 is not supported).")
-    if "float64" in s or "double" in s or s.endswith("f8") or s.endswith("64"):
-        return "float64"
-    raise ValueError("dtype must resolve to float64")
+    if bits != 64:
+        raise ValueError(f"dtype {dtype!r} does not resolve to float64")
+    return "float64"
 
 
 def _normalize_backend_spec(backend):
@@ -31,6 +48,20 @@ def _normalize_backend_spec(backend):
     return b
 
 
+def _package_logger():
+    """One stream handler per process, level from GPMP_LOG_LEVEL (the knob of gpmp/config.py:111-117; this
+    package stays quiet by default and reports library loading / fallbacks of the fast paths at DEBUG)."""
+    log = logging.getLogger("gpmp_amd")
+    wanted = os.environ.get("GPMP_LOG_LEVEL", "WARNING").strip().upper()
+    level = logging.getLevelName(wanted)
+    log.setLevel(level if isinstance(level, int) else logging.WARNING)
+    if not any(isinstance(h, logging.StreamHandler) for h in log.handlers):
+        handler = logging.StreamHandler()
+        handler.setFormatter(logging.Formatter("gpmp_amd %(levelname)s: %(message)s"))
+        log.addHandler(handler)
+    return log
+
+
 class _GPMPConfig:
     def __init__(self):
         self.backend = "hip"
@@ -41,18 +72,13 @@ class _GPMPConfig:
         self.caches = {}
         # device bytes one prediction chunk (n x m_chunk cross-covariance) may take
         self.predict_chunk_bytes = int(float(os.environ.get("GPMP_HIP_CHUNK_GB", "24")) * (1 << 30))
-        self.logger = logging.getLogger("gpmp_amd")
-        if not self.logger.handlers:
-            h = logging.StreamHandler()
-            h.setFormatter(logging.Formatter("[%(levelname)s] %(message)s"))
-            self.logger.addHandler(h)
-        self.logger.setLevel(getattr(logging, os.environ.get("GPMP_LOG_LEVEL", "WARNING").upper(), logging.WARNING))
+        self.logger = _package_logger()
 
     def clear_caches(self, name=None):
-        if name is None:
-            self.caches.clear()
-        else:
-            self.caches.pop(name, None)
+        """Drop one named cache (e.g. "gammaln"), or all of them."""
+        doomed = list(self.caches) if name is None else [name]
+        for key in doomed:
+            self.caches.pop(key, None)
 
 
 _config = _GPMPConfig()

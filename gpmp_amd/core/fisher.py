@@ -71,12 +71,12 @@ def fisher_information_cpd(model, xi, covparam=None, epsilon: float = 1e-3):
     F = gnp.cholesky_factor(gnp.asarray(model.covariance(xi, xi, theta)), overwrite=True)
     P = _mean_values(model, xi, model.meanparam)
     U = F.solve(P)                                   # n x q
-    S = P.T @ U
-    US = U @ torch.linalg.inv(0.5 * (S + S.T))       # n x q
+    S = gnp.matmul(P, U, ta=True)                    # q x q = P^T K^-1 P (library GEMM)
+    US = gnp.matmul(U, torch.linalg.inv(0.5 * (S + S.T)))   # n x q
     B = []
     for D in _derivative_matrices(model, xi, theta, epsilon):
         KD = F.solve(D)
-        B.append(KD - US @ (U.T @ D))
+        B.append(KD - gnp.matmul(US, gnp.matmul(U, D, ta=True)))
     return _pairwise_half_traces(B)
 
 

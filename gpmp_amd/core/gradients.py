@@ -90,8 +90,8 @@ class REMLAnalytic:
         X = F.solve_lower(ms.W, trans=True)           # K^-1 [z, P]
         alpha, U = X[:, 0], X[:, 1:]
         Sinv = numpy.linalg.inv(ms.S)
-        US = U @ gnp.asarray(Sinv)                    # n x q
-        beta = alpha - US @ gnp.asarray(ms.b)         # Qinv z
+        US = gnp.matmul(U, gnp.asarray(Sinv))         # n x q on the library GEMM
+        beta = alpha - gnp.matmul(US, gnp.asarray(ms.b))   # Qinv z
         Fm = gnp.hstack((US, beta.reshape(-1, 1)))
         Gm = gnp.hstack((U, beta.reshape(-1, 1)))
         Kinv = F.inverse_lower()

@@ -10,6 +10,10 @@ solve that the posterior mean and variance need,
 instead of the reference's two trsm (kriging.py:62) / the dense (n+q) sysv solve (kriging.py:98-109).
 The kriging weights lambda_t = L^-T (V - Wp mu) cost a second solve and are only formed on request.
 xt is processed in column chunks so that the n x m_chunk cross-covariance fits the configured budget.
+
+When K has no Cholesky factor (a conditionally positive definite kernel such as a variogram, where the
+reference's sysv block solve still answers) or P^T K^-1 P cannot be inverted, universal kriging falls back
+to the contrast space (the role of gpmp/core/kriging.py:116,202-257): ``_ContrastPredictor`` below.
 """
 import numpy
 import torch
@@ -51,7 +55,10 @@ class _Predictor:
             S = g[1:, 1:]
             self.S = 0.5 * (S + S.T)
             self.b = g[1:, 0]                               # Wp^T w
-            self.Sinv = torch.linalg.inv(self.S)            # q x q, plumbing-sized
+            ev = torch.linalg.eigvalsh(self.S)              # q x q, plumbing-sized
+            if not float(ev[0]) > self.q * gnp.eps * float(ev[-1]):
+                raise numpy.linalg.LinAlgError("P^T K^-1 P is singular to working precision (rank-deficient mean design)")
+            self.Sinv = torch.linalg.inv(self.S)
 
     def chunk(self, xt, want_lambda, want_var=True):
         model = self.model
@@ -67,8 +74,8 @@ class _Predictor:
         if self.q:
             Pt = _mean_values(model, xt, model.meanparam)   # m x q
             R = D[1:-1] - Pt.T                                  # S mu
-            mu = self.Sinv @ R                                  # q x m
-            mean = mean - self.b @ mu
+            mu = gnp.matmul(self.Sinv, R)                       # q x m
+            mean = mean - gnp.matmul(self.b, mu)
             reduction = reduction - torch.sum(mu * R, dim=0)
         lam = None
         if want_lambda:
@@ -86,10 +93,130 @@ class _Predictor:
         return mean, reduction, lam, mu
 
 
-def _run(model, xi, zi_centered, xt, use_mean, want_lambda):
+class _Reflectors:
+    """Householder QR of the n x q mean design, P = Q [R; 0] with Q = H_0 ... H_{q-1}, H_k = I - tau_k v_k v_k^T.
+    Q (n x n in the reference: gpmp/core/kriging.py:229, linalg.py:68-70) is never formed: its action on an n x m
+    matrix is q rank-one updates on the library GEMM, and Q^T K Q is q symmetric rank-two updates."""
+
+    def __init__(self, P):
+        A = gnp.asarray(P).clone()
+        n, q = A.shape
+        if q >= n:
+            raise numpy.linalg.LinAlgError("mean design has at least as many columns as observations")
+        self.n, self.q, self.v, self.tau = n, q, [], []
+        scale = [float(torch.linalg.vector_norm(A[:, k])) for k in range(q)]
+        for k in range(q):
+            x = A[k:, k]
+            nx = float(torch.linalg.vector_norm(x))
+            if not nx > n * gnp.eps * scale[k]:
+                raise numpy.linalg.LinAlgError("singular mean design: P is rank deficient")
+            alpha = -nx if float(x[0]) >= 0.0 else nx
+            v = gnp.zeros((n,))
+            v[k:] = x
+            v[k] -= alpha
+            tau = 2.0 / float(torch.sum(v * v))
+            A[:, k:] -= tau * v.reshape(-1, 1) * torch.sum(v.reshape(-1, 1) * A[:, k:], dim=0).reshape(1, -1)   # O(n q)
+            self.v.append(v)
+            self.tau.append(tau)
+        self.R = torch.triu(A[:q, :q])
+
+    def _rank_update(self, B, cols_a, cols_b):
+        """B -= [a_1 .. a_r] [b_1 .. b_r]^T on the library GEMM (B n x m in place; a_j: n, b_j: m)."""
+        lib = gnp._lib.load()
+        A_ = gnp.as_matrix(torch.stack(cols_a, dim=1), copy=True)
+        B_ = gnp.as_matrix(torch.stack(cols_b, dim=1), copy=True)
+        gnp._lib.check(lib.gpmp_dgemm(0, 1, B.shape[0], B.shape[1], len(cols_a), -1.0, gnp._ptr(A_), gnp._ld(A_), gnp._ptr(B_),
+                                      gnp._ld(B_), 1.0, gnp._ptr(B), gnp._ld(B), 0, gnp._stream()), "gpmp_dgemm")
+
+    def apply(self, B, transpose):
+        """B <- Q^T B (transpose) or Q B, in place; B is an n x m matrix."""
+        order = range(self.q) if transpose else range(self.q - 1, -1, -1)
+        for k in order:
+            c = gnp.coldots(B, self.v[k].reshape(-1, 1))[0]          # v^T B
+            self._rank_update(B, [self.tau[k] * self.v[k]], [c])
+        return B
+
+    def congruence(self, K):
+        """K <- Q^T K Q in place (K symmetric, full storage)."""
+        for k in range(self.q):
+            v, tau = self.v[k], self.tau[k]
+            w = gnp.matmul(K, v)
+            s = float(torch.sum(v * w))
+            u = tau * w - (0.5 * tau * tau * s) * v
+            self._rank_update(K, [v, u], [u, v])
+        return K
+
+
+class _ContrastPredictor:
+    """Universal kriging in the contrast space Null(P^T), for covariances that are only conditionally positive
+    definite.  With lambda = Q [beta; a] (first q coordinates fixed by the unbiasedness constraint R^T beta = Pt^T):
+
+        G a = (Q^T Kit)_2 - (Q^T K Q)_21 beta,      G = (Q^T K Q)_22   (= W^T K W, positive definite)
+        var = k_tt - 2 lambda^T Kit + lambda^T K lambda
+
+    which is the solution of the reference's block system (kriging.py:98-109).  ``reference_formula=True`` reproduces
+    the reference's own contrast route (kriging.py:202-257) instead: it solves G a = (Q^T Kit)_2 without the coupling
+    term and reports k_tt - [lambda; beta]^T [Kit; Pt^T] -- it differs from the block solve by O(1) whenever beta != 0
+    (tests/golden/ref_cpd.npz pins both)."""
+
+    def __init__(self, model, xi, zi_centered, reference_formula=False):
+        self.model, self.xi, self.ref = model, xi, reference_formula
+        P = _mean_values(model, xi, model.meanparam)
+        self.hq = _Reflectors(P)
+        q = self.q = self.hq.q
+        Kq = gnp.as_matrix(gnp.asarray(model.covariance(xi, xi, model.covparam)), copy=True)
+        self.hq.congruence(Kq)
+        self.K11 = Kq[:q, :q].clone()
+        self.K21 = gnp.as_matrix(Kq[q:, :q], copy=True)                    # (n - q) x q
+        self.F = gnp.cholesky_factor(gnp.as_matrix(Kq[q:, q:], copy=True), overwrite=True)
+        del Kq
+        zq = self.hq.apply(gnp.as_matrix(zi_centered.reshape(-1, 1), copy=True), transpose=True).reshape(-1)
+        self.z1, self.z2 = zq[:q].clone(), zq[q:].clone()
+
+    def chunk(self, xt, want_lambda, want_var=True):
+        model, q = self.model, self.q
+        Kit = gnp.as_matrix(gnp.asarray(model.covariance(self.xi, xt, model.covparam)), copy=True)
+        self.hq.apply(Kit, transpose=True)                                  # Q^T Kit
+        Pt = _mean_values(model, xt, model.meanparam)                       # m x q
+        beta = torch.linalg.solve_triangular(self.hq.R.T.contiguous(), Pt.T.contiguous(), upper=False)   # q x m
+        C1 = Kit[:q].clone()
+        rhs = gnp.as_matrix(Kit[q:], copy=True)
+        if not self.ref:
+            rhs = rhs - gnp.matmul(self.K21, beta)
+        a = self.F.solve(rhs)                                               # (n - q) x m
+        mean = gnp.matmul(self.z1, beta) + gnp.matmul(self.z2, a)
+        # lambda^T Kit and lambda^T K lambda in the rotated coordinates (Q is orthogonal)
+        lk = torch.sum(beta * C1, dim=0) + torch.sum(a * Kit[q:], dim=0)
+        if self.ref:
+            reduction = lk + torch.sum(beta * Pt.T, dim=0)
+        else:
+            Ga = rhs                                                        # G a = rhs
+            lKl = torch.sum(beta * gnp.matmul(self.K11, beta), dim=0) + 2.0 * torch.sum(a * gnp.matmul(self.K21, beta), dim=0) \
+                + torch.sum(a * Ga, dim=0)
+            reduction = 2.0 * lk - lKl
+        lam = None
+        if want_lambda:
+            Z = gnp.alloc_matrix(self.hq.n, xt.shape[0])
+            Z[:q] = beta
+            Z[q:] = a
+            lam = self.hq.apply(Z, transpose=False)
+        return mean, reduction, lam, beta
+
+
+def _run(model, xi, zi_centered, xt, use_mean, want_lambda, contrast=None):
     n, m = xi.shape[0], xt.shape[0]
     mc = _chunk_cols(n, m)
-    pred = _Predictor(model, xi, zi_centered, use_mean, xt_first=xt[: max(mc, 1)] if m > 0 else None)
+    if contrast is not None:
+        pred = _ContrastPredictor(model, xi, zi_centered, reference_formula=(contrast == "reference"))
+    else:
+        try:
+            pred = _Predictor(model, xi, zi_centered, use_mean, xt_first=xt[: max(mc, 1)] if m > 0 else None)
+        except (numpy.linalg.LinAlgError, torch.linalg.LinAlgError):
+            # K has no Cholesky factor / P^T K^-1 P is singular: with a mean design the contrast space may still be
+            # positive definite (conditionally positive definite kernels); without one the reference raises as well
+            if not use_mean:
+                raise
+            pred = _ContrastPredictor(model, xi, zi_centered)
     means, reds, lams, mus = [], [], [], []
     for j0 in range(0, m, max(mc, 1)):
         xtc = xt[j0 : j0 + mc]
@@ -105,7 +232,7 @@ def _run(model, xi, zi_centered, xt, use_mean, want_lambda):
     red = cat(reds) if reds else gnp.zeros((0,))
     lam = (cat(lams, 1) if lams else gnp.zeros((n, 0))) if want_lambda else None
     mu = cat(mus, 1) if mus else None
-    return mean, red, lam, mu
+    return mean, red, lam, mu, type(pred) is _ContrastPredictor and not pred.ref
 
 
 def _prior_variance(model, xt):
@@ -116,7 +243,7 @@ def kriging_predictor_with_zero_mean(model, xi, xt, return_type=0):
     """gpmp/core/kriging.py:35-67 -> (lambda_t, posterior variance | covariance | None)."""
     xi, xt = gnp.asarray(xi), gnp.asarray(xt)
     zero = gnp.zeros((xi.shape[0],))
-    _, red, lam, _ = _run(model, xi, zero, xt, use_mean=False, want_lambda=True)
+    _, red, lam, _, _ = _run(model, xi, zero, xt, use_mean=False, want_lambda=True)
     return lam, _posterior_variance(model, xi, xt, lam, None, red, return_type)
 
 
@@ -124,12 +251,21 @@ def kriging_predictor(model, xi, xt, return_type=0):
     """gpmp/core/kriging.py:70-116 (universal kriging) through the Schur complement of the block system."""
     xi, xt = gnp.asarray(xi), gnp.asarray(xt)
     zero = gnp.zeros((xi.shape[0],))
-    _, red, lam, mu = _run(model, xi, zero, xt, use_mean=True, want_lambda=True)
-    return lam, _posterior_variance(model, xi, xt, lam, mu, red, return_type)
+    _, red, lam, mu, general = _run(model, xi, zero, xt, use_mean=True, want_lambda=True)
+    return lam, _posterior_variance(model, xi, xt, lam, mu, red, return_type, general=general)
 
 
-def _posterior_variance(model, xi, xt, lam, mu, red, return_type):
-    """gpmp/core/kriging.py:170-199."""
+def _kriging_predictor_nullspace(model, xi, xt, return_type=0):
+    """gpmp/core/kriging.py:202-257, formula for formula (see ``_ContrastPredictor``: ``reference_formula``)."""
+    xi, xt = gnp.asarray(xi), gnp.asarray(xt)
+    zero = gnp.zeros((xi.shape[0],))
+    _, red, lam, beta, _ = _run(model, xi, zero, xt, use_mean=True, want_lambda=True, contrast="reference")
+    return lam, _posterior_variance(model, xi, xt, lam, beta, red, return_type)
+
+
+def _posterior_variance(model, xi, xt, lam, mu, red, return_type, general=False):
+    """gpmp/core/kriging.py:170-199.  ``general``: lambda came from the contrast-space fallback, where no Lagrange
+    multipliers exist; the full covariance is then Ktt - lambda^T Kit - Kit^T lambda + lambda^T K lambda."""
     if return_type == -1:
         return None
     if return_type == 0:
@@ -137,10 +273,14 @@ def _posterior_variance(model, xi, xt, lam, mu, red, return_type):
     if return_type == 1:
         Ktt = gnp.asarray(model.covariance(xt, None, model.covparam, pairwise=False))
         Kit = gnp.asarray(model.covariance(xi, xt, model.covparam))
-        cov = Ktt - gnp.matmul(lam.T.contiguous(), Kit)
+        LtK = gnp.matmul(lam, Kit, ta=True)
+        if general:
+            Kii = gnp.asarray(model.covariance(xi, xi, model.covparam))
+            return Ktt - LtK - LtK.T + gnp.matmul(lam, gnp.matmul(Kii, lam), ta=True)
+        cov = Ktt - LtK
         if mu is not None:
             Pt = _mean_values(model, xt, model.meanparam)
-            cov = cov - mu.T @ Pt.T
+            cov = cov - gnp.matmul(mu, Pt, ta=True, tb=True)
         return cov
     raise ValueError("return_type must be in {-1, 0, 1}")
 
@@ -167,6 +307,6 @@ def select_predictor(model, xi, zi, xt, return_lambdas=True):
         raise ValueError(
             f"Invalid meantype {model.meantype}. Supported types are 'zero', 'parameterized', and 'linear_predictor'."
         )
-    mean, red, lam, _ = _run(model, xi, zi_centered, xt, use_mean, return_lambdas)
+    mean, red, lam, _, _ = _run(model, xi, zi_centered, xt, use_mean, return_lambdas)
     var = _prior_variance(model, xt) - red
     return zi_centered, zt_prior_mean, lam, var, mean

@@ -16,10 +16,10 @@ def negative_log_likelihood_zero_mean(model, covparam, xi, zi):
     """gpmp/core/likelihood.py:18-52: 1/2 (n ln 2pi + 2 sum ln L_ii + z^T K^-1 z)."""
     xi, zi = gnp.asarray(xi), gnp.asarray(zi).reshape(-1)
     n = xi.shape[0]
-    try:
-        F = covariance_factor(model, xi, covparam)
-    except RuntimeError:
-        return gnp.safe_inf()
+    # a non-PD covariance raises HipLinAlgError (a numpy LinAlgError), as numpy.linalg.cholesky does under the reference's
+    # NumPy backend; the criterion wrappers (gnp.DifferentiableSelectionCriterion) turn it into +inf.  Library / HIP
+    # failures (GpmpHipError, out of memory) propagate: they are not numerical events.
+    F = covariance_factor(model, xi, covparam)
     w = F.solve_lower(zi)
     norm2 = float(gnp.sum(w * w).item())
     return _scalar(0.5 * (n * math.log(2.0 * math.pi) + F.logdet() + norm2))
@@ -35,10 +35,10 @@ def negative_log_likelihood(model, meanparam, covparam, xi, zi):
 def negative_log_restricted_likelihood(model, covparam, xi, zi):
     """gpmp/core/likelihood.py:92-129 without the n x n Q / W^T K W (identities in core/linalg.py)."""
     xi, zi = gnp.asarray(xi), gnp.asarray(zi).reshape(-1)
-    try:
-        F = covariance_factor(model, xi, covparam)
-    except RuntimeError:
-        return gnp.safe_inf()
+    # a non-PD covariance raises HipLinAlgError (a numpy LinAlgError), as numpy.linalg.cholesky does under the reference's
+    # NumPy backend; the criterion wrappers (gnp.DifferentiableSelectionCriterion) turn it into +inf.  Library / HIP
+    # failures (GpmpHipError, out of memory) propagate: they are not numerical events.
+    F = covariance_factor(model, xi, covparam)
     P = _mean_values(model, xi, model.meanparam)
     n, q = P.shape
     ms = MeanSpace(F, zi, P)

@@ -46,10 +46,11 @@ def _loo_with_linear_predictor_mean_cpd(model, meanparam, covparam, xi, zi):
     Y = gnp.hstack((zi.reshape(-1, 1), P))
     d, X = _kinv_diag_and_solve(model, covparam, xi, Y)
     Kinv_z, U = X[:, 0], X[:, 1:]
-    S = P.T @ U                                  # q x q
+    G = gnp.coldots(U, Y)[:-1]                   # (1 + q) x q: rows z^T U, P^T U  (one pass over U)
+    S = G[1:]                                    # q x q = P^T K^-1 P
     S = 0.5 * (S + S.T)
-    US = U @ torch.linalg.inv(S)                 # n x q
-    Qinv_z = Kinv_z - US @ (U.T @ zi.reshape(-1))
+    US = gnp.matmul(U, torch.linalg.inv(S))      # n x q on the library GEMM
+    Qinv_z = Kinv_z - gnp.matmul(US, G[0])
     Qinv_diag = d - torch.sum(US * U, dim=1)
     eloo = Qinv_z / Qinv_diag
     return zi - eloo, 1.0 / Qinv_diag, eloo

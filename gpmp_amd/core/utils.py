@@ -1,43 +1,57 @@
-"""Input contract of the Model entry points -- counterpart of gpmp/core/utils.py."""
+"""Input contract of the Model entry points -- counterpart of gpmp/core/utils.py.
+
+Same observable behaviour as the reference (gpmp/core/utils.py:19-118): shape violations are
+``AssertionError``s, an inconsistent mean specification is a ``ValueError`` / ``TypeError``; the checks
+themselves are written as a small rule table instead of a chain of statements.
+"""
 from .. import num as gnp
+
+_MEAN_TYPES = ("zero", "parameterized", "linear_predictor")
+
+
+def _rank(a):
+    return len(a.shape)
+
+
+def _require(ok, what):
+    if not ok:
+        raise AssertionError(what)
 
 
 def ensure_shapes_and_type(*, xi=None, zi=None, xt=None, convert: bool = True):
-    """gpmp/core/utils.py:19-81: 2-D xi / xt, zi (n,) or (n,1) -> (n,), matching row / column counts."""
-    if xi is not None:
-        assert len(xi.shape) == 2, "xi should be a 2D array"
-    if zi is not None:
-        if len(zi.shape) == 2:
-            assert zi.shape[1] == 1, "zi should only have one column if it's a 2D array"
+    """(xi, zi, xt) -> the same triple, checked and (optionally) moved to backend arrays.
+
+    Rules (gpmp/core/utils.py:19-81): points are (n, d) / (m, d) matrices sharing d; observations are a
+    vector of length n, a single-column matrix being flattened first."""
+    have = {name: a is not None for name, a in (("xi", xi), ("zi", zi), ("xt", xt))}
+    for name, pts in (("xi", xi), ("xt", xt)):
+        if have[name]:
+            _require(_rank(pts) == 2, f"{name} must be a 2-D array of points (got {_rank(pts)}-D)")
+    if have["zi"]:
+        r = _rank(zi)
+        _require(r in (1, 2), "zi must be a vector or a one-column matrix")
+        if r == 2:
+            _require(zi.shape[1] == 1, f"zi has {zi.shape[1]} columns; only one is allowed")
             zi = zi.reshape(-1)
-        else:
-            assert len(zi.shape) == 1, "zi should be 1D or a 2D column array"
-    if xt is not None:
-        assert len(xt.shape) == 2, "xt should be a 2D array"
-    if xi is not None and zi is not None:
-        assert xi.shape[0] == zi.shape[0], "xi and zi must have the same number of rows"
-    if xi is not None and xt is not None:
-        assert xi.shape[1] == xt.shape[1], "xi and xt must have the same number of columns"
-    if convert:
-        if xi is not None:
-            xi = gnp.asarray(xi)
-        if zi is not None:
-            zi = gnp.asarray(zi)
-        if xt is not None:
-            xt = gnp.asarray(xt)
-    return xi, zi, xt
+    if have["xi"] and have["zi"]:
+        _require(xi.shape[0] == zi.shape[0], f"xi has {xi.shape[0]} rows but zi has {zi.shape[0]} values")
+    if have["xi"] and have["xt"]:
+        _require(xi.shape[1] == xt.shape[1], f"xi is {xi.shape[1]}-dimensional but xt is {xt.shape[1]}-dimensional")
+    if not convert:
+        return xi, zi, xt
+    return tuple(gnp.asarray(a) if a is not None else None for a in (xi, zi, xt))
 
 
 def validate_model_mean(meantype: str, mean, meanparam):
-    """gpmp/core/utils.py:84-118."""
-    if meantype not in {"zero", "parameterized", "linear_predictor"}:
-        raise ValueError("meantype must be one of 'zero', 'parameterized', or 'linear_predictor'")
-    if meantype == "zero" and mean is not None:
-        raise ValueError("For meantype 'zero', mean must be None")
-    if meantype in ["parameterized", "linear_predictor"] and not callable(mean):
-        raise TypeError(
-            "For meantype 'parameterized' or 'linear_predictor', mean must be a callable function"
-        )
+    """Constructor-time check of the mean specification (gpmp/core/utils.py:84-118): a "zero" model carries
+    no mean function, the two other kinds need a callable; ``meanparam`` is not inspected here."""
+    if meantype not in _MEAN_TYPES:
+        raise ValueError(f"unknown meantype {meantype!r}: expected one of {', '.join(_MEAN_TYPES)}")
+    if meantype == "zero":
+        if mean is not None:
+            raise ValueError("a 'zero' mean model takes mean=None")
+    elif not callable(mean):
+        raise TypeError(f"meantype {meantype!r} needs a callable mean(x, meanparam)")
 
 
 def mean_values(model, x, param):
@@ -45,8 +59,6 @@ def mean_values(model, x, param):
     slice of it, ``model.meanparam``); user mean functions combine them with device arrays (``param * gnp.ones(...)``,
     examples/gpmp_example22_1d_interpolation_variation_ml.py:38-39), so they are moved to the device first."""
     import torch
-
-    from .. import num as gnp
 
     if param is not None and not isinstance(param, torch.Tensor):
         param = gnp.asarray(param)

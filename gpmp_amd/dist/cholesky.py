@@ -431,7 +431,9 @@ class BlockCyclicCholesky:
             Lkk.copy_(D)
             inf.copy_(info.to(torch.float64))
         if g.pr > 1:
-            self._bcast(dbuf, g.rank_of(rd, cd), g.col_group, col_members)
+            # its own communicator (grid.diag_col_group): issued from the diagonal stream with look-ahead, from the side
+            # stream without -- never interleaved with the column exchange's collectives on g.col_group
+            self._bcast(dbuf, g.rank_of(rd, cd), g.diag_col_group, col_members)
         self._info_acc[k: k + 1].copy_(inf)
         self.diag_cache[k] = (Lkk, dinv)
         return Lkk, dinv
@@ -527,9 +529,20 @@ class BlockCyclicCholesky:
         st = self._st = _Streams(getattr(ops, "device", None), self.reserve_cus if self.lookahead else 0, getattr(ops, "lib", None))
         ev_main_prev = None
         start = st.record(False)
+        d0 = None
+        if self.lookahead and g.c == g.owner_col(0):
+            # the first diagonal block too goes out from the diagonal stream: grid.diag_col_group is then used from that
+            # stream only, g.col_group / g.row_group from the side stream only
+            with st.diag_ctx():
+                st.wait_diag(start)
+                with self._phase("diag"):
+                    d0 = self._diagonal_block(0, g.owner_row(0), g.owner_col(0), self.bs(0), [g.rank_of(rr, g.c) for rr in range(g.pr)])
+                ev_d0 = st.record_diag()
         with st.side_ctx():
             st.wait(True, start)
-            bufs = self._prepare_panel(0)
+            if d0 is not None:
+                st.wait(True, ev_d0)
+            bufs = self._prepare_panel(0, diag=d0)
             ev_side = st.record(True)
         for k in range(nblk):
             panel, colop = bufs

@@ -13,6 +13,12 @@ class ProcessGrid:
         # one communicator per process row and per process column (every rank creates all of them)
         self.row_groups = [dist.new_group([rr * pc + cc for cc in range(pc)]) for rr in range(pr)]
         self.col_groups = [dist.new_group([rr * pc + cc for rr in range(pr)]) for cc in range(pc)]
+        # a second communicator per process column, used ONLY for the diagonal-block broadcast of the look-ahead
+        # Cholesky: that broadcast is enqueued from the diagonal stream while the column exchange of the same process
+        # column is enqueued from the side stream.  With one communicator both would serialise on its internal stream in
+        # host issue order (correct, but the critical-path diagonal block would queue behind a bulk exchange); with two,
+        # every communicator is only ever used from ONE stream and the two kinds of traffic are independent.
+        self.diag_col_groups = [dist.new_group([rr * pc + cc for rr in range(pr)]) for cc in range(pc)]
         self.world_group = group
 
     @staticmethod
@@ -34,6 +40,10 @@ class ProcessGrid:
     @property
     def col_group(self):
         return self.col_groups[self.c]
+
+    @property
+    def diag_col_group(self):
+        return self.diag_col_groups[self.c]
 
     # ---- block-cyclic maps: global block index -> (owner coordinate, local block index)
     def owner_row(self, I: int) -> int:

@@ -34,7 +34,6 @@ from .parameter_selection import (
     update_parameters_with_remap_with_power_laws_prior,
 )
 from .bounds import empirical_bounds_factory
-from .exponential import exponential_kernel
 from .utils import check_xi_zi_or_loader, prepare_data
 from .prior_helpers import compute_logrho_min_from_xi, resolve_covparam0_roles_for_update
 from .priors import (
@@ -67,6 +66,6 @@ __all__ = [
     "update_parameters_with_criterion", "update_parameters_with_ml_constant_mean", "update_parameters_with_reml",
     "update_parameters_with_remap", "select_parameters_with_remap_gaussian_logsigma2",
     "update_parameters_with_remap_gaussian_logsigma2", "update_parameters_with_remap_gaussian_logsigma2_and_logrho_prior",
-    "update_parameters_with_remap_with_power_laws_prior", "empirical_bounds_factory", "exponential_kernel",
+    "update_parameters_with_remap_with_power_laws_prior", "empirical_bounds_factory",
     "check_xi_zi_or_loader", "prepare_data", "log_prior_reference", "resolve_covparam0_roles_for_update",
 ]

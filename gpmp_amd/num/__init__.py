@@ -505,25 +505,28 @@ def svd(A, full_matrices=True, hermitian=True):
     return torch.linalg.svd(asarray(A), full_matrices=full_matrices)
 
 
-def matmul(A, B):
-    """Dense product on the library's fp64 MFMA GEMM (2-D x 2-D; 1-D operands become columns/rows)."""
+def matmul(A, B, ta=False, tb=False):
+    """Dense product op(A) op(B) on the library's fp64 MFMA GEMM (2-D x 2-D; 1-D operands become columns / rows).
+    ``ta`` / ``tb``: use the stored matrix transposed (no copy) -- the P^T U, U^T D products of the mean-space algebra."""
     lib = _lib.load()
     A, B = asarray(A), asarray(B)
     va, vb = A.dim() == 1, B.dim() == 1
-    Am = as_matrix(A.reshape(1, -1) if va else A)
-    Bm = as_matrix(B.reshape(-1, 1) if vb else B)
-    M, K = Am.shape
-    K2, N = Bm.shape
+    Am = as_matrix((A.reshape(-1, 1) if ta else A.reshape(1, -1)) if va else A)
+    Bm = as_matrix((B.reshape(1, -1) if tb else B.reshape(-1, 1)) if vb else B)
+    M, K = (Am.shape[1], Am.shape[0]) if ta else Am.shape
+    K2, N = (Bm.shape[1], Bm.shape[0]) if tb else Bm.shape
     if K != K2:
         raise ValueError("matmul: inner dimensions differ")
     C = alloc_matrix(M, N)
-    _lib.check(lib.gpmp_dgemm(0, 0, M, N, K, 1.0, _ptr(Am), _ld(Am), _ptr(Bm), _ld(Bm), 0.0, _ptr(C), _ld(C), 0, _stream()),
-               "gpmp_dgemm")
+    if M == 0 or N == 0:
+        return C
+    if K == 0:
+        return C.zero_()
+    _lib.check(lib.gpmp_dgemm(1 if ta else 0, 1 if tb else 0, M, N, K, 1.0, _ptr(Am), _ld(Am), _ptr(Bm), _ld(Bm), 0.0, _ptr(C),
+                              _ld(C), 0, _stream()), "gpmp_dgemm")
     if va and vb:
         return C.reshape(())
-    if va:
-        return C.reshape(-1)
-    if vb:
+    if va or vb:
         return C.reshape(-1)
     return C
 

@@ -195,9 +195,40 @@ def kriging_predictor(model, xi, xt, return_type=0):
     Kit = model.covariance(xi, xt, model.covparam)
     Pt = model.mean(xt, model.meanparam)
     RHS = np.vstack((Kit, Pt.T))
-    lambdamu_t = _sp_solve(LHS, RHS, overwrite_a=True, overwrite_b=False, assume_a="sym")
-    lambda_t = lambdamu_t[0:ni, :]
-    return lambda_t, _posterior_variance(model, xt, lambdamu_t, RHS, return_type)
+    try:
+        lambdamu_t = _sp_solve(LHS, RHS, overwrite_a=True, overwrite_b=False, assume_a="sym")
+        lambda_t = lambdamu_t[0:ni, :]
+        return lambda_t, _posterior_variance(model, xt, lambdamu_t, RHS, return_type)
+    except Exception:                                       # kriging.py:115-116
+        return _kriging_predictor_nullspace(model, xi, xt, return_type)
+
+
+def _kriging_predictor_nullspace(model, xi, xt, return_type=0):
+    """gpmp/core/kriging.py:202-257, formula for formula: complete QR of P, G = W^T K W, alpha = G^-1 W^T Kit,
+    beta = R_q^-T Pt^T, lambda = W alpha + Q1 beta, variance k_tt - [lambda; beta]^T [Kit; Pt^T]."""
+    K = model.covariance(xi, xi, model.covparam)
+    P = model.mean(xi, model.meanparam)
+    n, q = P.shape
+    Kit = model.covariance(xi, xt, model.covparam)
+    Pt = model.mean(xt, model.meanparam)
+    Q, R = np.linalg.qr(P, mode="complete")
+    Q1, W = Q[:, :q], Q[:, q:]
+    Rq = R[:q, :q]
+    G = W.T @ (K @ W)
+    alpha, _ = cholesky_solve(G, W.T @ Kit)
+    beta = _sp_solve(Rq.T, Pt.T, assume_a="sym")
+    lambda_t = W @ alpha + Q1 @ beta
+    if return_type == -1:
+        return lambda_t, None
+    RHS = np.vstack((Kit, Pt.T))
+    LM = np.vstack((lambda_t, beta))
+    if return_type == 0:
+        v0 = model.covariance(xt, xt, model.covparam, pairwise=True)
+        return lambda_t, v0 - np.einsum("i..., i...", LM, RHS)
+    if return_type == 1:
+        V0 = model.covariance(xt, xt, model.covparam, pairwise=False)
+        return lambda_t, V0 - LM.T @ RHS
+    raise ValueError("return_type must be in {-1,0,1}")
 
 
 def predict(model, xi, zi, xt, return_lambdas=False, zero_neg_variances=True):

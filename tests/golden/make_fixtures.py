@@ -314,6 +314,44 @@ def gen_remap_extra(out):
     out["rx_contrast_proj"] = tonp(gnp.matmul(W, W.T))          # the projector is unique, W is not
 
 
+
+def gen_cpd(out):
+    """Universal kriging with a covariance that is only CONDITIONALLY positive definite: k(x, y) = -||invrho (x - y)||
+    (the linear variogram, CPD with respect to constants).  K itself is indefinite (zero diagonal), so a Cholesky of K
+    does not exist; the reference's block system [[K, P], [P^T, 0]] is solved by LAPACK sysv (kriging.py:98-109) and the
+    contrast-space route (kriging.py:202-257) answers as well.  Both are pinned."""
+    from gpmp.core import kriging as rk
+
+    def variogram(x, y, covparam, pairwise=False):
+        if y is x or y is None:
+            if pairwise:
+                return gnp.zeros((x.shape[0],))
+            return -gnp.exp(covparam[0]) * gnp.scaled_distance(covparam[1:], x, x)
+        if pairwise:
+            return -gnp.exp(covparam[0]) * gnp.scaled_distance_elementwise(covparam[1:], x, y)
+        return -gnp.exp(covparam[0]) * gnp.scaled_distance(covparam[1:], x, y)
+
+    for tag, (n, m, d), mean in (("c", (60, 25, 2), constant_mean), ("l", (150, 40, 3), constant_mean)):
+        xi, zi = make_xz(n, d, 31)
+        xt, _ = make_xz(m, d, 32)
+        th = theta_aniso(d, sigma2=1.3)
+        model = gp.core.Model(mean, variogram, None, th, "linear_predictor")
+        zpm, zpv, lam = model.predict(xi, zi, xt, return_lambdas=True)
+        lam_ns, var_ns = rk._kriging_predictor_nullspace(model, xi, xt, 0)
+        _, cov_ns = rk._kriging_predictor_nullspace(model, xi, xt, 1)
+        out[f"cpd_{tag}_xi"], out[f"cpd_{tag}_zi"], out[f"cpd_{tag}_xt"], out[f"cpd_{tag}_theta"] = xi, zi, xt, th
+        out[f"cpd_{tag}_zpm"], out[f"cpd_{tag}_zpv"], out[f"cpd_{tag}_lambda"] = zpm, zpv, lam
+        out[f"cpd_{tag}_ns_lambda"], out[f"cpd_{tag}_ns_var"], out[f"cpd_{tag}_ns_cov"] = tonp(lam_ns), tonp(var_ns), tonp(cov_ns)
+    # a positive definite case through the contrast-space route with a q = d + 1 linear mean: must agree with the block solve
+    xi, zi = make_xz(90, 3, 33)
+    xt, _ = make_xz(30, 3, 34)
+    th = theta_aniso(3, sigma2=0.7)
+    model = gp.core.Model(linear_mean, make_kernel(2), None, th, "linear_predictor")
+    lam_ns, var_ns = rk._kriging_predictor_nullspace(model, xi, xt, 0)
+    out["cpd_pd_xi"], out["cpd_pd_zi"], out["cpd_pd_xt"], out["cpd_pd_theta"] = xi, zi, xt, th
+    out["cpd_pd_ns_lambda"], out["cpd_pd_ns_var"] = tonp(lam_ns), tonp(var_ns)
+
+
 def numpy_pass():
     for name, fn in (("matern", gen_matern), ("predict", gen_predict), ("likelihood", gen_likelihood), ("example02", gen_example02), ("remap", gen_remap), ("fisher_paths", gen_fisher_paths)):
         out = {}
@@ -485,6 +523,12 @@ if __name__ == "__main__":
         o = {}
         gen_dataloader(o)
         path = os.path.join(HERE, "ref_dataloader.npz")
+        np.savez_compressed(path, **{k: np.asarray(v) for k, v in o.items()})
+        print("wrote", path, os.path.getsize(path), "bytes,", len(o), "arrays")
+    elif len(sys.argv) > 2 and sys.argv[2] == "cpd":
+        o = {}
+        gen_cpd(o)
+        path = os.path.join(HERE, "ref_cpd.npz")
         np.savez_compressed(path, **{k: np.asarray(v) for k, v in o.items()})
         print("wrote", path, os.path.getsize(path), "bytes,", len(o), "arrays")
     elif len(sys.argv) > 2 and sys.argv[2] == "remap_extra":

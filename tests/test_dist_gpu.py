@@ -21,11 +21,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, pr, pc, n, nb, out, transport, lookahead):
+def _worker(rank, world, port, pr, pc, n, nb, out, transport, lookahead, backend="gloo"):
     import torch.distributed as dist
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # gloo: every rank on the one test GPU; nccl (= RCCL): one GPU per rank
+    local = str(rank) if backend == "nccl" else "0"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=local,
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "nccl":
+        torch.cuda.set_device(int(local))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", int(local)))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import gpmp_amd.num as gnp
         from gpmp_amd.dist import BlockCyclicCholesky, HipLocalOps, ProcessGrid
@@ -58,13 +65,31 @@ def _worker(rank, world, port, pr, pc, n, nb, out, transport, lookahead):
                                                              (2, 2, 2000, 256, "p2p", True), (2, 2, 2000, 256, "bcast", False),
                                                              (1, 1, 4096, 512, "bcast", True)])
 def test_block_cyclic_cholesky_hip(tmp_path, pr, pc, n, nb, transport, lookahead):
+    _run_and_check(tmp_path, pr, pc, n, nb, transport, lookahead, "gloo")
+
+
+@pytest.mark.parametrize("pr,pc,n,nb,transport,lookahead", [(1, 1, 1500, 512, "bcast", True),
+                                                             (1, 2, 1500, 256, "bcast", True), (2, 1, 1500, 256, "p2p", True),
+                                                             (1, 2, 1500, 256, "p2p", False), (2, 1, 2000, 256, "bcast", False),
+                                                             (2, 2, 2000, 256, "p2p", True), (2, 2, 2000, 256, "bcast", True),
+                                                             (2, 4, 4000, 256, "bcast", True), (2, 4, 4000, 256, "p2p", True)])
+def test_block_cyclic_cholesky_rccl(tmp_path, pr, pc, n, nb, transport, lookahead):
+    """The same schedule over RCCL, one GPU per rank: both transports, look-ahead on and off.  Needs pr * pc GPUs --
+    skipped on the one-GPU boxes of this pool (only the 1 x 1 grid runs there), so until a multi-GPU node has run it
+    the RCCL path with more than one rank is unproven and bench.py keeps its distributed extra opt-in."""
+    if torch.cuda.device_count() < pr * pc:
+        pytest.skip(f"needs {pr * pc} GPUs, have {torch.cuda.device_count()}")
+    _run_and_check(tmp_path, pr, pc, n, nb, transport, lookahead, "nccl")
+
+
+def _run_and_check(tmp_path, pr, pc, n, nb, transport, lookahead, backend):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
 
     world = pr * pc
     out = str(tmp_path / "L.npy")
-    mp.spawn(_worker, args=(world, _free_port(), pr, pc, n, nb, out, transport, lookahead), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), pr, pc, n, nb, out, transport, lookahead, backend), nprocs=world, join=True)
     L = np.load(out)
     info, nll = np.load(out + ".meta.npy")
     x, z = make_xz(n, 4, 11)

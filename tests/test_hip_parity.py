@@ -1,7 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI) against (i) the golden vectors produced by the
 reference and (ii) the CPU oracle on seeded inputs.  fp64 tolerances, conditioning-aware
-(SURVEY.md section 8c): Gram entries rel 1e-14; NLL / REML rel 1e-10; posterior mean abs
-1e-9 |z|_inf; posterior variance abs 1e-9 sigma^2; gradients rel 1e-7 (vs the reference autograd).
+(SURVEY.md section 8c): Gram entries rel 1e-14; for cond(K) <= 1e6 NLL / REML rel 1e-12, posterior mean
+abs 1e-10 |z|_inf, posterior variance abs 1e-10 sigma^2, each scaled by cond(K) / 1e6 above that (``_cond_scale``
+measures it); gradients rel 1e-7 (vs the reference autograd).
 """
 import math
 import warnings
@@ -32,6 +33,15 @@ def gnp(gp):
     import gpmp_amd.num as gnp
 
     return gnp
+
+
+def _cond_scale(x, p, theta):
+    """max(1, cond(K) / 1e6) for the Matern covariance of the fixture (host eigenvalues): the factor by which the
+    SURVEY 8(c) tolerances grow with the conditioning."""
+    from oracle import gp_oracle as orc
+
+    ev = np.linalg.eigvalsh(orc.maternp_covariance(np.asarray(x), None, p, np.asarray(theta)))
+    return max(1.0, float(ev[-1] / max(ev[0], 1e-300)) / 1e6)
 
 
 def constant_mean(x, param):
@@ -476,13 +486,18 @@ def test_c_abi_nll_driver_reports_failure_as_inf(gnp):
 
 # ------------------------------------------------------------------------------ Matern / Gram
 def test_matern_kernel_grid(gp, gnp, golden):
+    """maternp_kernel on the whole grid of the fixture, h = 0, 1e-300 ... 400 and h = inf: inftobigf
+    (numpy_backend.py:250-252) turns inf into fmax / 1000, where the reference returns 0 for p <= 1 and NaN
+    (0 * overflowed polynomial) for p >= 2 -- the same pattern must come out of the device kernel."""
     g = golden("matern")
     h = g["matern_h"]
-    finite = np.isfinite(h)
+    assert np.isinf(h[-1])
     for p in (0, 1, 2, 3, 6, 10):
-        k = gnp.to_np(gp.kernel.maternp_kernel(p, h[finite]))
-        ref = g[f"matern_k_p{p}"][finite]
-        np.testing.assert_allclose(k, ref, rtol=2e-14, atol=1e-300)
+        k = gnp.to_np(gp.kernel.maternp_kernel(p, h))
+        ref = g[f"matern_k_p{p}"]
+        assert np.array_equal(np.isnan(k), np.isnan(ref)), (p, k[-2:], ref[-2:])
+        ok = ~np.isnan(ref)
+        np.testing.assert_allclose(k[ok], ref[ok], rtol=2e-14, atol=1e-300)
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
@@ -580,11 +595,12 @@ def test_predict_and_loo_vs_reference(gp, gnp, golden, tag):
     th, p, mp = g[f"pred_{tag}_theta"], int(g[f"pred_{tag}_p"]), g[f"pred_{tag}_meanparam"]
     zs = np.max(np.abs(zi))
     s2 = math.exp(th[0])
+    cs = _cond_scale(xi, p, th)
     for mt, model in _models(gp, p, th, mp).items():
         zpm, zpv, lam = model.predict(xi, zi, xt, return_lambdas=True)
         assert isinstance(zpm, np.ndarray) and zpm.shape == (len(xt),)
-        assert np.max(np.abs(zpm - g[f"pred_{tag}_{mt}_zpm"])) < 1e-9 * zs, mt
-        assert np.max(np.abs(zpv - g[f"pred_{tag}_{mt}_zpv"])) < 1e-9 * s2, mt
+        assert np.max(np.abs(zpm - g[f"pred_{tag}_{mt}_zpm"])) < 1e-10 * cs * zs, (mt, cs)
+        assert np.max(np.abs(zpv - g[f"pred_{tag}_{mt}_zpv"])) < 1e-10 * cs * s2, (mt, cs)
         assert rel_err(gnp.to_np(lam), g[f"pred_{tag}_{mt}_lambda"]) < 1e-7, mt
         zpm2, zpv2 = model.predict(xi, zi, xt)   # the one-solve route (no lambda)
         assert np.max(np.abs(zpm2 - zpm)) < 1e-10 * zs and np.max(np.abs(zpv2 - zpv)) < 1e-10 * s2
@@ -594,9 +610,53 @@ def test_predict_and_loo_vs_reference(gp, gnp, golden, tag):
         assert rel_err(gnp.to_np(el), g[f"loo_{tag}_{mt}_eloo"]) < 1e-8, mt
     m0 = _models(gp, p, th, mp)["zero"]
     lam, cov = m0.kriging_predictor_with_zero_mean(gnp.asarray(xi), gnp.asarray(xt), return_type=1)
-    assert np.max(np.abs(gnp.to_np(cov) - g[f"pred_{tag}_zero_fullcov"])) < 1e-9 * s2
+    assert np.max(np.abs(gnp.to_np(cov) - g[f"pred_{tag}_zero_fullcov"])) < 1e-10 * cs * s2
     zpm, _ = m0.predict(xi, zi.reshape(-1, 1), xt)
-    assert np.max(np.abs(zpm - g[f"pred_{tag}_zero_zpm_col"])) < 1e-9 * zs
+    assert np.max(np.abs(zpm - g[f"pred_{tag}_zero_zpm_col"])) < 1e-10 * cs * zs
+
+
+def test_universal_kriging_conditionally_positive_definite(gp, gnp, golden):
+    """K = -sigma^2 ||invrho (x - y)|| has no Cholesky factor: the reference answers through LAPACK sysv
+    (kriging.py:98-109); here the potrf failure sends universal kriging to the contrast space (Householder reflectors of
+    P, no n x n Q).  Also the reference's own contrast route (kriging.py:202-257), formula for formula."""
+    g = golden("cpd")
+
+    def variogram(x, y, covparam, pairwise=False):
+        s2 = math.exp(float(covparam[0]))
+        if y is x or y is None:
+            if pairwise:
+                return gnp.zeros((x.shape[0],))
+            return -s2 * gnp.scaled_distance(covparam[1:], x, x)
+        if pairwise:
+            return -s2 * gnp.scaled_distance_elementwise(covparam[1:], x, y)
+        return -s2 * gnp.scaled_distance(covparam[1:], x, y)
+
+    from gpmp_amd.core import kriging as kr
+
+    for tag in ("c", "l"):
+        xi, zi, xt, th = (g[f"cpd_{tag}_{k}"] for k in ("xi", "zi", "xt", "theta"))
+        model = gp.Model(constant_mean, variogram, None, th, "linear_predictor")
+        zpm, zpv, lam = model.predict(xi, zi, xt, return_lambdas=True)
+        assert np.max(np.abs(zpm - g[f"cpd_{tag}_zpm"])) < 1e-10 * np.max(np.abs(zi))
+        assert np.max(np.abs(zpv - g[f"cpd_{tag}_zpv"])) < 1e-10 * math.exp(th[0])
+        assert rel_err(gnp.to_np(lam), g[f"cpd_{tag}_lambda"]) < 1e-9
+        zpm2, zpv2 = model.predict(xi, zi, xt)                      # without forming lambda
+        assert np.max(np.abs(zpm2 - zpm)) < 1e-11 and np.max(np.abs(zpv2 - zpv)) < 1e-11
+        lam2, cov = model.kriging_predictor(gnp.asarray(xi), gnp.asarray(xt), return_type=1)
+        assert np.max(np.abs(np.diag(gnp.to_np(cov)) - g[f"cpd_{tag}_zpv"])) < 1e-10
+        lam_ns, var_ns = kr._kriging_predictor_nullspace(model, xi, xt, 0)
+        _, cov_ns = kr._kriging_predictor_nullspace(model, xi, xt, 1)
+        assert rel_err(gnp.to_np(lam_ns), g[f"cpd_{tag}_ns_lambda"]) < 1e-9
+        assert np.max(np.abs(gnp.to_np(var_ns) - g[f"cpd_{tag}_ns_var"])) < 1e-10
+        assert np.max(np.abs(gnp.to_np(cov_ns) - g[f"cpd_{tag}_ns_cov"])) < 1e-10
+    model = gp.Model(linear_mean, gp.kernel.MaternCovariance(2), None, g["cpd_pd_theta"], "linear_predictor")
+    lam_ns, var_ns = kr._kriging_predictor_nullspace(model, g["cpd_pd_xi"], g["cpd_pd_xt"], 0)
+    assert rel_err(gnp.to_np(lam_ns), g["cpd_pd_ns_lambda"]) < 1e-8 and np.max(np.abs(gnp.to_np(var_ns) - g["cpd_pd_ns_var"])) < 1e-9
+    # rank-deficient mean design: the reference raises (singular block system, then singular R in its contrast route)
+    dup = lambda x, p: gnp.hstack((gnp.ones((x.shape[0], 1)), gnp.ones((x.shape[0], 1))))  # noqa: E731
+    bad = gp.Model(dup, gp.kernel.MaternCovariance(2), None, g["cpd_pd_theta"], "linear_predictor")
+    with pytest.raises((np.linalg.LinAlgError, RuntimeError)):
+        bad.predict(g["cpd_pd_xi"], g["cpd_pd_zi"], g["cpd_pd_xt"])
 
 
 def test_predict_generic_callable_covariance(gp, gnp, golden):
@@ -666,8 +726,10 @@ def test_likelihoods_vs_reference(gp, gnp, golden, tag):
     mpm = gp.Model(param_mean, k, np.array([0.2, 0.5]), None, "parameterized")
     xit, zit = gnp.asarray(xi), gnp.asarray(zi)
     for i, t in enumerate(g[f"lik_{tag}_thetas"]):
+        cs = _cond_scale(xi, p, t)
+
         def close(a, b):
-            return abs(float(a) - float(b)) < 1e-10 * max(1.0, abs(float(b)))
+            return abs(float(a) - float(b)) < 1e-12 * cs * max(1.0, abs(float(b)))
         assert close(mz.negative_log_likelihood_zero_mean(t, xit, zit), g[f"lik_{tag}_nll"][i])
         assert close(mpm.negative_log_likelihood(np.array([0.2, 0.5]), t, xit, zit), g[f"lik_{tag}_nll_param"][i])
         assert close(mc.negative_log_restricted_likelihood(t, xit, zit), g[f"lik_{tag}_reml_const"][i])
@@ -842,7 +904,7 @@ def test_user_kernel_written_with_gnp_primitives(gp, gnp):
     om = orc.OracleModel(np_constant_mean, lambda x, y, t, pairwise=False: orc.noisy_maternp_covariance(x, y, 2, t, pairwise), None, th)
     ref = float(orc.negative_log_restricted_likelihood(om, th, xi, zi))
     for model in (user, decl):
-        assert abs(float(model.negative_log_restricted_likelihood(th, xi, zi)) - ref) < 1e-10 * abs(ref)
+        assert abs(float(model.negative_log_restricted_likelihood(th, xi, zi)) - ref) < 1e-12 * abs(ref)
     (m1, v1), (m2, v2) = user.predict(xi, zi, xt), decl.predict(xi, zi, xt)
     rm, rv = orc.predict(om, xi, zi, xt)[:2]
     for m_, v_ in ((m1, v1), (m2, v2)):
@@ -1024,7 +1086,6 @@ def test_remap_variants_bounds_reference_prior_contrasts(gp, gnp, golden):
     K = gnp.asarray(gnp.to_np(k(gnp.asarray(xi), None, c0)))
     G = L.compute_contrast_covariance(W, K)
     assert rel_err(gnp.to_np(G), gnp.to_np(W).T @ gnp.to_np(K) @ gnp.to_np(W)) < 1e-13
-    assert float(gnp.to_np(gp.kernel.exponential_kernel(np.array([0.0, 1.0])))[1]) == pytest.approx(math.exp(-1.0))
     assert gp.kernel.check_xi_zi_or_loader(xi, zi, None) == "arrays" and gp.kernel.prepare_data(xi, zi)[2:] == (90, 2, "arrays")
 
 
