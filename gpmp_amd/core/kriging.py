@@ -156,8 +156,8 @@ class _ContrastPredictor:
 
     which is the solution of the reference's block system (kriging.py:98-109).  ``reference_formula=True`` reproduces
     the reference's own contrast route (kriging.py:202-257) instead: it solves G a = (Q^T Kit)_2 without the coupling
-    term and reports k_tt - [lambda; beta]^T [Kit; Pt^T] -- it differs from the block solve by O(1) whenever beta != 0
-    (tests/golden/ref_cpd.npz pins both)."""
+    term, takes beta from diag(R) alone (see ``chunk``) and reports k_tt - [lambda; beta]^T [Kit; Pt^T] -- it differs
+    from the block solve by O(1) whenever beta != 0 (tests/golden/ref_cpd.npz pins both)."""
 
     def __init__(self, model, xi, zi_centered, reference_formula=False):
         self.model, self.xi, self.ref = model, xi, reference_formula
@@ -178,7 +178,12 @@ class _ContrastPredictor:
         Kit = gnp.as_matrix(gnp.asarray(model.covariance(self.xi, xt, model.covparam)), copy=True)
         self.hq.apply(Kit, transpose=True)                                  # Q^T Kit
         Pt = _mean_values(model, xt, model.meanparam)                       # m x q
-        beta = torch.linalg.solve_triangular(self.hq.R.T.contiguous(), Pt.T.contiguous(), upper=False)   # q x m
+        if self.ref:
+            # kriging.py:238 calls solve(Rq.T, Pt.T, assume_a="sym") on a TRIANGULAR matrix: SciPy's symmetric solver
+            # reads the upper triangle of Rq.T only, i.e. diag(Rq) -- exact for q = 1, not beyond.  Reproduced as is.
+            beta = Pt.T / torch.diagonal(self.hq.R).reshape(-1, 1)
+        else:
+            beta = torch.linalg.solve_triangular(self.hq.R.T.contiguous(), Pt.T.contiguous(), upper=False)   # q x m
         C1 = Kit[:q].clone()
         rhs = gnp.as_matrix(Kit[q:], copy=True)
         if not self.ref:
