@@ -12,6 +12,9 @@
 #include "common.h"
 #include <cstdlib>
 #include <cstdint>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace gpmp {
 namespace {
@@ -172,9 +175,11 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 #define GPMP_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 constexpr int TRSV_MAXBLK = 4096;                 // n <= 524288
-constexpr int TRSV_RING = 4;                      // concurrent calls on different streams use different state blocks
 // state block: [0] ticket, [1] abort, [2..3] pad, [4 + k] flag of row block k.  Zeroed by hipMemsetAsync before a launch.
-__device__ __attribute__((aligned(16))) unsigned int g_trsv_state[TRSV_RING][4 + TRSV_MAXBLK];
+// One block per (device, stream) that has ever run a one-launch solve, allocated on first use and kept (16.4 KB each):
+// solves on the same stream are ordered, solves on different streams never share a block, whatever their number in
+// flight.  [1] doubles as the sticky "a solve on this stream gave up" word read by gpmp_solve_status.
+constexpr size_t TRSV_STATE_WORDS = 4 + TRSV_MAXBLK;
 
 struct TrsvP {
   const double* L;
@@ -277,7 +282,11 @@ __global__ void __launch_bounds__(256) trsv_persist_kernel(TrsvP p) {
       __syncthreads();                     // xs is rewritten by the next tile
     }
     if (dead) {
-      if (t == 0) p.B[0] = __builtin_nan("");   // visible downstream: the solve did not complete
+      // a producer never published: this block (and, through the abort word, every later one) gives up.  Its rows of
+      // EVERY right-hand side become NaN, so nothing downstream can consume a half-solved vector silently; the abort
+      // word stays set in the stream's state block until gpmp_solve_status reads it.
+      if (half == 0 && i < rb)
+        for (int c = 0; c < p.m; ++c) p.B[(long)(j0 + i) * p.ldb + c] = __builtin_nan("");
       return;
     }
     // b_j - sum: the two half-row partial sums meet in LDS; the block's own rows of B hold the right-hand side
@@ -321,24 +330,56 @@ __global__ void __launch_bounds__(256) trsv_persist_kernel(TrsvP p) {
   }
 }
 
+struct StreamState { unsigned int* words; unsigned int* sticky; };
+std::mutex g_state_mu;
+std::map<std::pair<int, hipStream_t>, StreamState> g_states;
+std::map<int, int> g_ncu;
+
+int state_for(hipStream_t st, StreamState& out, int& ncu) {
+  int dev = 0;
+  GPMP_HIP_TRY(hipGetDevice(&dev));
+  auto it = g_states.find({dev, st});
+  if (it == g_states.end()) {
+    StreamState ns{nullptr, nullptr};
+    // [state words | sticky abort counter]: the counter survives the per-launch memset of the state words
+    GPMP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ns.words), sizeof(unsigned int) * (TRSV_STATE_WORDS + 4)));
+    GPMP_HIP_TRY(hipMemset(ns.words, 0, sizeof(unsigned int) * (TRSV_STATE_WORDS + 4)));
+    ns.sticky = ns.words + TRSV_STATE_WORDS;
+    it = g_states.emplace(std::make_pair(dev, st), ns).first;
+  }
+  auto nit = g_ncu.find(dev);
+  if (nit == g_ncu.end()) {
+    int v = 0;
+    GPMP_HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    nit = g_ncu.emplace(dev, v).first;
+  }
+  out = it->second;
+  ncu = nit->second;
+  return 0;
+}
+
+// abort word of the finished solve -> sticky counter of the stream (one thread; runs right behind the solve)
+__global__ void trsv_latch_kernel(const unsigned int* state, unsigned int* sticky) {
+  if (state[1] != 0u) sticky[0] += 1u;
+}
+
 template <int R>
 int run_persist(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int trans, hipStream_t st) {
-  static int ring = 0;
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0;
-    GPMP_HIP_TRY(hipGetDevice(&dev));
-    GPMP_HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
   const int nblk = (n + NB - 1) / NB;
-  static unsigned int* state_base = nullptr;
-  if (state_base == nullptr) GPMP_HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&state_base), HIP_SYMBOL(g_trsv_state)));
-  unsigned int* state = state_base + (size_t)(ring++ % TRSV_RING) * (4 + TRSV_MAXBLK);
-  GPMP_HIP_TRY(hipMemsetAsync(state, 0, sizeof(unsigned int) * (size_t)((4 + nblk + 3) / 4 * 4), st));
-  TrsvP p{L, ldl, dinv, B, ldb, n, m, nblk, state};
+  // memset + launch + latch must reach the stream as one unit: another host thread enqueueing a solve on the SAME stream
+  // in between would run on this solve's dirty state
+  std::lock_guard<std::mutex> lock(g_state_mu);
+  StreamState ss;
+  int ncu = 0;
+  int rc = state_for(st, ss, ncu);
+  if (rc) return rc;
+  GPMP_HIP_TRY(hipMemsetAsync(ss.words, 0, sizeof(unsigned int) * (size_t)((4 + nblk + 3) / 4 * 4), st));
+  TrsvP p{L, ldl, dinv, B, ldb, n, m, nblk, ss.words};
   const int grid = nblk < ncu ? nblk : ncu;
   if (!trans) hipLaunchKernelGGL((trsv_persist_kernel<R, false>), dim3(grid), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((trsv_persist_kernel<R, true>), dim3(grid), dim3(256), 0, st, p);
+  GPMP_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(trsv_latch_kernel, dim3(1), dim3(1), 0, st, ss.words, ss.sticky);
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -378,4 +419,25 @@ int trsv_few(const double* L, int n, long ldl, const double* dinv, double* B, in
   return run<4>(L, n, ldl, dinv, B, m, ldb, trans, st);
 }
 
+// Number of single-vector solves on `stream` that gave up since the last call (0 in any healthy run); synchronises the
+// stream.  status_host may be NULL (then only the return value is meaningful: 0 ok, > 0 count, < 0 error).
+int solve_status(hipStream_t st, int* status_host) {
+  std::lock_guard<std::mutex> lock(g_state_mu);
+  int dev = 0;
+  GPMP_HIP_TRY(hipGetDevice(&dev));
+  auto it = g_states.find({dev, st});
+  unsigned int v = 0;
+  if (it != g_states.end()) {
+    GPMP_HIP_TRY(hipStreamSynchronize(st));
+    GPMP_HIP_TRY(hipMemcpy(&v, it->second.sticky, sizeof(v), hipMemcpyDeviceToHost));
+    if (v != 0) GPMP_HIP_TRY(hipMemset(it->second.sticky, 0, sizeof(v)));
+  }
+  if (status_host) *status_host = (int)v;
+  return (int)v;
+}
+
 }  // namespace gpmp
+
+extern "C" int gpmp_solve_status(gpmp_stream_t stream, int* status_host) {
+  return gpmp::solve_status(gpmp::as_stream(stream), status_host);
+}

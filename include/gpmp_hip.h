@@ -207,6 +207,44 @@ int gpmp_predict_zero_mean(const double* xi, const double* zi, const double* xt,
                            const double* theta_host, int noise, int zero_neg_variances, double* ws,
                            double* zpm_dev, double* zpv_dev, int* info_dev, gpmp_stream_t stream);
 
+/* ---- fused drivers with a linear-predictor mean (REML, gradients, leave-one-out) ------------------------------- */
+
+/* The three drivers below take the mean DESIGN matrix P = mean(xi, meanparam) (n x q row-major, leading dimension ldp, on
+ * the device; q = 0 / P = NULL: zero-mean model) -- mean functions are user callables in the reference
+ * (gpmp/core/model.py:30-52).  0 <= q <= GPMP_MAX_RANK - 1, q < n.  Each call only enqueues: Gram build, Cholesky, the
+ * solves, and the q x q algebra (Cholesky of S = P^T K^-1 P and of P^T P, S^-1) in one small workgroup on the device.
+ * *info_dev: 0; k in [1, n]: K not positive definite at leading minor k (as gpmp_potrf_lower_async); n + k: S or P^T P
+ * not positive definite at pivot k (rank-deficient mean design).  ws: the matching gpmp_*_ws_elems doubles.
+ *
+ * gpmp_reml: *value_dev = 1/2 ((n - q) ln 2 pi + ln|W^T K W| + (W^T z)^T (W^T K W)^-1 (W^T z)), W an orthonormal basis
+ * of Null(P^T) -- negative_log_restricted_likelihood (gpmp/core/likelihood.py:92-129; the n x n complete QR and the two
+ * n^3 products of gpmp/core/linalg.py:49-88 are replaced by ln|K| + ln|S| - ln|P^T P| and z^T K^-1 z - b^T S^-1 b,
+ * b = P^T K^-1 z).  q = 0: the zero-mean NLL (likelihood.py:18-52).  +inf when *info_dev != 0 (likelihood.py:123-124). */
+size_t gpmp_reml_ws_elems(int n, int q);
+int gpmp_reml(const double* x, const double* z, const double* P, long ldp, int n, int d, int q, int p,
+              const double* theta_host, int noise, double* ws, double* value_dev, int* info_dev, gpmp_stream_t stream);
+
+/* Value as gpmp_reml plus its gradient with respect to the covariance parameters, grad_dev[1 + noise + d] (device):
+ *   d/dtheta_j = 1/2 tr((Qinv - beta beta^T) dK/dtheta_j),  Qinv = K^-1 - U S^-1 U^T, U = K^-1 P, beta = Qinv z
+ * (q = 0: Qinv = K^-1, beta = K^-1 z: the ML gradient).  The reference has no analytic form: NumPy backend
+ * gradient = None -> SciPy finite differences (gpmp/num/numpy_backend.py:333), torch backend autograd
+ * (gpmp/num/torch_backend.py:574-604); this is what gpmp/kernel/parameter_selection.py:35-124 wraps for the optimiser.
+ * K^-1 = T^T T with T = L^-1 (gpmp_trtri_lower, gpmp_lauum_lower), the trace in one fused pass
+ * (gpmp_matern_grad_trace).  A failed factorisation gives value +inf and a zero gradient. */
+size_t gpmp_nll_grad_ws_elems(int n, int d, int q);
+int gpmp_nll_grad(const double* x, const double* z, const double* P, long ldp, int n, int d, int q, int p,
+                  const double* theta_host, int noise, double* ws, double* value_dev, double* grad_dev, int* info_dev,
+                  gpmp_stream_t stream);
+
+/* Leave-one-out by virtual cross-validation: eloo_i = (Qinv z)_i / Qinv_ii, sigma2loo_i = 1 / Qinv_ii,
+ * zloo_i = z_i - eloo_i (three device vectors of length n) -- _loo_with_zero_mean (gpmp/core/loo.py:65-83, q = 0) and
+ * _loo_with_linear_predictor_mean_cpd (loo.py:103-130, q > 0); diag(K^-1) = column sums of squares of L^-1
+ * (gpmp/core/linalg.py:17-46).  A failed factorisation fills the outputs with NaN. */
+size_t gpmp_loo_ws_elems(int n, int q);
+int gpmp_loo(const double* x, const double* z, const double* P, long ldp, int n, int d, int q, int p,
+             const double* theta_host, int noise, double* ws, double* zloo_dev, double* sigma2loo_dev, double* eloo_dev,
+             int* info_dev, gpmp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,169 @@
+"""The fused C-ABI drivers with a linear-predictor mean (include/gpmp_hip.h: gpmp_reml, gpmp_nll_grad, gpmp_loo), called
+through ctypes exactly as a non-Python host would: device pointers in, device scalars / vectors out, one info word.
+Checked against the vectors the REFERENCE produced (tests/golden/ref_likelihood.npz, ref_gradients.npz -- torch-CPU
+autograd --, ref_predict.npz loo_*), i.e. against gpmp/core/likelihood.py:92-129, loo.py:65-130 and the criterion +
+gradient of gpmp/kernel/parameter_selection.py:35-124."""
+import math
+
+import numpy as np
+import pytest
+
+from tests.helpers import constant_mean, linear_mean, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gpmp_amd.num as gnp
+    from gpmp_amd import _lib
+
+    return torch, gnp, _lib, _lib.load()
+
+
+class _Call:
+    """Device copies of (x, z, P) and the three drivers as plain functions of theta."""
+
+    def __init__(self, env, x, z, P, p, noise=0):
+        torch, gnp, _lib, lib = self.env = env
+        dev = gnp._dev()
+        self.n, self.d = x.shape
+        self.q = 0 if P is None else P.shape[1]
+        self.p, self.noise = p, noise
+        self.X = torch.as_tensor(np.ascontiguousarray(x), device=dev)
+        self.Z = torch.as_tensor(np.ascontiguousarray(z), device=dev)
+        self.P = None if P is None else torch.as_tensor(np.ascontiguousarray(P), device=dev)
+        self.info = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.dev = dev
+
+    def _args(self, theta):
+        torch, gnp, _lib, lib = self.env
+        hv = _lib.host_vec(theta)
+        return (gnp._ptr(self.X), gnp._ptr(self.Z), gnp._ptr(self.P), max(self.q, 1), self.n, self.d, self.q, self.p, hv, self.noise)
+
+    def reml(self, theta):
+        torch, gnp, _lib, lib = self.env
+        ws = torch.empty(int(lib.gpmp_reml_ws_elems(self.n, self.q)), dtype=torch.float64, device=self.dev)
+        val = torch.empty(1, dtype=torch.float64, device=self.dev)
+        _lib.check(lib.gpmp_reml(*self._args(theta), gnp._ptr(ws), gnp._ptr(val), gnp._ptr(self.info), gnp._stream()), "gpmp_reml")
+        return float(val.item()), int(self.info.item())
+
+    def value_grad(self, theta):
+        torch, gnp, _lib, lib = self.env
+        ws = torch.empty(int(lib.gpmp_nll_grad_ws_elems(self.n, self.d, self.q)), dtype=torch.float64, device=self.dev)
+        val = torch.empty(1, dtype=torch.float64, device=self.dev)
+        g = torch.empty(len(theta), dtype=torch.float64, device=self.dev)
+        _lib.check(lib.gpmp_nll_grad(*self._args(theta), gnp._ptr(ws), gnp._ptr(val), gnp._ptr(g), gnp._ptr(self.info), gnp._stream()),
+                   "gpmp_nll_grad")
+        return float(val.item()), g.cpu().numpy(), int(self.info.item())
+
+    def loo(self, theta):
+        torch, gnp, _lib, lib = self.env
+        ws = torch.empty(int(lib.gpmp_loo_ws_elems(self.n, self.q)), dtype=torch.float64, device=self.dev)
+        out = [torch.empty(self.n, dtype=torch.float64, device=self.dev) for _ in range(3)]
+        _lib.check(lib.gpmp_loo(*self._args(theta), gnp._ptr(ws), *(gnp._ptr(o) for o in out), gnp._ptr(self.info), gnp._stream()), "gpmp_loo")
+        return [o.cpu().numpy() for o in out], int(self.info.item())
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_reml_driver_vs_reference(env, golden, tag):
+    g = golden("likelihood")
+    xi, zi, p = g[f"lik_{tag}_xi"], g[f"lik_{tag}_zi"], int(g[f"lik_{tag}_p"])
+    calls = {"nll": _Call(env, xi, zi, None, p), "reml_const": _Call(env, xi, zi, constant_mean(xi, None), p),
+             "reml_lin": _Call(env, xi, zi, linear_mean(xi, None), p)}
+    for i, t in enumerate(g[f"lik_{tag}_thetas"]):
+        for name, c in calls.items():
+            v, info = c.reml(t)
+            ref = float(g[f"lik_{tag}_{name}"][i])
+            assert info == 0 and abs(v - ref) < 1e-12 * max(1.0, abs(ref)), (name, i, v, ref)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
+def test_value_and_gradient_driver_vs_reference_autograd(env, golden, tag):
+    g = golden("gradients")
+    xi, zi, p = g[f"grad_{tag}_xi"], g[f"grad_{tag}_zi"], int(g[f"grad_{tag}_p"])
+    calls = {"nll": _Call(env, xi, zi, None, p), "reml_const": _Call(env, xi, zi, constant_mean(xi, None), p),
+             "reml_lin": _Call(env, xi, zi, linear_mean(xi, None), p)}
+    for i, t in enumerate(g[f"grad_{tag}_thetas"]):
+        for name, c in calls.items():
+            v, gr, info = c.value_grad(t)
+            assert info == 0
+            assert abs(v - g[f"grad_{tag}_{name}_val"][i]) < 1e-9 * abs(v), (name, i)        # torch-backend value (its cdist expands norms)
+            assert rel_err(gr, g[f"grad_{tag}_{name}_grad"][i]) < 1e-7, (name, i)
+            v2, _ = c.reml(t)
+            assert v2 == v                                                                      # same kernels, same order
+
+
+@pytest.mark.parametrize("tag", ["na", "nb"])
+def test_value_and_gradient_driver_noisy_kernel(env, golden, tag):
+    g = golden("gradients")
+    xi, zi, p = g[f"grad_{tag}_xi"], g[f"grad_{tag}_zi"], int(g[f"grad_{tag}_p"])
+    calls = {"nll": _Call(env, xi, zi, None, p, noise=1), "reml_const": _Call(env, xi, zi, constant_mean(xi, None), p, noise=1)}
+    for i, t in enumerate(g[f"grad_{tag}_thetas"]):
+        for name, c in calls.items():
+            v, gr, info = c.value_grad(t)
+            assert info == 0 and abs(v - g[f"grad_{tag}_{name}_val"][i]) < 1e-9 * abs(v)
+            assert rel_err(gr, g[f"grad_{tag}_{name}_grad"][i]) < 1e-7, (name, i)
+
+
+@pytest.mark.parametrize("tag", ["s", "m", "p3"])
+def test_loo_driver_vs_reference(env, golden, tag):
+    g = golden("predict")
+    xi, zi, th, p = g[f"pred_{tag}_xi"], g[f"pred_{tag}_zi"], g[f"pred_{tag}_theta"], int(g[f"pred_{tag}_p"])
+    for mt, P in (("zero", None), ("const", constant_mean(xi, None)), ("lin", linear_mean(xi, None))):
+        (zl, s2, el), info = _Call(env, xi, zi, P, p).loo(th)
+        assert info == 0
+        assert rel_err(zl, g[f"loo_{tag}_{mt}_zloo"]) < 1e-8 and rel_err(s2, g[f"loo_{tag}_{mt}_s2"]) < 1e-8, mt
+        assert rel_err(el, g[f"loo_{tag}_{mt}_eloo"]) < 1e-8, mt
+
+
+def test_mean_drivers_at_blocked_sizes_vs_python_path(env):
+    """n beyond one diagonal block / one panel (ragged), q = 0, 1 and d + 1, against the Python layer's own route"""
+    torch, gnp, _lib, lib = env
+    import gpmp_amd as gp
+    from gpmp_amd.core.gradients import MLZeroMeanAnalytic, REMLAnalytic
+
+    ones = lambda x, prm: gnp.ones((x.shape[0], 1))  # noqa: E731
+    lin = lambda x, prm: gnp.hstack((gnp.ones((x.shape[0], 1)), gnp.asarray(x)))  # noqa: E731
+    for n, d in ((1500, 3), (2177, 5)):
+        rng = np.random.default_rng(n)
+        x = rng.random((n, d))
+        z = np.sin(3 * x[:, 0]) + x.sum(axis=1) + 0.01 * rng.standard_normal(n)
+        th = np.concatenate(([0.2], -np.log(0.3 + 0.2 * np.arange(d))))
+        cov = gp.kernel.MaternCovariance(2)
+        for P, model, crit in ((None, gp.Model(None, cov, None, th, "zero"), MLZeroMeanAnalytic),
+                               (constant_mean(x, None), gp.Model(ones, cov, None, th), REMLAnalytic),
+                               (linear_mean(x, None), gp.Model(lin, cov, None, th), REMLAnalytic)):
+            c = _Call(env, x, z, P, 2)
+            v, gr, info = c.value_grad(th)
+            pv, state = crit(model).value_and_state(th, gnp.asarray(x), gnp.asarray(z))
+            pg = crit(model).gradient_from_state(state)
+            assert info == 0 and abs(v - pv) < 1e-11 * abs(pv) and rel_err(gr, pg) < 1e-9
+            (zl, s2, el), info = c.loo(th)
+            pz, ps, pe = model.loo(x, z)
+            assert info == 0 and rel_err(zl, gnp.to_np(pz)) < 1e-9 and rel_err(s2, gnp.to_np(ps)) < 1e-9 and rel_err(el, gnp.to_np(pe)) < 1e-9
+
+
+def test_mean_drivers_failure_conventions(env, golden):
+    """non-PD K: info = failing minor, value +inf, zero gradient, NaN loo; rank-deficient P: info = n + pivot"""
+    g = golden("likelihood")
+    xi, zi, th = g["lik_bad_xi"], g["lik_bad_zi"], g["lik_bad_theta"]
+    c = _Call(env, xi, zi, constant_mean(xi, None), 2)
+    v, info = c.reml(th)
+    assert info > 0 and info <= len(zi) and math.isinf(v) and v > 0
+    v, gr, info = c.value_grad(th)
+    assert info > 0 and math.isinf(v) and np.all(gr == 0.0)
+    (zl, s2, el), info = c.loo(th)
+    assert info > 0 and np.all(np.isnan(zl)) and np.all(np.isnan(s2))
+    x = np.random.default_rng(1).random((200, 2))
+    z = x.sum(axis=1)
+    P = np.hstack((np.ones((200, 1)), np.ones((200, 1))))                 # duplicated column
+    v, info = _Call(env, x, z, P, 2).reml(np.array([0.0, 0.5, 0.5]))
+    assert info == 200 + 2 and math.isinf(v)
+    torch, gnp, _lib, lib = env
+    assert lib.gpmp_reml_ws_elems(100, 72) == 0                               # q beyond GPMP_MAX_RANK - 1
+    assert lib.gpmp_reml(None, None, None, 1, 10, 2, 0, 2, None, 0, None, None, None, None) < 0
