@@ -35,13 +35,16 @@ __global__ void pack_zp_kernel(const double* __restrict__ z, const double* __res
 }
 
 // In-LDS Cholesky A = R R^T (lower, in place) of a q x q matrix by one workgroup; returns the first failing pivot (1-based) or 0.
-__device__ int chol_lds(double (*A)[QLD + 1], int q, int* fail) {
+// A pivot that is not above q * eps * (its original diagonal entry) counts as a failure: the matrix is singular to working
+// precision (a rank-deficient mean design leaves a pivot of rounding-error size, of either sign).
+__device__ int chol_lds(double (*A)[QLD + 1], int q, int* fail, double* d0) {
   const int t = threadIdx.x, nt = blockDim.x;
+  for (int k = t; k < q; k += nt) d0[k] = A[k][k];
   for (int k = 0; k < q; ++k) {
     __syncthreads();
     if (t == 0) {
       const double dkk = A[k][k];
-      if (!(dkk > 0.0)) { if (*fail == 0) *fail = k + 1; A[k][k] = 1.0; } else A[k][k] = sqrt(dkk);
+      if (!(dkk > (double)q * 2.220446049250313e-16 * d0[k])) { if (*fail == 0) *fail = k + 1; A[k][k] = 1.0; } else A[k][k] = sqrt(dkk);
     }
     __syncthreads();
     const double piv = A[k][k];
@@ -68,6 +71,7 @@ __global__ void __launch_bounds__(256) meanspace_kernel(const double* __restrict
   double (*R)[QLD + 1] = reinterpret_cast<double (*)[QLD + 1]>(ms_lds + QLD * (QLD + 1));     // R^-1 (lower)
   double* b = ms_lds + 2 * QLD * (QLD + 1);
   double* c = b + QLD;
+  double* d0 = c + QLD;
   __shared__ int fail;
   const int t = threadIdx.x, nt = blockDim.x;
   if (t == 0) fail = 0;
@@ -77,7 +81,7 @@ __global__ void __launch_bounds__(256) meanspace_kernel(const double* __restrict
     A[i][j] = 0.5 * (PtP[(long)i * ldp + j] + PtP[(long)j * ldp + i]);
   }
   __syncthreads();
-  chol_lds(A, q, &fail);
+  chol_lds(A, q, &fail, d0);
   if (t == 0) {
     double s = 0.0;
     for (int k = 0; k < q; ++k) s += log(A[k][k]);
@@ -91,7 +95,7 @@ __global__ void __launch_bounds__(256) meanspace_kernel(const double* __restrict
   }
   for (int i = t; i < q; i += nt) b[i] = Gm[(long)(1 + i) * ldg];
   __syncthreads();
-  chol_lds(A, q, &fail);
+  chol_lds(A, q, &fail, d0);
   if (t == 0) {
     double s = 0.0;
     for (int k = 0; k < q; ++k) s += log(A[k][k]);
@@ -254,7 +258,7 @@ int factor_and_meanspace(const MeanLayout& l, const double* x, const double* z, 
   if (q > 0) {
     rc = gpmp_coldots(P, n, q, ldp, P, q, ldp, ws + l.PtP, l.ldq, ws + l.cd, stream);
     if (rc) return rc;
-    const size_t ms_bytes = sizeof(double) * (2 * QLD * (QLD + 1) + 2 * QLD);
+    const size_t ms_bytes = sizeof(double) * (2 * QLD * (QLD + 1) + 3 * QLD);
     static bool attr_done = false;
     if (!attr_done) {
       GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(meanspace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

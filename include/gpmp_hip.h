@@ -14,8 +14,10 @@
  *    style info > 0 where stated.  No entry point synchronises: every function only enqueues work
  *    on `stream` (a hipStream_t passed as void*; NULL = the default stream); scalar results
  *    (info, log-det, gradient) land in caller-provided DEVICE words.
- *  - The library owns no device memory: callers (the torch allocator) own every buffer including
- *    workspaces, whose sizes come from the gpmp_*_ws_* queries.
+ *  - Callers (the torch allocator) own every matrix, vector and workspace; workspace sizes come from the
+ *    gpmp_*_ws_* / gpmp_dinv_elems queries.  The library itself allocates only the 16.4 KB flag block of the one-launch
+ *    triangular solve, once per (device, stream) that uses it (see gpmp_solve_status), plus host-side helper streams /
+ *    events.  One device per process and one calling thread at a time per stream.
  *  - covparam layout (gpmp/kernel/matern.py:78-79,88-89): theta = [log sigma^2, log(1/rho_1..d)];
  *    with `noise` != 0 the layout is [log sigma^2, log sigma_noise^2, log(1/rho_1..d)]
  *    (examples/gpmp_example07_nd_regression.py:95-131).
@@ -125,6 +127,14 @@ int gpmp_potrf_trsm_lower_async(double* A, int n, long lda, double* dinv, int* i
  * without it the solve runs launch-per-block leaves (same results, about 5 % slower at n = 32768). */
 int gpmp_trsm_lower(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb,
                     int trans, double* scratch, gpmp_stream_t stream);
+
+/* Solves with m <= 4 right-hand sides run as ONE launch whose workgroups hand the solved blocks over through flags in
+ * device memory; every wait in it is bounded (no launch can hang the GPU).  If a wait ever ran out -- it does not in a
+ * healthy run -- the rows from that block on are filled with NaN in EVERY right-hand side, and the event is counted per
+ * stream.  gpmp_solve_status synchronises `stream`, stores that count in *status_host (may be NULL), resets it and
+ * returns it (0 = every solve on this stream completed; < 0: HIP error).  The flag block (16.4 KB) is the one piece of
+ * device memory the library allocates itself: one per (device, stream) that has run such a solve, on first use. */
+int gpmp_solve_status(gpmp_stream_t stream, int* status_host);
 
 /* B <- B L^-T for an M x k row-major B and a k x k lower-triangular L (right-side solve: the panel step
  * A21 <- A21 inv(L11)^T of a blocked / distributed Cholesky).  dinv as produced by gpmp_potrf_lower_async

@@ -372,6 +372,44 @@ def test_single_vector_solve_persistent_under_load(gnp):
     torch.cuda.synchronize()
 
 
+def test_single_vector_solves_eight_streams_in_flight(gnp):
+    """the flag block of the one-launch solve is per stream: eight solves (different factors, both directions) enqueued
+    on eight streams before anything is synchronised, each behind a machine-filling GEMM on its own stream so that they
+    really are in flight together; every result bit-identical to its solo run and gpmp_solve_status clean"""
+    import ctypes
+    import torch
+    from gpmp_amd import _lib
+    from oracle import gp_oracle as orc
+
+    lib = _lib.load()
+    rng = np.random.default_rng(8)
+    facs, refs = [], []
+    for k, n in enumerate((2048, 3000, 4101, 1500)):
+        x = rng.random((n, 3))
+        K = orc.maternp_covariance(x, None, 2, np.array([0.0, 1.0, 0.7, 1.3])) + 1e-5 * np.eye(n)
+        F = gnp.cholesky_factor(gnp.asarray(K))
+        z = gnp.asarray(rng.standard_normal((n, 1 + k)))
+        facs.append((F, z))
+        refs.append((F.solve_lower(z).clone(), F.solve_lower(z, trans=True).clone()))
+    A = gnp.alloc_matrix(8192, 1024, zero=True)
+    Cs = [gnp.alloc_matrix(8192, 8192, zero=True) for _ in range(8)]
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    torch.cuda.synchronize()
+    outs = []
+    for s, st in enumerate(streams):
+        F, z = facs[s % 4]
+        with torch.cuda.stream(st):
+            _lib.check(lib.gpmp_dgemm(0, 1, 8192, 8192, 1024, -1.0, gnp._ptr(A), gnp._ld(A), gnp._ptr(A), gnp._ld(A), 1.0, gnp._ptr(Cs[s]),
+                                      gnp._ld(Cs[s]), 1, gnp._stream()), "gpmp_dgemm")
+            outs.append(F.solve_lower(z, trans=(s >= 4)))
+    torch.cuda.synchronize()
+    for s, got in enumerate(outs):
+        assert torch.equal(got, refs[s % 4][1 if s >= 4 else 0]), s
+    for st in streams:
+        status = ctypes.c_int(-1)
+        assert lib.gpmp_solve_status(ctypes.c_void_p(st.cuda_stream), ctypes.byref(status)) == 0 and status.value == 0
+
+
 @pytest.mark.parametrize("n,m", [(1536, 700), (2048, 1024), (1280, 514), (1500, 900)])
 def test_forward_solve_many_rhs_fused_leaves(gnp, n, m):
     """L^-1 B with the factor's scratch area (n > 1024): fused 512-row leaves incl. a narrow last column strip;
