@@ -68,19 +68,179 @@ def pmc_traffic_per_launch(kernel_substr):
     return tot if n_disp else None
 
 
-def cpu_baseline(n, m, d, threads):
-    """The oracle (NumPy/SciPy restatement of the reference's NumPy backend) timed on the host cores."""
+def _host_threads():
+    try:
+        from threadpoolctl import threadpool_info
+
+        return max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(n, m, d, threads, m_sample=1024):
+    """The oracle (NumPy / SciPy restatement of the reference's NumPy backend: cdist -> Matern ufuncs -> cholesky ->
+    2 x solve_triangular -> einsum) on the host cores, on a BOUNDED sample of the SAME workload: the full n, the
+    prediction set cut to ``m_sample`` of the m points.  One step of the metric is predict + NLL:
+        T(m) = 2 (Gram(xi, xi) + Cholesky)  +  NLL solves  +  (m / m_sample) (Gram(xi, xt_s) + 2 solves + reductions)
+    the n x n parts are measured once in full (the predict's and the NLL's are the same calls), the per-point part is
+    measured on the sample and scaled linearly in m (it is linear: m right-hand sides).  Also returns the host potrf time
+    at this n."""
+    from scipy.linalg import solve_triangular
+
     from oracle import gp_oracle as orc
 
     xi, zi, xt, theta = synth(n, m, d, 0)
-    kern = lambda x, y, t, pairwise=False: orc.maternp_covariance(x, y, 2, t, pairwise)  # noqa: E731
-    model = orc.OracleModel(None, kern, None, theta, "zero")
-    t0 = time.perf_counter()
-    orc.predict(model, xi, zi, xt)
-    orc.negative_log_likelihood_zero_mean(model, theta, xi, zi)
-    dt = time.perf_counter() - t0
-    return {"value": m / dt, "unit": "points/s", "cores": threads, "kind": "port",
-            "sample": f"oracle predict+NLL at n={n}, m={m}, d={d} (config 2 size; {dt:.1f} s), BLAS threads={threads}"}
+    xs = xt[:m_sample]
+    t = {}
+    np.linalg.cholesky(orc.maternp_covariance(xi[:512], None, 2, theta))    # BLAS thread pool / page-in warm-up, untimed
+
+    def tick(name, fn):
+        t0 = time.perf_counter()
+        out = fn()
+        t[name] = time.perf_counter() - t0
+        return out
+
+    K = tick("gram_ii", lambda: orc.maternp_covariance(xi, None, 2, theta))                 # kriging.py:59, likelihood.py:43
+    L = tick("cholesky", lambda: np.linalg.cholesky(K))                                      # numpy_backend.py:466
+    del K
+    Kit = tick("gram_it", lambda: orc.maternp_covariance(xi, xs, 2, theta))                 # kriging.py:60
+
+    def solves():                                                                            # numpy_backend.py:467-468, kriging.py:193-194, model.py:298
+        y = solve_triangular(L, Kit, lower=True)
+        lam = solve_triangular(L.T, y, lower=False)
+        var = orc.maternp_covariance(xs, None, 2, theta, True) - np.einsum("i..., i...", lam, Kit)
+        return np.einsum("i..., i...", lam, zi), var
+
+    tick("solve_sample", solves)
+
+    def nll_tail():                                                                          # likelihood.py:46-51
+        a = solve_triangular(L.T, solve_triangular(L, zi, lower=True), lower=False)
+        return 0.5 * (n * math.log(2 * math.pi) + 2.0 * np.sum(np.log(np.diag(L))) + zi @ a)
+
+    tick("nll_tail", nll_tail)
+    per_point = (t["gram_it"] + t["solve_sample"]) / m_sample
+    step = 2.0 * (t["gram_ii"] + t["cholesky"]) + t["nll_tail"] + m * per_point
+    return {"value": m / step, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (cdist + Matern ufuncs + LAPACK) at the full n={n}, d={d}; prediction set cut to {m_sample} of {m} points and "
+                      f"scaled linearly in m; Gram(xi,xi) {t['gram_ii']:.1f} s + Cholesky {t['cholesky']:.1f} s measured once and counted for "
+                      f"predict and NLL; per point {1e3 * per_point:.2f} ms; extrapolated step {step:.0f} s; "
+                      f"CPU work done {sum(t.values()):.0f} s; BLAS threads={threads} (cdist is single-threaded)",
+            "host_potrf": {"n": n, "s": t["cholesky"], "tflops": n ** 3 / 3.0 / t["cholesky"] / 1e12},
+            "phases_s": {k_: round(v_, 3) for k_, v_ in t.items()}}
+
+
+def config2_extra(model, d, threads, with_cpu):
+    """BASELINE.json configs[1]: d = 8, n = 4096 / m = 10000 -- one predict + NLL step on the GPU beside the oracle at the
+    SAME size on the host cores (full run, a few seconds)."""
+    import torch
+
+    import gpmp_amd.num as gnp
+
+    n, m = 4096, 10000
+    xi_h, zi_h, xt_h, theta = synth(n, m, d, 0)
+    xi, zi, xt = gnp.asarray(xi_h), gnp.asarray(zi_h), gnp.asarray(xt_h)
+
+    def step():
+        model.predict(xi, zi, xt, convert_in=False, convert_out=False)
+        return model.negative_log_likelihood_zero_mean(theta, xi, zi)
+
+    step()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(5):
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    flops = 2.0 * n ** 3 / 3.0 + float(n) * n * m      # two factorisations + the one solve the prediction needs
+    out = {"n": n, "m": m, "d": d, "ms_per_step": 1e3 * best, "points_per_s": m / best, "mfma_flops": flops,
+           "frac_of_fp64_mfma_peak": flops / best / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+    if with_cpu:
+        from oracle import gp_oracle as orc
+
+        kern = lambda x, y, t, pairwise=False: orc.maternp_covariance(x, y, 2, t, pairwise)  # noqa: E731
+        om = orc.OracleModel(None, kern, None, theta, "zero")
+        t0 = time.perf_counter()
+        orc.predict(om, xi_h, zi_h, xt_h)
+        orc.negative_log_likelihood_zero_mean(om, theta, xi_h, zi_h)
+        dt = time.perf_counter() - t0
+        out["cpu_same_size"] = {"s_per_step": dt, "points_per_s": m / dt, "cores": threads, "kind": "port (oracle, full run)"}
+    return out
+
+
+def config4_extra(threads, with_cpu):
+    """BASELINE.json configs[3]: REML fit at n = 16384, d = 20 -- one criterion value + analytic gradient evaluation on the
+    GPU (what each of the 50 L-BFGS evaluations costs), beside the two CPU routes SURVEY 8(d) names at n = 4096:
+    (i) the NumPy backend's finite-difference route = (d + 2) criterion values per value + gradient
+    (numpy_backend.py:333, parameter_selection.py:248-260), (ii) an analytic-gradient CPU route (potrf + inverse + traces)."""
+    import torch
+
+    import gpmp_amd as gp
+    import gpmp_amd.num as gnp
+    from gpmp_amd.core.gradients import REMLAnalytic
+    from gpmp_amd.kernel import MaternCovariance
+
+    n, d = 16384, 20
+    rng = np.random.default_rng(1234)
+    x = rng.random((n, d))
+    z = np.sin(2 * np.pi * x[:, 0]) + x[:, 1:].sum(axis=1)
+    theta = np.concatenate(([0.0], -np.log(0.5 + np.arange(d) / (d - 1.0))))      # rho_j in [0.5, 1.5]
+    xd, zd = gnp.asarray(x), gnp.asarray(z)
+    crit = REMLAnalytic(gp.Model(lambda a, p: gnp.ones((a.shape[0], 1)), MaternCovariance(2), None, theta))
+
+    def evaluate():
+        v, st = crit.value_and_state(theta, xd, zd)
+        return v, crit.gradient_from_state(st)
+
+    evaluate()
+    torch.cuda.synchronize()
+    best, best_v = float("inf"), float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        v, st = crit.value_and_state(theta, xd, zd)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        g = crit.gradient_from_state(st)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        best, best_v = min(best, t2 - t0), min(best_v, t1 - t0)
+        del st
+    flops = float(n) ** 3                                 # potrf + trtri + lauum, n^3 / 3 each
+    out = {"n": n, "d": d, "criterion": "REML, constant mean", "ms_per_value_and_gradient": 1e3 * best, "ms_value_only": 1e3 * best_v,
+           "s_per_50_evaluations": 50 * best, "mfma_flops": flops, "frac_of_fp64_mfma_peak": flops / best / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+           "value": float(v), "grad_norm": float(np.linalg.norm(g))}
+    del xd, zd
+    torch.cuda.empty_cache()
+    if with_cpu:
+        from oracle import gp_oracle as orc
+
+        nc = 4096
+        xc, zc = x[:nc], z[:nc]
+        P = np.ones((nc, 1))
+        kern = lambda a, b, t, pairwise=False: orc.maternp_covariance(a, b, 2, t, pairwise)  # noqa: E731
+        om = orc.OracleModel(lambda a, p: np.ones((a.shape[0], 1)), kern, None, theta, "linear_predictor")
+        t0 = time.perf_counter()
+        orc.negative_log_restricted_likelihood(om, theta, xc, zc)
+        t_val = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        orc.reml_value_and_grad(xc, zc, P, 2, theta)
+        t_ana = time.perf_counter() - t0
+        # the GPU at the same size, for a like-for-like ratio
+        xg, zg = gnp.asarray(xc), gnp.asarray(zc)
+        crit.value_and_state(theta, xg, zg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, st = crit.value_and_state(theta, xg, zg)
+        crit.gradient_from_state(st)
+        torch.cuda.synchronize()
+        t_gpu = time.perf_counter() - t0
+        out["cpu_n4096"] = {"cores": threads, "kind": "port (oracle)",
+                            "reml_value_s": t_val,
+                            "fd_route_s_per_value_and_gradient": (d + 2) * t_val,
+                            "fd_route_note": f"(d + 2) = {d + 2} criterion values per value + gradient (SciPy finite differences of the NumPy backend)",
+                            "analytic_route_s_per_value_and_gradient": t_ana,
+                            "gpu_same_size_ms": 1e3 * t_gpu}
+    return out
 
 
 DIST_N = {2: 65536, 4: 90112, 8: 131072}     # about 17 GB of local matrix per GPU; 8 GPUs = BASELINE.json configs[4]
@@ -173,8 +333,8 @@ def main():
     ap.add_argument("--dim-d", dest="d", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--cpu-n", type=int, default=4096)
-    ap.add_argument("--cpu-m", type=int, default=10000)
+    ap.add_argument("--cpu-m-sample", type=int, default=1024, help="prediction points of the CPU baseline's bounded sample")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] extras")
     args = ap.parse_args()
 
     import torch
@@ -319,14 +479,17 @@ def main():
             "roofline": roof,
             "extra": extra,
         }
-        if not args.no_cpu_baseline:
-            try:
-                from threadpoolctl import threadpool_info
-
-                threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-            except Exception:
-                threads = os.cpu_count() or 1
-            line["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_m, d, threads)
+        threads = _host_threads()
+        if world == 1 and not args.no_extras:
+            # configs[1] and configs[3] at their stated sizes, outside the timed region, each beside a same-size CPU figure
+            del out, zpm, zpv
+            torch.cuda.empty_cache()
+            extra["config2"] = config2_extra(model, d, threads, not args.no_cpu_baseline)
+            extra["config4"] = config4_extra(threads, not args.no_cpu_baseline)
+            out = zpm = zpv = None
+        if world == 1 and not args.no_cpu_baseline:      # rank 0 at N = 1 only
+            line["cpu_baseline"] = cpu_baseline(n, m, d, threads, m_sample=args.cpu_m_sample)
+            extra["potrf"]["host_potrf"] = line["cpu_baseline"].pop("host_potrf")
 
     # ---- N > 1, OPT-IN (GPMP_BENCH_DIST=1; =force also runs it on a 1 x 1 grid): the distributed Cholesky of configs[4]
     # as an extra after the headline measurement.  Off by default: its RCCL path with more than one rank has not run on
@@ -360,7 +523,7 @@ def main():
         wd = threading.Timer(float(os.environ.get("GPMP_BENCH_DIST_TIMEOUT", "240")), finish, args=("timeout",))
         wd.daemon = True
         wd.start()
-        del out, zpm, zpv
+        out = zpm = zpv = None
         try:
             dist_potrf_extra(world, rank, res)
             wd.cancel()
