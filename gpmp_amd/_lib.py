@@ -55,6 +55,9 @@ SIGNATURES = {
     "gpmp_reml": (c_int, [_P, _P, _P, c_long, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
     "gpmp_nll_grad_ws_elems": (c_size_t, [c_int, c_int, c_int]),
     "gpmp_nll_grad": (c_int, [_P, _P, _P, c_long, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P]),
+    "gpmp_batch_ws_elems": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "gpmp_nll_grad_batch": (c_int, [_P, c_long, _P, c_long, _P, c_long, c_long, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int,
+                                    _P, _P, _P, _P, _P]),
     "gpmp_loo_ws_elems": (c_size_t, [c_int, c_int]),
     "gpmp_loo": (c_int, [_P, _P, _P, c_long, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]),
 }

@@ -96,3 +96,90 @@ class REMLAnalytic:
         Gm = gnp.hstack((U, beta.reshape(-1, 1)))
         Kinv = F.inverse_lower()
         return _grad_trace(self.model.covariance, Kinv, xi, covparam, Fm, Gm)
+
+
+# ---- many small problems in one call ------------------------------------------------------------------
+BATCH_MAX_N = 1024      # GPMP_BATCH_MAX_N
+BATCH_MAX_Q = 3
+
+
+def batch_values_and_gradients(model, covparams, batches, want_grad=True, use_mean=False, mean_offset=None):
+    """Criterion values (and gradients) of B small problems through ONE library call (gpmp_nll_grad_batch: every
+    kernel batched over the problems) -- the throughput path behind ``gnp.BatchDifferentiableSelectionCriterion``
+    (gpmp/num/torch_backend.py:607-718) and multi-parameter log_prob evaluations (gpmp/mcmc/param_posterior.py:229-278).
+
+    ``batches``: list of (x_b, z_b) device arrays; ``covparams``: one parameter vector (shared) or a (B, ntheta) array.
+    ``use_mean``: REML with ``model.mean`` as the linear predictor (q <= 3 columns), else the zero-mean NLL.
+    Returns ``(values, grads)`` as NumPy arrays ((B,), (B, ntheta) or None), or ``None`` when the batch does not
+    qualify (not a declared Matern covariance, a batch above 1024 points, more than 3 mean columns): the caller then
+    evaluates the batches one after the other.  A failed factorisation raises ``HipLinAlgError`` like the array path."""
+    cov = model.covariance
+    if not isinstance(cov, MaternCovariance) or len(batches) == 0:
+        return None
+    lib = _lib.load()
+    xs = [gnp._points(xb) for xb, _ in batches]
+    zs = [gnp.asarray(zb).reshape(-1) for _, zb in batches]
+    if mean_offset is not None:
+        zs = [z - mean_offset(x) for x, z in zip(xs, zs)]
+    ns = [int(x.shape[0]) for x in xs]
+    d = int(xs[0].shape[1])
+    nmax, B = max(ns), len(xs)
+    if nmax > BATCH_MAX_N or any(int(x.shape[1]) != d for x in xs):
+        return None
+    Ps, q = None, 0
+    if use_mean:
+        Ps = [_mean_values(model, x, model.meanparam) for x in xs]
+        q = int(Ps[0].shape[1])
+        if q > BATCH_MAX_Q or any(int(P.shape[1]) != q for P in Ps):
+            return None
+    if min(ns) <= q:
+        return None
+    dev = xs[0].device
+    X = torch.zeros((B, nmax, d), dtype=torch.float64, device=dev)
+    Z = torch.zeros((B, nmax), dtype=torch.float64, device=dev)
+    Pm = torch.zeros((B, nmax, max(q, 1)), dtype=torch.float64, device=dev)
+    for b in range(B):
+        X[b, : ns[b]] = xs[b]
+        Z[b, : ns[b]] = zs[b]
+        if q:
+            Pm[b, : ns[b]] = Ps[b]
+    th = numpy.ascontiguousarray(numpy.asarray(covparams, dtype=numpy.float64))
+    shared = th.ndim == 1
+    ntheta = th.shape[-1]
+    if not shared and th.shape[0] != B:
+        raise ValueError("covparams must be one vector or one row per problem")
+    noise = 1 if cov.noise else 0
+    if ntheta != 1 + noise + d:
+        raise ValueError("covparam length does not match 1 + noise + d")
+    hv = _lib.host_vec(th.reshape(-1))
+    import ctypes
+
+    n_host = (ctypes.c_int * B)(*ns)
+    ws = torch.empty(int(lib.gpmp_batch_ws_elems(nmax, d, q, B, 1 if want_grad else 0)), dtype=torch.float64, device=dev)
+    values = torch.empty(B, dtype=torch.float64, device=dev)
+    grads = torch.empty((B, ntheta), dtype=torch.float64, device=dev) if want_grad else None
+    info = torch.zeros(B, dtype=torch.int32, device=dev)
+    _lib.check(
+        lib.gpmp_nll_grad_batch(gnp._ptr(X), nmax * d, gnp._ptr(Z), nmax, gnp._ptr(Pm) if q else None, max(q, 1), nmax * max(q, 1), q,
+                                n_host, nmax, d, B, cov.p, hv, 0 if shared else ntheta, noise, gnp._ptr(ws), gnp._ptr(values),
+                                gnp._ptr(grads), gnp._ptr(info), gnp._stream()),
+        "gpmp_nll_grad_batch",
+    )
+    bad = numpy.nonzero(gnp.to_np(info))[0]
+    if bad.size:
+        k = int(gnp.to_np(info)[bad[0]])
+        raise gnp.HipLinAlgError(
+            f"Matrix is not positive definite: Cholesky factorization failed in batched problem {int(bad[0])} (info={k})")
+    return gnp.to_np(values), (gnp.to_np(grads) if want_grad else None)
+
+
+def _ml_batch(self, covparam, batches, want_grad=True):
+    return batch_values_and_gradients(self.model, covparam, batches, want_grad, use_mean=False, mean_offset=self.mean_offset)
+
+
+def _reml_batch(self, covparam, batches, want_grad=True):
+    return batch_values_and_gradients(self.model, covparam, batches, want_grad, use_mean=True)
+
+
+MLZeroMeanAnalytic.batch_values_and_gradients = _ml_batch
+REMLAnalytic.batch_values_and_gradients = _reml_batch

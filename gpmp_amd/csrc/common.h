@@ -61,6 +61,8 @@ struct GemmOpts {
                             // column j only needs l < col0(j) + 128
   int batch = 1;            // independent products of one shape: operand / result pointers advance by the strides below
   long stride_a = 0, stride_b = 0, stride_c = 0;   // (elements) per batch index (blockIdx.y)
+  int batch2 = 1;           // a second, outer batch dimension (blockIdx.z): independent PROBLEMS, each with `batch` products
+  long stride2_a = 0, stride2_b = 0, stride2_c = 0;
   int lean = 0;             // NT products with K <= 512 issued next to a machine-filling GEMM on another stream: take the
                             // small-footprint kernel that starts beside the two resident workgroups of that GEMM on every CU
 };
@@ -77,6 +79,8 @@ int launch_trsm_leaf_forward(const double* L, long ldl, const double* dinv_leaf,
 // Factor the jb x jb block at A (lower, in place) and write inv(L) (NB x NB, ld NB, zero padded /
 // identity padded) to dinv.  info_dev: set to (offset + k + 1) at the first non-positive pivot.
 int launch_potf2_inv(double* A, long lda, int jb, double* dinv, int* info_dev, int offset, hipStream_t st);
+int launch_potf2_inv_batch(double* A, long lda, int jb, double* dinv, int* info_dev, int offset, int nprob, long stride_a,
+                           long stride_dinv, hipStream_t st);
 // inv(L_kk) of every NB diagonal block of an already factored n x n lower L (one launch).
 int launch_trtri_blocks(const double* L, long ldl, int n, double* dinv, hipStream_t st);
 
@@ -85,9 +89,23 @@ int trsv_few(const double* L, int n, long ldl, const double* dinv, double* B, in
              hipStream_t st);
 
 // ---- misc kernels (reduce.hip) -----------------------------------------------------------------
-int launch_tril(double* A, int n, long lda, hipStream_t st);
+int launch_tril(double* A, int n, long lda, hipStream_t st, int nprob = 1, long prob_stride = 0);
 int launch_symmetrize(double* A, int n, long lda, hipStream_t st);
 int launch_set_identity_lower(double* T, int n, long ldt, hipStream_t st);
-int launch_diag_blocks(double* T, int n, long ldt, const double* dinv, hipStream_t st);
+int launch_diag_blocks(double* T, int n, long ldt, const double* dinv, hipStream_t st, int nprob = 1, long prob_stride_t = 0,
+                       long prob_stride_dinv = 0);
+
+// ---- batched small problems (linalg.hip): `nprob` independent n x n matrices (n <= GPMP_BATCH_MAX_N), a fixed number of
+// elements apart; every step is ONE launch over all problems (blockIdx.y / .z = problem)
+struct ProblemBatch {
+  int nprob = 1;
+  long stride_a = 0;      // between the matrices (factor / inverse factor / inverse), elements
+  long stride_dinv = 0;   // between the diagonal-block inverse buffers
+};
+int potrf_blocked_batch(double* A, int n, long lda, double* dinv, int* info_dev, const ProblemBatch& pb, hipStream_t st);
+int trtri_doubling_batch(const double* L, int n, long ldl, const double* dinv, double* T, long ldt, const ProblemBatch& pb,
+                         long stride_t, hipStream_t st);
+int lauum_lower_batch(const double* T, int n, long ldt, long stride_t, double* Kinv, long ldk, long stride_k, int nprob,
+                      hipStream_t st);
 
 }  // namespace gpmp

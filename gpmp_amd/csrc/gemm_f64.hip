@@ -45,8 +45,10 @@ struct GemmParams {
   int cspread;  // v2: read C inside the first 16 k-tiles instead of up front
   int lean;     // NT, K <= 512: small-footprint kernel (see gemm_nt_lean_kernel)
   int batch;    // gridDim.y independent products
+  int batch2;   // gridDim.z independent problems (outer batch)
   int pair16;   // v2 epilogue: 16-byte stores after a lane-pair exchange
   long sa, sb, sc;   // element strides of A, B, C per batch index
+  long sa2, sb2, sc2;   // ... per outer batch index (blockIdx.z)
 };
 
 __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& ti, int& tj) {
@@ -182,9 +184,9 @@ template <bool AKC, bool BKC, bool CACC>
 __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) double smem[];  // [2 buffers][A tile | B tile]
   int ti, tj;
-  p.A += (long)blockIdx.y * p.sa;   // batched launch: one independent product per blockIdx.y
-  p.B += (long)blockIdx.y * p.sb;
-  p.C += (long)blockIdx.y * p.sc;
+  p.A += (long)blockIdx.y * p.sa + (long)blockIdx.z * p.sa2;   // batched launch: one independent product per blockIdx.y
+  p.B += (long)blockIdx.y * p.sb + (long)blockIdx.z * p.sb2;
+  p.C += (long)blockIdx.y * p.sc + (long)blockIdx.z * p.sc2;
   decode_tile(p, blockIdx.x, ti, tj);
   // the tile coordinates are wave-uniform but come out of VALU code (sqrt in the triangular decode):
   // pin them to SGPRs so every tile base address below is scalar
@@ -366,9 +368,9 @@ template <bool AKC, bool BKC, bool CACC>
 __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) double smem[];  // [2 buffers][A image | B image] = 64 KB
   int ti, tj;
-  p.A += (long)blockIdx.y * p.sa;   // batched launch: one independent product per blockIdx.y
-  p.B += (long)blockIdx.y * p.sb;
-  p.C += (long)blockIdx.y * p.sc;
+  p.A += (long)blockIdx.y * p.sa + (long)blockIdx.z * p.sa2;   // batched launch: one independent product per blockIdx.y
+  p.B += (long)blockIdx.y * p.sb + (long)blockIdx.z * p.sb2;
+  p.C += (long)blockIdx.y * p.sc + (long)blockIdx.z * p.sc2;
   decode_tile(p, blockIdx.x, ti, tj);
   ti = __builtin_amdgcn_readfirstlane(ti);
   tj = __builtin_amdgcn_readfirstlane(tj);
@@ -1018,20 +1020,20 @@ int launch_t(const GemmParams& p, hipStream_t st) {
   }
   static int use_lean = -1;
   if (use_lean < 0) { const char* e = getenv("GPMP_GEMM_LEAN"); use_lean = e ? atoi(e) : 1; }
-  const bool lean_nt = p.batch == 1 && AKC && BKC && p.lean && use_lean && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
+  const bool lean_nt = p.batch == 1 && p.batch2 == 1 && AKC && BKC && p.lean && use_lean && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
                        !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col) && ((long)SBN * p.ldb * 8 + (long)p.K * 8 < 0x7FFFFFFFL) &&
                        ((long)SBM * p.lda * 8 + (long)p.K * 8 < 0x7FFFFFFFL);
-  const bool small_nt = !lean_nt && p.batch == 1 && AKC && BKC && use_small && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
+  const bool small_nt = !lean_nt && p.batch == 1 && p.batch2 == 1 && AKC && BKC && use_small && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
                         p.ntiles <= (p.K >= 512 ? 384 : small_max) && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col);
   {
     // executed flops of this launch (tiles actually visited, k range actually swept)
     const double kavg = (p.kstart_row || p.kend_row || p.kstart_col || p.kend_col) ? 0.5 * p.K : (double)p.K;
     ProfScope ps((AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN)) + ((v2ok && !small_nt) ? 8 : 0), st,
-                 2.0 * (double)p.ntiles * BM * BN * kavg * p.batch);
+                 2.0 * (double)p.ntiles * BM * BN * kavg * p.batch * p.batch2);
     if (lean_nt) hipLaunchKernelGGL(gemm_nt_lean_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
     else if (small_nt) hipLaunchKernelGGL(gemm_nt_small_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
-    else if (v2ok) hipLaunchKernelGGL((gemm_f64_kernel_v2<AKC, BKC, CACC>), dim3(p.ntiles, p.batch), dim3(256), lds2, st, p);
-    else hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC, CACC>), dim3(p.ntiles, p.batch), dim3(256), lds, st, p);
+    else if (v2ok) hipLaunchKernelGGL((gemm_f64_kernel_v2<AKC, BKC, CACC>), dim3(p.ntiles, p.batch, p.batch2), dim3(256), lds2, st, p);
+    else hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC, CACC>), dim3(p.ntiles, p.batch, p.batch2), dim3(256), lds, st, p);
   }
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
@@ -1097,6 +1099,8 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   p.lean = o.lean | g_machine_busy;
   p.batch = o.batch > 1 ? o.batch : 1;
   p.sa = o.stride_a; p.sb = o.stride_b; p.sc = o.stride_c;
+  p.batch2 = o.batch2 > 1 ? o.batch2 : 1;
+  p.sa2 = o.stride2_a; p.sb2 = o.stride2_b; p.sc2 = o.stride2_c;
   p.aligned = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0) &&
               ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((ldb & 1) == 0);
   if (a_kc && b_kc) return launch_c<true, true>(p, st);
@@ -1111,7 +1115,7 @@ int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const d
   if (M <= 0 || N <= 0) return 0;
   // The LDS-direct kernel needs even M and N (16-byte clipping at the edges): peel an odd last row / column off a
   // large rectangular product so that everything else runs on it.
-  const bool plain = !o.lower_only && !o.kstart_row && !o.kend_row && !o.kstart_col && !o.kend_col && o.batch <= 1;
+  const bool plain = !o.lower_only && !o.kstart_row && !o.kend_row && !o.kstart_col && !o.kend_col && o.batch <= 1 && o.batch2 <= 1;
   const int Nr = N % 2, Mr = M % 2;
   if (plain && (Nr || Mr) && (K % BK == 0) && K >= 512 && (M >= 4 * BM || N >= 4 * BN) && C != A && C != B) {
     const int Mf = M - Mr, Nf = N - Nr;

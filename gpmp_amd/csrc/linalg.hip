@@ -19,11 +19,22 @@ inline int imin(int a, int b) { return a < b ? a : b; }
 inline int imax(int a, int b) { return a > b ? a : b; }
 
 // Blocked (two-level) leaf of the recursive factorisation; row0 = global index of A[0][0] (for info).
-int potrf_blocked(double* A, int n, long lda, double* dinv, int* info_dev, int row0, hipStream_t st) {
+int potrf_blocked(double* A, int n, long lda, double* dinv, int* info_dev, int row0, hipStream_t st,
+                  const ProblemBatch* pb = nullptr) {
   const int nblk = (n + NB - 1) / NB;
   GemmOpts lower;
   lower.lower_only = 1;
   GemmOpts plain;
+  GemmOpts scale;          // panel scaling: B operand = the diagonal-block inverses
+  if (pb != nullptr && pb->nprob > 1) {
+    // every launch below covers all problems: blockIdx.z of the GEMM / blockIdx.y of the diagonal-block kernel
+    lower.batch2 = plain.batch2 = scale.batch2 = pb->nprob;
+    lower.stride2_a = lower.stride2_b = lower.stride2_c = pb->stride_a;
+    plain.stride2_a = plain.stride2_b = plain.stride2_c = pb->stride_a;
+    scale.stride2_a = scale.stride2_c = pb->stride_a;
+    scale.stride2_b = pb->stride_dinv;
+  }
+  const bool batched = pb != nullptr && pb->nprob > 1;
   for (int ob = 0; ob < nblk; ob += OUTER_BLOCKS) {
     const int oe = imin(ob + OUTER_BLOCKS, nblk);
     const int out_end = imin(oe * NB, n);
@@ -31,14 +42,16 @@ int potrf_blocked(double* A, int n, long lda, double* dinv, int* info_dev, int r
       const int c0 = c * NB;
       const int jb = imin(NB, n - c0);
       double* dc = dinv + (size_t)c * NB * NB;
-      int rc = launch_potf2_inv(A + (long)c0 * lda + c0, lda, jb, dc, info_dev, row0 + c0, st);
+      int rc = batched ? launch_potf2_inv_batch(A + (long)c0 * lda + c0, lda, jb, dc, info_dev, row0 + c0, pb->nprob, pb->stride_a,
+                                                pb->stride_dinv, st)
+                       : launch_potf2_inv(A + (long)c0 * lda + c0, lda, jb, dc, info_dev, row0 + c0, st);
       if (rc) return rc;
       const int r1 = c0 + jb;
       const int mrem = n - r1;
       if (mrem <= 0) break;
       double* A21 = A + (long)r1 * lda + c0;
       // panel: A21 <- A21 * inv(L_cc)^T  (in place: one 128-wide tile column, K = 128)
-      rc = launch_gemm(true, true, mrem, jb, jb, 1.0, A21, lda, dc, NB, 0.0, A21, lda, plain, st);
+      rc = launch_gemm(true, true, mrem, jb, jb, 1.0, A21, lda, dc, NB, 0.0, A21, lda, scale, st);
       if (rc) return rc;
       const int ncols_in = out_end - r1;
       if (ncols_in > 0) {
@@ -437,8 +450,11 @@ int trsm_backward(const double* L, int n, long ldl, const double* dinv, double* 
 // kept transposed in the pair's T12 block (s x len2: always fits), which is otherwise zero; the triangular structure of
 // T11 (first product, as the transposed left operand) and of T22 (second product) is skipped tile-wise, so the W blocks
 // above the diagonal are never read as part of a triangle; they are zeroed at the end.
-int trtri_doubling(const double* L, int n, long ldl, const double* dinv, double* T, long ldt, hipStream_t st) {
-  int rc = launch_diag_blocks(T, n, ldt, dinv, st);
+int trtri_doubling(const double* L, int n, long ldl, const double* dinv, double* T, long ldt, hipStream_t st,
+                   const ProblemBatch* pb = nullptr, long stride_t = 0) {
+  const int nprob = pb != nullptr ? pb->nprob : 1;
+  const long sl = pb != nullptr ? pb->stride_a : 0;
+  int rc = launch_diag_blocks(T, n, ldt, dinv, st, nprob, stride_t, pb != nullptr ? pb->stride_dinv : 0);
   if (rc) return rc;
   for (long s = NB; s < n; s *= 2) {
     const int npairs = (int)(n / (2 * s));                  // pairs with two full halves
@@ -456,19 +472,39 @@ int trtri_doubling(const double* L, int n, long ldl, const double* dinv, double*
       GemmOpts g1;
       g1.kstart_row = 1;                                     // (T11^T)(i, l) = T11(l, i) = 0 for l < i
       g1.batch = batch; g1.stride_a = 2 * s * (ldt + 1); g1.stride_b = 2 * s * (ldl + 1); g1.stride_c = 2 * s * (ldt + 1);
+      g1.batch2 = nprob; g1.stride2_a = stride_t; g1.stride2_b = sl; g1.stride2_c = stride_t;
       rc = launch_gemm(false, true, (int)s, len2, (int)s, 1.0, T11, ldt, L21, ldl, 0.0, Wt, ldt, g1, st);
       if (rc) return rc;
       GemmOpts g2;
       g2.kend_row = 1;                                       // T22(i, l) = 0 for l > i
       g2.batch = batch; g2.stride_a = g2.stride_b = g2.stride_c = 2 * s * (ldt + 1);
+      g2.batch2 = nprob; g2.stride2_a = g2.stride2_b = g2.stride2_c = stride_t;
       rc = launch_gemm(true, true, len2, (int)s, len2, -1.0, T22, ldt, Wt, ldt, 0.0, T21, ldt, g2, st);
       if (rc) return rc;
     }
   }
-  return launch_tril(T, n, ldt, st);
+  return launch_tril(T, n, ldt, st, nprob, stride_t);
 }
 
 }  // namespace
+
+// ---- batched small problems (drivers_batch.hip) ---------------------------------------------------------------------
+int potrf_blocked_batch(double* A, int n, long lda, double* dinv, int* info_dev, const ProblemBatch& pb, hipStream_t st) {
+  GPMP_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int) * (size_t)pb.nprob, st));
+  return potrf_blocked(A, n, lda, dinv, info_dev, 0, st, &pb);
+}
+int trtri_doubling_batch(const double* L, int n, long ldl, const double* dinv, double* T, long ldt, const ProblemBatch& pb,
+                         long stride_t, hipStream_t st) {
+  return trtri_doubling(L, n, ldl, dinv, T, ldt, st, &pb, stride_t);
+}
+int lauum_lower_batch(const double* T, int n, long ldt, long stride_t, double* Kinv, long ldk, long stride_k, int nprob,
+                      hipStream_t st) {
+  GemmOpts o;
+  o.lower_only = 1;
+  o.kstart_row = 1;
+  o.batch2 = nprob; o.stride2_a = o.stride2_b = stride_t; o.stride2_c = stride_k;
+  return launch_gemm(false, false, n, n, n, 1.0, T, ldt, T, ldt, 0.0, Kinv, ldk, o, st);
+}
 }  // namespace gpmp
 
 using namespace gpmp;

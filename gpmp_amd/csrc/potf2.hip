@@ -61,8 +61,12 @@ __device__ long long g_potf2_trace[64];
 
 __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__ A, long lda, int n_total,
                                                             double* __restrict__ dinv, int* info, int offset,
-                                                            int do_factor) {
-  // batched over blockIdx.x: block b works on the diagonal block starting at row/col b * NB
+                                                            int do_factor, long prob_stride_a, long prob_stride_dinv) {
+  // batched over blockIdx.x: block b works on the diagonal block starting at row/col b * NB;
+  // batched over blockIdx.y: independent matrices (problems) prob_stride_a / prob_stride_dinv elements apart, one info word each
+  A += (long)blockIdx.y * prob_stride_a;
+  dinv += (long)blockIdx.y * prob_stride_dinv;
+  if (info != nullptr) info += blockIdx.y;
   A += (long)blockIdx.x * NB * (lda + 1);
   dinv += (long)blockIdx.x * NB * NB;
   offset += blockIdx.x * NB;
@@ -277,7 +281,7 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
 }
 
 int launch(double* A, long lda, int n_total, int nblocks, double* dinv, int* info_dev, int offset,
-           int do_factor, hipStream_t st) {
+           int do_factor, hipStream_t st, int nprob = 1, long prob_stride_a = 0, long prob_stride_dinv = 0) {
   static bool attr_done = false;
   const size_t lds = sizeof(double) * (NPACK * 256 + NSB * 256 + NB);   // 91,136 B
   if (!attr_done) {
@@ -286,9 +290,9 @@ int launch(double* A, long lda, int n_total, int nblocks, double* dinv, int* inf
     attr_done = true;
   }
   {
-    ProfScope ps(PK_POTF2, st, (double)nblocks);
-    hipLaunchKernelGGL(potf2_inv_kernel, dim3(nblocks), dim3(THREADS), lds, st, A, lda, n_total, dinv, info_dev,
-                       offset, do_factor);
+    ProfScope ps(PK_POTF2, st, (double)nblocks * nprob);
+    hipLaunchKernelGGL(potf2_inv_kernel, dim3(nblocks, nprob), dim3(THREADS), lds, st, A, lda, n_total, dinv, info_dev,
+                       offset, do_factor, prob_stride_a, prob_stride_dinv);
   }
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
@@ -298,6 +302,11 @@ int launch(double* A, long lda, int n_total, int nblocks, double* dinv, int* inf
 
 int launch_potf2_inv(double* A, long lda, int jb, double* dinv, int* info_dev, int offset, hipStream_t st) {
   return launch(A, lda, jb, 1, dinv, info_dev, offset, 1, st);
+}
+// the same diagonal block of `nprob` independent matrices (batched small problems, drivers_batch.hip)
+int launch_potf2_inv_batch(double* A, long lda, int jb, double* dinv, int* info_dev, int offset, int nprob, long stride_a,
+                           long stride_dinv, hipStream_t st) {
+  return launch(A, lda, jb, 1, dinv, info_dev, offset, 1, st, nprob, stride_a, stride_dinv);
 }
 int launch_trtri_blocks(const double* L, long ldl, int n, double* dinv, hipStream_t st) {
   if (n <= 0) return 0;

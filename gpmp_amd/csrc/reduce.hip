@@ -74,7 +74,8 @@ __global__ void __launch_bounds__(1024) logdet_kernel(const double* __restrict__
   }
 }
 
-__global__ void tril_kernel(double* __restrict__ A, int n, long lda) {
+__global__ void tril_kernel(double* __restrict__ A, int n, long lda, long prob_stride) {
+  A += (long)blockIdx.z * prob_stride;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   for (int i = blockIdx.y; i < n; i += gridDim.y)
@@ -99,7 +100,10 @@ __global__ void __launch_bounds__(256) symmetrize_kernel(double* __restrict__ A,
 }
 
 // T's diagonal 128 x 128 blocks <- the block inverses (dinv: [block][128][128], identity-padded last block)
-__global__ void diag_blocks_kernel(double* __restrict__ T, int n, long ldt, const double* __restrict__ dinv) {
+__global__ void diag_blocks_kernel(double* __restrict__ T, int n, long ldt, const double* __restrict__ dinv, long prob_stride_t,
+                                   long prob_stride_dinv) {
+  T += (long)blockIdx.y * prob_stride_t;
+  dinv += (long)blockIdx.y * prob_stride_dinv;
   const int b = blockIdx.x, b0 = b * NB;
   const int jb = (n - b0) < NB ? (n - b0) : NB;
   const double* D = dinv + (size_t)b * NB * NB;
@@ -117,9 +121,9 @@ __global__ void identity_kernel(double* __restrict__ T, int n, long ldt) {
 
 }  // namespace
 
-int launch_tril(double* A, int n, long lda, hipStream_t st) {
+int launch_tril(double* A, int n, long lda, hipStream_t st, int nprob, long prob_stride) {
   if (n <= 1) return 0;
-  hipLaunchKernelGGL(tril_kernel, dim3((n + 255) / 256, n < 16384 ? n : 16384), dim3(256), 0, st, A, n, lda);
+  hipLaunchKernelGGL(tril_kernel, dim3((n + 255) / 256, n < 16384 ? n : 16384, nprob), dim3(256), 0, st, A, n, lda, prob_stride);
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -130,9 +134,11 @@ int launch_symmetrize(double* A, int n, long lda, hipStream_t st) {
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }
-int launch_diag_blocks(double* T, int n, long ldt, const double* dinv, hipStream_t st) {
+int launch_diag_blocks(double* T, int n, long ldt, const double* dinv, hipStream_t st, int nprob, long prob_stride_t,
+                       long prob_stride_dinv) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(diag_blocks_kernel, dim3((n + NB - 1) / NB), dim3(256), 0, st, T, n, ldt, dinv);
+  hipLaunchKernelGGL(diag_blocks_kernel, dim3((n + NB - 1) / NB, nprob), dim3(256), 0, st, T, n, ldt, dinv, prob_stride_t,
+                     prob_stride_dinv);
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }

