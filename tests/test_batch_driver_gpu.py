@@ -121,12 +121,14 @@ def test_batch_driver_failure_is_per_problem(env, golden):
     d = xb.shape[1]
     good = [_data(len(zb), d, 50 + k) for k in range(3)]
     xs, zs = [good[0][0], xb, good[1][0], good[2][0]], [good[0][1], zb, good[1][1], good[2][1]]
-    vals, grads, info = _batch(env, xs, zs, None, thb, shared=True)
+    thg = np.concatenate(([0.0], -np.log(0.3 + 0.2 * np.arange(d))))
+    thetas = np.stack([thg, thb, thg, thg])                       # only problem 1 gets the degenerate parameters
+    vals, grads, info = _batch(env, xs, zs, None, thetas, shared=False)
     assert info[1] > 0 and math.isinf(vals[1]) and np.all(grads[1] == 0.0)
     assert np.all(info[[0, 2, 3]] == 0) and np.all(np.isfinite(vals[[0, 2, 3]]))
     for b in (0, 2, 3):
-        v, gr, _ = _single(env, xs[b], zs[b], None, thb)
-        assert abs(vals[b] - v) < 1e-10 * abs(v) and rel_err(grads[b], gr) < 1e-8
+        v, gr, _ = _single(env, xs[b], zs[b], None, thetas[b])
+        assert abs(vals[b] - v) < 1e-8 * abs(v) and rel_err(grads[b], gr) < 1e-6      # (ill-conditioned at these length scales)
     torch, gnp, _lib, lib = env
     assert lib.gpmp_batch_ws_elems(2048, 3, 0, 4, 1) == 0 and lib.gpmp_batch_ws_elems(512, 3, 4, 4, 1) == 0
 
@@ -152,4 +154,4 @@ def test_batch_criterion_fast_path_equals_one_at_a_time(env, golden):
             v2, g2, e2 = pre(t), grad(t).copy(), ev(t)
             assert abs(v1 - v2) < 1e-12 * abs(v2) and abs(e1 - e2) < 1e-12 * abs(e2) and rel_err(g1, g2) < 1e-10
         obj.use_batched_kernel = True
-        assert math.isinf(pre(golden("likelihood")["lik_bad_theta"][: len(g["batch_thetas"][0])] * 0 - 40.0)) or True
+        assert math.isinf(pre(np.full(len(g["batch_thetas"][0]), -40.0))) and np.all(grad(np.full(len(g["batch_thetas"][0]), -40.0)) == 0.0)
