@@ -125,6 +125,31 @@ class HipLocalOps:
     def asarray(self, a):
         return self.gnp.asarray(a)
 
+    def trsm_left(self, L, dinv, B):
+        """B <- L^-1 B in place (B: k x m view, L: k x k lower)."""
+        g = self.gnp
+        if B.shape[1] == 0:
+            return
+        self._lib.check(self.lib.gpmp_trsm_lower(g._ptr(L), L.shape[0], g._ld(L), g._ptr(dinv), g._ptr(B), B.shape[1], g._ld(B), 0, None,
+                                                 g._stream()), "gpmp_trsm_lower")
+
+    def gemm_nn_sub(self, C, A, B):
+        """C -= A B  (C: M x N view, A: M x K, B: K x N)."""
+        g = self.gnp
+        M, N, K = C.shape[0], C.shape[1], A.shape[1]
+        if M == 0 or N == 0:
+            return
+        self._lib.check(self.lib.gpmp_dgemm(0, 0, M, N, K, -1.0, g._ptr(A), g._ld(A), g._ptr(B), g._ld(B), 1.0, g._ptr(C), g._ld(C), 0,
+                                            g._stream()), "gpmp_dgemm")
+
+    def coldots(self, V, w):
+        """(V^T w, column sums of squares of V) for the local rows: two (m,) device vectors."""
+        out = self.gnp.coldots(V, w.reshape(-1, 1))
+        return out[0], out[1]
+
+    def pairwise_variance(self, cov, xt, covparam):
+        return self.gnp.asarray(cov(xt, None, covparam, pairwise=True)).reshape(-1)
+
 
 # ------------------------------------------------------------------------------------------------
 def _comm_tensor(t: torch.Tensor, backend: str) -> torch.Tensor:
@@ -640,6 +665,90 @@ class BlockCyclicCholesky:
             dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=g.world_group)
             w[k0 + bk:] -= delta
         return w
+
+    # ---- many right-hand sides on the distributed factor (prediction beyond one GPU's HBM)
+    def solve_lower_many(self, Bloc: torch.Tensor) -> torch.Tensor:
+        """V = L^-1 B in place for a right-hand side laid out like the factor's rows: ``Bloc`` holds the block rows this
+        process row owns (self.local_rows() x m_c) of THIS process column's shard of the columns of B (the columns of B are
+        split over the process columns, gpmp_amd.dist.shard_bounds(m, Pc, c)).  Per block column k:
+          1. L_kk (+ its diagonal-block inverses) travels along process row k mod Pr      [one broadcast, nb^2]
+          2. the ranks of that process row solve X_k = L_kk^-1 B_k for their column shard   [local]
+          3. X_k travels down every process column                                          [nb x m_c per column]
+          4. the panel L_{I>k, k} travels along every process row; B_I -= L_Ik X_k          [panel broadcast + local GEMM]
+        n^2 m flops spread evenly over the grid; the panel broadcasts are the ones of the factorisation again."""
+        g, ops, nb = self.grid, self.ops, self.nb
+        mloc = Bloc.shape[1]
+        row_members = [g.rank_of(g.r, cc) for cc in range(g.pc)]
+        col_members = [g.rank_of(rr, g.c) for rr in range(g.pr)]
+        for k in range(self.nblocks):
+            rd, cd = g.owner_row(k), g.owner_col(k)
+            bk = self.bs(k)
+            ldk = (bk + 15) // 16 * 16
+            ndinv = ((bk + 127) // 128) * 128 * 128
+            xk = ops.empty(bk, mloc)
+            if g.r == rd:
+                dbuf = self._flat(bk * ldk + ndinv)
+                Lkk = dbuf[: bk * ldk].view(bk, ldk)[:, :bk]
+                dinv = dbuf[bk * ldk:]
+                if g.c == cd:
+                    L0, d0 = self.diag_cache[k]
+                    Lkk.copy_(L0)
+                    dinv.copy_(d0[:ndinv])
+                if g.pc > 1:
+                    self._bcast(dbuf, g.rank_of(rd, cd), g.row_group, row_members)
+                li = k // g.pr
+                Bk = Bloc[self.roff[li]:self.roff[li + 1]]
+                if mloc:
+                    ops.trsm_left(Lkk, dinv, Bk)
+                    xk.copy_(Bk)
+            if g.pr > 1 and mloc:
+                self._bcast(xk, g.rank_of(rd, g.c), g.col_group, col_members)
+            i0 = self._first_row_after(k)
+            Mr = self.roff[-1] - self.roff[i0]
+            if Mr > 0:
+                panel = ops.empty(Mr, bk)
+                if g.c == cd:
+                    lj = k // g.pc
+                    panel.copy_(self.A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]])
+                if g.pc > 1:
+                    self._bcast(panel, g.rank_of(g.r, cd), g.row_group, row_members)
+                if mloc:
+                    ops.gemm_nn_sub(Bloc[self.roff[i0]:], panel, xk)
+        return Bloc
+
+    def predict_zero_mean(self, cov, x, z, xt, covparam):
+        """Posterior mean and variance at xt from the distributed factor of K(x, x) (zero-mean kriging,
+        gpmp/core/kriging.py:35-67,170-199 restated as ONE solve: V = L^-1 K(x, xt), mean = V^T (L^-1 z),
+        var = k(xt, xt) - colsumsq(V)).  The prediction points are split over the process COLUMNS, the rows of V over the
+        process ROWS; the local block K(x[rows owned], xt[column shard]) is one Gram call, and the only reductions are
+        two (m_c,) all-reduces inside each process column.  Returns (mean, variance, (j0, j1)): this process column's
+        shard of the results (identical on the ranks of one process column), as NumPy arrays."""
+        from .predict import shard_bounds
+
+        if self.info:
+            raise np.linalg.LinAlgError("the distributed factorisation failed (not positive definite): no prediction")
+        g, ops = self.grid, self.ops
+        x, xt = ops.asarray(x), ops.asarray(xt)
+        j0, j1 = shard_bounds(xt.shape[0], g.pc, g.c)
+        xtc = xt[j0:j1].contiguous()
+        ri = self.global_row_index()
+        xr = x[torch.as_tensor(ri, device=x.device)] if len(ri) else x[:0]
+        if len(ri) and j1 > j0:
+            Kit = ops.gram_block(cov, xr.contiguous(), xtc, covparam)
+        else:
+            Kit = ops.empty(len(ri), j1 - j0)
+        V = self.solve_lower_many(Kit)
+        w = self.solve_lower_vector(z)                                   # replicated L^-1 z
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        part = torch.zeros((2, j1 - j0), dtype=torch.float64, device=dev)
+        if len(ri) and j1 > j0:
+            wloc = ops.asarray(w[torch.as_tensor(ri, device=w.device)])
+            mean_p, ssq_p = ops.coldots(V, wloc)
+            part[0], part[1] = mean_p.to(dev), ssq_p.to(dev)
+        if g.pr > 1:
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=g.col_group)
+        prior = ops.pairwise_variance(cov, xtc, covparam).to(dev) if j1 > j0 else part[1]
+        return part[0].cpu().numpy(), (prior - part[1]).cpu().numpy(), (j0, j1)
 
     def negative_log_likelihood(self, z) -> float:
         """1/2 (n ln 2pi + ln|K| + z^T K^-1 z) -- gpmp/core/likelihood.py:18-52 on the distributed factor."""

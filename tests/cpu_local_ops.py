@@ -42,3 +42,17 @@ class CpuLocalOps:
 
     def sum_log_diag(self, L):
         return float(torch.log(torch.diagonal(L)).sum())
+
+    def trsm_left(self, L, dinv, B):
+        if B.numel():
+            B.copy_(torch.linalg.solve_triangular(torch.tril(L), B, upper=False))
+
+    def gemm_nn_sub(self, C, A, B):
+        if C.numel():
+            C.sub_(A @ B)
+
+    def coldots(self, V, w):
+        return V.T @ w, (V * V).sum(dim=0)
+
+    def pairwise_variance(self, cov, xt, covparam):
+        return torch.as_tensor(np.ascontiguousarray(cov(xt.numpy(), None, covparam, True)))

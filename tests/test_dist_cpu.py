@@ -135,6 +135,61 @@ def test_block_cyclic_not_positive_definite(tmp_path):
     assert info == 301 and math.isinf(nll)      # LAPACK-style 1-based leading minor; criterion -> +inf
 
 
+def _cov_full(x, y, t, pairwise=False):
+    """covariance callable with the reference's signature (y None -> the tt / pairwise path)"""
+    return orc.maternp_covariance(np.asarray(x), None if y is None else np.asarray(y), 2, t, pairwise)
+
+
+def _dist_predict_worker(rank, world, port, pr, pc, n, m, nb, out, transport):
+    _init(rank, world, port)
+    try:
+        from gpmp_amd.dist import BlockCyclicCholesky, ProcessGrid
+        from tests.cpu_local_ops import CpuLocalOps
+
+        x, z = make_xz(n, 3, 7)
+        xt, _ = make_xz(m, 3, 8)
+        th = theta_aniso(3, scale=0.4)
+        grid = ProcessGrid(pr, pc)
+        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=CpuLocalOps(), transport=transport)
+        ch.build_local_gram(_cov, x, th, 1e-6)
+        assert ch.factor() == 0
+        mean, var, (j0, j1) = ch.predict_zero_mean(_cov_full, x, z, xt, th)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (grid.r, grid.c, j0, j1, mean, var))
+        if rank == 0:
+            zpm, zpv = np.full(m, np.nan), np.full(m, np.nan)
+            for (r, c, a, b, mu, v) in gathered:
+                if r == 0:
+                    zpm[a:b], zpv[a:b] = mu, v
+                else:       # every rank of a process column holds the same shard
+                    assert np.array_equal(zpm[a:b], mu) or np.allclose(zpm[a:b], mu, rtol=0, atol=1e-13)
+            np.save(out, np.stack([zpm, zpv]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pr,pc,n,m,nb,transport", [(1, 2, 500, 77, 128, "bcast"), (2, 1, 500, 77, 128, "bcast"), (2, 2, 1000, 301, 128, "bcast"),
+                                                    (2, 2, 700, 130, 256, "p2p"), (2, 4, 1900, 403, 128, "bcast"), (2, 4, 1900, 3, 128, "p2p")])
+def test_block_cyclic_many_rhs_solve_and_predict(tmp_path, pr, pc, n, m, nb, transport):
+    """predict mean + variance from the 2-D block-cyclic factor (many-right-hand-side forward solve with the prediction
+    points split over the process columns) against the oracle's two-solve route; m = 3 on 4 process columns leaves one
+    column without any point"""
+    world = pr * pc
+    out = str(tmp_path / "p.npy")
+    mp.spawn(_dist_predict_worker, args=(world, _free_port(), pr, pc, n, m, nb, out, transport), nprocs=world, join=True)
+    got = np.load(out)
+    x, z = make_xz(n, 3, 7)
+    xt, _ = make_xz(m, 3, 8)
+    th = theta_aniso(3, scale=0.4)
+    K = orc.maternp_covariance_it(x, x, 2, th) + 1e-6 * np.eye(n)
+    Kit = orc.maternp_covariance_it(x, xt, 2, th)
+    lam = np.linalg.solve(K, Kit)
+    ref_mean = lam.T @ z
+    ref_var = orc.maternp_covariance(xt, None, 2, th, True) - np.einsum("ij,ij->j", lam, Kit)
+    assert np.max(np.abs(got[0] - ref_mean)) < 1e-8 * np.max(np.abs(z))
+    assert np.max(np.abs(got[1] - ref_var)) < 1e-8
+
+
 class _OracleBackedModel:
     """predict() with the reference semantics, computed by the CPU oracle (stand-in for gpmp_amd.Model)."""
 

@@ -101,3 +101,56 @@ def _run_and_check(tmp_path, pr, pc, n, nb, transport, lookahead, backend):
     om = orc.OracleModel(None, lambda a, b, t, pairwise=False: orc.maternp_covariance(a, b, 2, t, pairwise), None, th, "zero")
     ref = float(orc.negative_log_likelihood_zero_mean(om, th, x, z))
     assert abs(nll - ref) < 1e-8 * abs(ref)
+
+
+def _predict_worker(rank, world, port, pr, pc, n, m, nb, out, transport):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gpmp_amd.num as gnp
+        from gpmp_amd.dist import BlockCyclicCholesky, HipLocalOps, ProcessGrid
+        from gpmp_amd.kernel import MaternCovariance
+
+        x, z = make_xz(n, 4, 11)
+        xt, _ = make_xz(m, 4, 12)
+        th = theta_aniso(4, scale=0.5)
+        cov = MaternCovariance(2)
+        grid = ProcessGrid(pr, pc)
+        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=HipLocalOps(), transport=transport)
+        ch.build_local_gram(cov, x, th, 10.0 * math.exp(th[0]) * gnp.eps)
+        assert ch.factor() == 0
+        mean, var, (j0, j1) = ch.predict_zero_mean(cov, x, z, xt, th)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (grid.r, j0, j1, mean, var))
+        if rank == 0:
+            zpm, zpv = np.full(m, np.nan), np.full(m, np.nan)
+            for (r, a, b, mu, v) in gathered:
+                if r == 0:
+                    zpm[a:b], zpv[a:b] = mu, v
+            np.save(out, np.stack([zpm, zpv]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pr,pc,n,m,nb,transport", [(1, 1, 1500, 700, 512, "bcast"), (2, 2, 2000, 901, 256, "bcast"), (1, 2, 1500, 333, 256, "p2p")])
+def test_block_cyclic_predict_hip(tmp_path, pr, pc, n, m, nb, transport):
+    """many-right-hand-side solve on the block-cyclic factor with the real kernels (ranks share the test GPU over gloo):
+    posterior mean / variance against the oracle's predict"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+
+    world = pr * pc
+    out = str(tmp_path / "p.npy")
+    mp.spawn(_predict_worker, args=(world, _free_port(), pr, pc, n, m, nb, out, transport), nprocs=world, join=True)
+    got = np.load(out)
+    x, z = make_xz(n, 4, 11)
+    xt, _ = make_xz(m, 4, 12)
+    th = theta_aniso(4, scale=0.5)
+    om = orc.OracleModel(None, lambda a, b, t, pairwise=False: orc.maternp_covariance(a, b, 2, t, pairwise), None, th, "zero")
+    rm, rv = orc.predict(om, x, z, xt, zero_neg_variances=False)
+    assert np.max(np.abs(got[0] - rm)) < 1e-8 * np.max(np.abs(z))
+    assert np.max(np.abs(got[1] - rv)) < 1e-8
