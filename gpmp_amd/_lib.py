@@ -10,7 +10,8 @@ import os
 from ctypes import c_char_p, c_double, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpmp_hip.so")
+# GPMP_HIP_LIB: another build of the same library (the host-sanitizer build `make -C gpmp_amd/csrc asan`)
+LIB_PATH = os.environ.get("GPMP_HIP_LIB") or os.path.join(_HERE, "libgpmp_hip.so")
 
 _lib = None
 

@@ -11,6 +11,7 @@
 #include "common.h"
 #include <vector>
 #include <cstdlib>
+#include <mutex>
 
 namespace gpmp {
 namespace {
@@ -211,6 +212,12 @@ struct LookAhead {
   }
 };
 LookAhead g_la;
+// The helper stream, the event pool and the solve stream belong to the device that was current when they were created,
+// and the pool is reset at every factorisation: ONE device per process and one look-ahead factorisation being enqueued at
+// a time.  Both are enforced here rather than assumed: a second host thread waits at the mutex (enqueueing takes
+// microseconds), a call on another device is refused with an error.
+std::mutex g_la_mu;
+int g_la_device = -1;
 
 // Factor the panel of columns [p0, p1) (p0, p1 multiples of NB; rows p0 .. n): diagonal blocks in LDS,
 // panel scaling, rank-128 updates inside 512-column sub-panels and rank-512 updates between them.
@@ -272,6 +279,17 @@ struct SolveAlong {
 hipStream_t g_solve_stream = nullptr;
 
 int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hipStream_t s0, const SolveAlong* sa = nullptr) {
+  std::lock_guard<std::mutex> la_lock(g_la_mu);
+  {
+    int dev = 0;
+    GPMP_HIP_TRY(hipGetDevice(&dev));
+    if (g_la_device < 0) g_la_device = dev;
+    if (dev != g_la_device) {
+      set_error("the library's helper streams were created on device %d; this call runs on device %d (one device per process)",
+                g_la_device, dev);
+      return -1;
+    }
+  }
   // panel boundaries: 1024-wide panels while the trailing matrix is large (rank-1024 updates run at
   // ~89 % of the MFMA peak against ~84 % for rank-512, and the longer panel still hides behind them),
   // 512-wide afterwards (shorter latency-bound tail)
