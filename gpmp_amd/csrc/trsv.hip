@@ -189,6 +189,7 @@ struct TrsvP {
   long ldb;
   int n, m, nblk;
   unsigned int* state;
+  unsigned int spin_limit;      // polls of one wait before the solve gives up (GPMP_TRSV_SPIN_LOG2, default 2^26: tens of seconds)
 };
 
 template <int R, bool TRANS>
@@ -254,7 +255,7 @@ __global__ void __launch_bounds__(256) trsv_persist_kernel(TrsvP p) {
       if (t == 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(st + 4 + k, GPMP_RLX_AGENT) == 0u) {
-          if (__hip_atomic_load(st + 1, GPMP_RLX_AGENT) != 0u || ++spins > (1u << 22)) {
+          if (__hip_atomic_load(st + 1, GPMP_RLX_AGENT) != 0u || ++spins > p.spin_limit) {
             __hip_atomic_store(st + 1, 1u, GPMP_RLX_AGENT);   // give up everywhere: the result is poisoned below
             s_blk = -1;
             break;
@@ -374,7 +375,13 @@ int run_persist(const double* L, int n, long ldl, const double* dinv, double* B,
   int rc = state_for(st, ss, ncu);
   if (rc) return rc;
   GPMP_HIP_TRY(hipMemsetAsync(ss.words, 0, sizeof(unsigned int) * (size_t)((4 + nblk + 3) / 4 * 4), st));
-  TrsvP p{L, ldl, dinv, B, ldb, n, m, nblk, ss.words};
+  static unsigned int spin_limit = 0;
+  if (spin_limit == 0) {
+    const char* e = getenv("GPMP_TRSV_SPIN_LOG2");
+    const int lg = e ? atoi(e) : 26;
+    spin_limit = 1u << (lg < 8 ? 8 : (lg > 31 ? 31 : lg));
+  }
+  TrsvP p{L, ldl, dinv, B, ldb, n, m, nblk, ss.words, spin_limit};
   const int grid = nblk < ncu ? nblk : ncu;
   if (!trans) hipLaunchKernelGGL((trsv_persist_kernel<R, false>), dim3(grid), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((trsv_persist_kernel<R, true>), dim3(grid), dim3(256), 0, st, p);

@@ -403,11 +403,15 @@ def test_single_vector_solves_eight_streams_in_flight(gnp):
                                       gnp._ld(Cs[s]), 1, gnp._stream()), "gpmp_dgemm")
             outs.append(F.solve_lower(z, trans=(s >= 4)))
     torch.cuda.synchronize()
-    for s, got in enumerate(outs):
-        assert torch.equal(got, refs[s % 4][1 if s >= 4 else 0]), s
+    gave_up = []
     for st in streams:
         status = ctypes.c_int(-1)
-        assert lib.gpmp_solve_status(ctypes.c_void_p(st.cuda_stream), ctypes.byref(status)) == 0 and status.value == 0
+        assert lib.gpmp_solve_status(ctypes.c_void_p(st.cuda_stream), ctypes.byref(status)) >= 0
+        gave_up.append(status.value)
+    nans = [int(torch.isnan(o).sum()) for o in outs]
+    assert gave_up == [0] * 8 and nans == [0] * 8, (gave_up, nans)
+    for s, got in enumerate(outs):
+        assert torch.equal(got, refs[s % 4][1 if s >= 4 else 0]), s
 
 
 @pytest.mark.parametrize("n,m", [(1536, 700), (2048, 1024), (1280, 514), (1500, 900)])
