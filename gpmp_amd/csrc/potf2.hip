@@ -135,33 +135,82 @@ __global__ void __launch_bounds__(THREADS) potf2_inv_kernel(double* __restrict__
     for (int j = 0; j < NSB; ++j) {
       const int j0 = j * SB;
       double* Djj = S + ((j * (j + 1) / 2 + j) << 8);   // diagonal sub-block image
-      // ---- A1: diagonal 16 x 16 block, wave 0, row (lane & 15) in registers
+      // ---- A1: diagonal 16 x 16 block, wave 0, in the MFMA accumulator layout: lane (g, i) = (lane >> 4, lane & 15) holds
+      // C[g + 4 r][i], r = 0..3 -- the full symmetric block, read from its lower triangle.  Blocked by 4 columns: by symmetry
+      // register s of lane group g IS column 4 s + g (entry of row i on lane i), so
+      //   * the four columns of a step are factored in place: pivot by v_readlane, scaling on one lane group, the update of
+      //     the (at most three) later columns of the step with the scaled column broadcast across the lane groups by
+      //     v_permlane16_swap / v_permlane32_swap (gfx950; 4 VALU instructions per double, no LDS round trip);
+      //   * the rank-4 update of the whole block by these columns is ONE v_mfma_f64_16x16x4_f64 whose A and B operands are
+      //     that same register (A[row i][k = g] = L[i][4 s + g] = B[k = g][col i]), zeroed above the diagonal so that rows of
+      //     earlier steps (which by now hold L) receive exactly 0.
+      // The row-per-lane version spent 2.7 us per 16 x 16 block, 21 of the kernel's 46 us, on ~75 instructions per column
+      // (two v_readlane per multiplier of the rank-one updates); this one issues ~35 and four MFMAs per block.
       if (wave == 0) {
-        double a[SB];
+        const int g = lane >> 4, i16 = lane & 15;
+        d4 acc;
 #pragma unroll
-        for (int c = 0; c < SB; ++c) a[c] = Djj[sidx(lr, c)];
-#pragma unroll
-        for (int c = 0; c < SB; ++c) {
-          double d = bcast_lane(a[c], c);
-          if (!(d > 0.0)) {  // also NaN
-            if (lane == 0 && j0 + c < jb) atomicCAS(info, 0, offset + j0 + c + 1);
-            d = 1.0;
-          }
-          const double y = rsqrt_full(d);
-          double s = d * y;
-          s = fma(0.5 * y, fma(-s, s, d), s);   // one correction step: sqrt(d) to < 1 ulp
-          a[c] = (lane == c) ? s : a[c] * y;
-          if (lane == c) dg[j0 + c] = y;
-#pragma unroll
-          for (int k = c + 1; k < SB; ++k) {
-            const double lkc = bcast_lane(a[c], k);
-            a[k] = fma(-a[c], lkc, a[k]);
-          }
+        for (int r = 0; r < 4; ++r) {
+          const int row = g + 4 * r;
+          acc[r] = Djj[row >= i16 ? sidx(row, i16) : sidx(i16, row)];
         }
-        if (lane < SB) {
+        unsigned badmask = 0;                  // bit c: pivot c was not positive (also NaN); uniform, off the dependency chain
+        double ykeep = 0.0;                    // 1 / L_cc of the column this lane owns on its diagonal row (lane (g, 4 s + g))
 #pragma unroll
-          for (int c = 0; c < SB; ++c) Djj[sidx(lr, c)] = (c <= lane) ? a[c] : 0.0;
+        for (int s4 = 0; s4 < 4; ++s4) {
+          // the four columns of the step on EVERY lane (x[t] = entry of row i16 in column 4 s4 + t): two permlane rounds
+          // per 32-bit half, once per step; from here on the step is lane-local except for uniform v_readlane broadcasts
+          double x[4];
+          {
+            const double v = acc[s4];
+            const int lo = __double2loint(v), hi = __double2hiint(v);
+            const auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);   // [0]: v0 v0 v2 v2   [1]: v1 v1 v3 v3
+            const auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+            const auto la = __builtin_amdgcn_permlane32_swap(l16[0], l16[0], false, false);   // [0]: v0 x 4   [1]: v2 x 4
+            const auto ha = __builtin_amdgcn_permlane32_swap(h16[0], h16[0], false, false);
+            const auto lb = __builtin_amdgcn_permlane32_swap(l16[1], l16[1], false, false);   // [0]: v1 x 4   [1]: v3 x 4
+            const auto hb = __builtin_amdgcn_permlane32_swap(h16[1], h16[1], false, false);
+            x[0] = __hiloint2double(ha[0], la[0]);
+            x[1] = __hiloint2double(hb[0], lb[0]);
+            x[2] = __hiloint2double(ha[1], la[1]);
+            x[3] = __hiloint2double(hb[1], lb[1]);
+          }
+          double sq[4], yy[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int c = 4 * s4 + t;
+            const double d = bcast_lane(x[t], c);
+            badmask |= (!(d > 0.0)) ? (1u << c) : 0u;      // a failed pivot lets NaN / inf run through (the factor is unspecified then)
+            // 1 / sqrt(d): hardware estimate + one third-order step y (1 + e/2 + 3 e^2 / 8), e = 1 - d y^2
+            double y = __builtin_amdgcn_rsq(d);
+            const double e = fma(-(d * y), y, 1.0);
+            y = fma(y * e, fma(0.375, e, 0.5), y);
+            x[t] *= y;
+#pragma unroll
+            for (int tp = t + 1; tp < 4; ++tp) x[tp] = fma(-x[t], bcast_lane(x[t], 4 * s4 + tp), x[tp]);
+            // diagonal entry sqrt(d) = d y with one correction (< 1 ulp): uniform, off the chain
+            double sd = d * y;
+            sd = fma(0.5 * y, fma(-sd, sd, d), sd);
+            sq[t] = sd;
+            yy[t] = y;
+          }
+          // back to one column per lane group: group g takes column 4 s4 + g; zero above the diagonal
+          const double xg = g == 0 ? x[0] : g == 1 ? x[1] : g == 2 ? x[2] : x[3];
+          const double sg = g == 0 ? sq[0] : g == 1 ? sq[1] : g == 2 ? sq[2] : sq[3];
+          const double yg = g == 0 ? yy[0] : g == 1 ? yy[1] : g == 2 ? yy[2] : yy[3];
+          const int cdiag = 4 * s4 + g;
+          const double xz = i16 > cdiag ? xg : (i16 == cdiag ? sg : 0.0);
+          ykeep = i16 == cdiag ? yg : ykeep;
+          if (s4 < 3) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xz, xz, acc, 0, 0, 0);
+          acc[s4] = xz;
         }
+        if (badmask != 0 && lane == 0) {
+          const int badcol = __builtin_ctz(badmask);
+          if (j0 + badcol < jb) atomicCAS(info, 0, offset + j0 + badcol + 1);
+        }
+        if (((i16 - g) & 3) == 0 && i16 >= g) dg[j0 + i16] = ykeep;      // lane (g, 4 s + g) owns 1 / L_cc of column c = 4 s + g
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) Djj[sidx(i16, 4 * s4 + g)] = acc[s4];
       } else if (j >= 1) {
         a3_blocks(j - 1, wave, THREADS / 64 - 1, 1 << 30);   // b = 1, 2, ... of A3(j-1) over waves 1..7 (b = 0 was wave 0's)
       }
