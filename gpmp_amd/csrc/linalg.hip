@@ -298,10 +298,17 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   if (lean_above < 0) { const char* e = getenv("GPMP_POTRF_LEAN_ABOVE"); lean_above = e ? atoi(e) : 4096; }
   static int along_lean = -1;
   if (along_lean < 0) { const char* e = getenv("GPMP_POTRF_ALONG_LEAN"); along_lean = e ? atoi(e) : 0; }
+  // ... and narrower still once the trailing matrix is so small that the panel chain is all that is left: with 256- or
+  // 128-column panels the in-panel rank-128 updates and most of the look-ahead update move from the chain (helper stream)
+  // to the trailing update on the caller's stream, which has the machine to itself there
+  static int w256_below = -1, w128_below = -1;
+  if (w256_below < 0) { const char* e = getenv("GPMP_POTRF_W256_BELOW"); w256_below = e ? atoi(e) : 4096; }
+  if (w128_below < 0) { const char* e = getenv("GPMP_POTRF_W128_BELOW"); w128_below = e ? atoi(e) : 0; }
   std::vector<int> pb;
   for (int p = 0; p < n;) {
     pb.push_back(p);
-    p += (n - p > wide_thresh) ? 2 * OUTER_BLOCKS * NB : OUTER_BLOCKS * NB;
+    const int rest = n - p;
+    p += rest > wide_thresh ? 2 * OUTER_BLOCKS * NB : (rest <= w128_below ? NB : (rest <= w256_below ? 2 * NB : OUTER_BLOCKS * NB));
   }
   pb.push_back(n);
   const int np = (int)pb.size() - 1;
@@ -347,6 +354,16 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     rc = launch_gemm(true, true, n - p1, p2 - p1, w, -1.0, A + (long)p1 * lda + p0, lda, A + (long)p1 * lda + p0, lda,
                      1.0, A + (long)p1 * lda + p1, lda, lower, s1);
     if (rc) return rc;
+    // chain-bound tail: the trailing update of this step starts only when the look-ahead update above has finished, so
+    // that the latter -- on the critical chain -- does not share the machine with it (kernel trace, n = 4096: 12 us alone,
+    // 37 us when both start together); the trailing update has slack there
+    static int main_after_la_below = -1;
+    if (main_after_la_below < 0) { const char* e = getenv("GPMP_POTRF_MAIN_AFTER_LA_BELOW"); main_after_la_below = e ? atoi(e) : 4096; }
+    hipEvent_t e_main_go = e_f;
+    if (n - p1 <= main_after_la_below) {
+      e_main_go = g_la.next();
+      GPMP_HIP_TRY(hipEventRecord(e_main_go, s1));
+    }
     // (the main stream's update of this iteration covers (n - p2)^2 / 2: with at least two rounds of tiles it holds every
     //  workgroup slot of the machine while this panel is factored)
     // (with the panel-by-panel solve the solve stream's GEMMs hold the slots instead)
@@ -384,7 +401,7 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
       GPMP_HIP_TRY(hipEventRecord(e_half, g_solve_stream));
     }
     // -- main: rank-w update of the rest of the trailing matrix with P_k
-    GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_f, 0));
+    GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_main_go, 0));
     if (p2 < n) {
       rc = launch_gemm(true, true, n - p2, n - p2, w, -1.0, A + (long)p2 * lda + p0, lda, A + (long)p2 * lda + p0, lda,
                        1.0, A + (long)p2 * lda + p2, lda, lower, s0);
