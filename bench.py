@@ -50,6 +50,7 @@ def pmc_traffic_per_launch(kernel_substr):
 
     tot = 0.0
     n_disp = None
+    pmc_traffic_per_launch.source = None
     for name, factor in (("fetch", 2.0), ("write", 1.0)):
         import re
 
@@ -61,6 +62,7 @@ def pmc_traffic_per_launch(kernel_substr):
         if not found:
             return None
         path = found[-1]   # the latest committed pass
+        pmc_traffic_per_launch.source = os.path.relpath(os.path.dirname(path), ROOT) + "/" + re.sub(r"_(fetch|write)_", "_{fetch,write}_", os.path.basename(path))
         for row in csv.DictReader(open(path)):
             if kernel_substr in row["kernel"]:
                 tot += factor * 1024.0 * float(row["per_dispatch_KB_raw"])
@@ -463,8 +465,9 @@ def main():
             "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": (nn_exec / (nn_ms * 1e-3) / 1e12) / FP64_MFMA_PEAK_TFLOPS if nn_ms > 0 else None,
             "traffic": pmc_traffic_per_launch("gemm_f64_kernel_v2<true, false, true>") if (n, m) == (32768, 50000) else None,
-            "traffic_note": "bytes per launch at the fabric side of L2 (Infinity-Cache hits included), from the committed "
-                            "PMC passes in profiles/r1/ (FETCH_SIZE x2 + WRITE_SIZE)",
+            "traffic_note": "NOT measured in this run: bytes per launch at the fabric side of L2 (Infinity-Cache hits included) from the "
+                            "latest COMMITTED rocprofv3 --pmc passes of this same command (separate FETCH_SIZE / WRITE_SIZE passes, "
+                            "FETCH_SIZE x2 on gfx950 + WRITE_SIZE): " + str(getattr(pmc_traffic_per_launch, "source", None)),
             "launches_per_step": nn_cnt / steps, "avg_launch_ms": nn_ms / max(nn_cnt, 1),
             "algorithmic_flops_per_launch": nn_exec / max(nn_cnt, 1),
             "share_of_solve_flops": nn_exec / alg_solve,
