@@ -1,5 +1,6 @@
 /* Host program on the C ABI alone (no Python, no torch): zero-mean Matern-5/2 kriging at m points and the
- * negative log-likelihood through the two fused drivers of include/gpmp_hip.h.
+ * negative log-likelihood through the fused drivers of include/gpmp_hip.h, then -- with a constant mean, P = ones(n, 1) --
+ * the restricted likelihood with its analytic gradient (gpmp_nll_grad) and leave-one-out (gpmp_loo).
  *
  *   gcc -std=c99 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_abi_predict.c -Lgpmp_amd -lgpmp_hip \
  *       -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,$PWD/gpmp_amd -o c_abi_predict
@@ -53,5 +54,25 @@ int main(int argc, char** argv) {
   const int k = m < 4 ? m : 4;
   CK(hipMemcpy(hm, zpm, sizeof(double) * k, hipMemcpyDeviceToHost)); CK(hipMemcpy(hv, zpv, sizeof(double) * k, hipMemcpyDeviceToHost));
   for (int i = 0; i < k; ++i) printf("xt[%d]: mean %.12e  var %.6e\n", i, hm[i], hv[i]);
+
+  /* constant-mean model: REML value + gradient (what each optimiser evaluation needs) and leave-one-out */
+  const int q = 1;
+  double *P = malloc(sizeof(double) * n), *dP, *ws2, *val, *grad, *zl, *s2, *el;
+  for (int i = 0; i < n; ++i) P[i] = 1.0;
+  const size_t wg = gpmp_nll_grad_ws_elems(n, d, q), wo = gpmp_loo_ws_elems(n, q);
+  CK(hipMalloc((void**)&dP, sizeof(double) * n)); CK(hipMemcpy(dP, P, sizeof(double) * n, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&ws2, sizeof(double) * (wg > wo ? wg : wo)));
+  CK(hipMalloc((void**)&val, sizeof(double))); CK(hipMalloc((void**)&grad, sizeof(double) * (1 + d)));
+  CK(hipMalloc((void**)&zl, sizeof(double) * n)); CK(hipMalloc((void**)&s2, sizeof(double) * n)); CK(hipMalloc((void**)&el, sizeof(double) * n));
+  GK(gpmp_nll_grad(dxi, dzi, dP, 1, n, d, q, p, theta, 0, ws2, val, grad, info, NULL));
+  double hval, hgrad[1 + 4];
+  CK(hipMemcpy(&hval, val, sizeof(double), hipMemcpyDeviceToHost)); CK(hipMemcpy(hgrad, grad, sizeof(double) * (1 + d), hipMemcpyDeviceToHost));
+  CK(hipMemcpy(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost));
+  printf("reml=%.12e  info=%d\n", hval, hinfo);
+  for (int j = 0; j < 1 + d; ++j) printf("dreml[%d] %.12e\n", j, hgrad[j]);
+  GK(gpmp_loo(dxi, dzi, dP, 1, n, d, q, p, theta, 0, ws2, zl, s2, el, info, NULL));
+  double hz[3], hs[3];
+  CK(hipMemcpy(hz, zl, sizeof(double) * 3, hipMemcpyDeviceToHost)); CK(hipMemcpy(hs, s2, sizeof(double) * 3, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 3; ++i) printf("loo[%d]: zloo %.12e  s2loo %.6e\n", i, hz[i], hs[i]);
   return hinfo != 0;
 }

@@ -505,6 +505,21 @@ def test_c_host_example_matches_python_path(gp, gnp):
     assert abs(nll_c - nll) <= 1e-10 * abs(nll)
     np.testing.assert_allclose(means, zpm[:4], rtol=0, atol=1e-9)
     np.testing.assert_allclose(variances, zpv[:4], rtol=1e-5, atol=1e-12)
+    # the constant-mean part of the example: REML value + gradient, leave-one-out
+    from gpmp_amd.core.gradients import REMLAnalytic
+
+    mc = gp.Model(constant_mean, gp.kernel.MaternCovariance(2), None, theta)
+    crit = REMLAnalytic(mc)
+    v, st = crit.value_and_state(theta, gnp.asarray(xi), gnp.asarray(zi))
+    g = crit.gradient_from_state(st)
+    reml_c = float(re.search(r"reml=([-+0-9.eE]+)", out).group(1))
+    grad_c = [float(v_) for v_ in re.findall(r"dreml\[\d+\] ([-+0-9.eE]+)", out)]
+    assert abs(reml_c - v) <= 1e-11 * abs(v) and rel_err(grad_c, g) < 1e-9
+    zl, sl, _ = mc.loo(xi, zi)
+    zloo_c = [float(v_) for v_ in re.findall(r"zloo ([-+0-9.eE]+)", out)]
+    s2_c = [float(v_) for v_ in re.findall(r"s2loo ([-+0-9.eE]+)", out)]
+    np.testing.assert_allclose(zloo_c, gnp.to_np(zl)[:3], rtol=1e-9)
+    np.testing.assert_allclose(s2_c, gnp.to_np(sl)[:3], rtol=1e-5)
 
 
 def test_c_abi_nll_driver_reports_failure_as_inf(gnp):
