@@ -34,6 +34,14 @@ __global__ void pad_identity_kernel(double* __restrict__ K, long ld, int n, int 
   if (i >= nmax || j >= nmax || j > i) return;
   K[(long)i * ld + j] = (i == j) ? 1.0 : 0.0;
 }
+// the same for every slot of a batch in one launch (blockIdx.z = problem, sizes from the device array)
+__global__ void pad_identity_batch_kernel(double* __restrict__ Kall, long ld, long stride, const int* __restrict__ ns, int nmax) {
+  const int n = ns[blockIdx.z];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (i < n || i >= nmax || j >= nmax || j > i) return;
+  Kall[(long)blockIdx.z * stride + (long)i * ld + j] = (i == j) ? 1.0 : 0.0;
+}
 
 // Y_b[i] = [z_b[i], P_b[i, :]] for i < n_b, zeros in the padding
 __global__ void batch_pack_kernel(const double* __restrict__ z, long sz, const double* __restrict__ P, long ldp, long sp, int q,
@@ -334,18 +342,32 @@ extern "C" int gpmp_nll_grad_batch(const double* x, long stride_x, const double*
     hipLaunchKernelGGL(fill_int_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ns, B, nmax);
     GPMP_HIP_TRY(hipGetLastError());
   }
-  // ---- Gram matrices (lower tiles), identity in the padding
-  for (int b = 0; b < B; ++b) {
-    const int nb = n_host != nullptr ? n_host[b] : nmax;
-    const double* th = theta_host + (long)b * theta_stride;
-    const double sigma2 = std::exp(th[0]);
-    const double diag = noise ? std::exp(th[1]) : 10.0 * sigma2 * DBL_EPSILON;      // matern.py:90
-    double* Kb = K + (size_t)b * l.sK;
-    int rc = gpmp_matern_gram(x + (long)b * stride_x, nullptr, nb, nb, d, p, th, noise, diag, 1, Kb, l.ld, stream);
-    if (rc) return rc;
-    if (nb < nmax) {
-      hipLaunchKernelGGL(pad_identity_kernel, dim3((nmax + 255) / 256, nmax - nb), dim3(256), 0, st, Kb, l.ld, nb, nmax);
+  // ---- Gram matrices (lower tiles), identity in the padding: ONE launch each when the problems share their parameters
+  // (mini-batches of a loader), one small launch per problem otherwise (their parameters travel in the kernel arguments)
+  bool ragged = false;
+  for (int b = 0; n_host != nullptr && b < B; ++b) ragged = ragged || n_host[b] < nmax;
+  if (theta_stride == 0) {
+    const double sigma2 = std::exp(theta_host[0]);
+    const double diag = noise ? std::exp(theta_host[1]) : 10.0 * sigma2 * DBL_EPSILON;      // matern.py:90
+    int rc0 = launch_gram_lower_batch(x, stride_x, ns, nmax, d, p, theta_host, noise, diag, K, l.ld, (long)l.sK, B, st);
+    if (rc0) return rc0;
+    if (ragged) {
+      hipLaunchKernelGGL(pad_identity_batch_kernel, dim3((nmax + 255) / 256, nmax, B), dim3(256), 0, st, K, l.ld, (long)l.sK, ns, nmax);
       GPMP_HIP_TRY(hipGetLastError());
+    }
+  } else {
+    for (int b = 0; b < B; ++b) {
+      const int nb = n_host != nullptr ? n_host[b] : nmax;
+      const double* th = theta_host + (long)b * theta_stride;
+      const double sigma2 = std::exp(th[0]);
+      const double diag = noise ? std::exp(th[1]) : 10.0 * sigma2 * DBL_EPSILON;      // matern.py:90
+      double* Kb = K + (size_t)b * l.sK;
+      int rc0 = gpmp_matern_gram(x + (long)b * stride_x, nullptr, nb, nb, d, p, th, noise, diag, 1, Kb, l.ld, stream);
+      if (rc0) return rc0;
+      if (nb < nmax) {
+        hipLaunchKernelGGL(pad_identity_kernel, dim3((nmax + 255) / 256, nmax - nb), dim3(256), 0, st, Kb, l.ld, nb, nmax);
+        GPMP_HIP_TRY(hipGetLastError());
+      }
     }
   }
   // ---- Cholesky of every slot, each kernel batched over the problems
@@ -378,12 +400,18 @@ extern "C" int gpmp_nll_grad_batch(const double* x, long stride_x, const double*
   if (rc) return rc;
   rc = lauum_lower_batch(T, nmax, l.ld, (long)l.sK, K, l.ld, (long)l.sK, B, st);
   if (rc) return rc;
-  for (int b = 0; b < B; ++b) {
-    const int nb = n_host != nullptr ? n_host[b] : nmax;
-    rc = gpmp_matern_grad_trace(K + (size_t)b * l.sK, l.ld, x + (long)b * stride_x, nb, d, p, theta_host + (long)b * theta_stride, noise,
-                                ws + l.F + (size_t)b * l.sY, ws + l.G + (size_t)b * l.sY, q + 1, l.ldq, grads_dev + (size_t)b * ntheta,
-                                ws + l.gws + (size_t)b * l.sG, stream);
+  if (theta_stride == 0) {
+    rc = launch_grad_trace_batch(K, l.ld, (long)l.sK, x, stride_x, ns, nmax, d, p, theta_host, noise, ws + l.F, ws + l.G, q + 1, l.ldq,
+                                 (long)l.sY, grads_dev, ws + l.gws, B, st);
     if (rc) return rc;
+  } else {
+    for (int b = 0; b < B; ++b) {
+      const int nb = n_host != nullptr ? n_host[b] : nmax;
+      rc = gpmp_matern_grad_trace(K + (size_t)b * l.sK, l.ld, x + (long)b * stride_x, nb, d, p, theta_host + (long)b * theta_stride, noise,
+                                  ws + l.F + (size_t)b * l.sY, ws + l.G + (size_t)b * l.sY, q + 1, l.ldq, grads_dev + (size_t)b * ntheta,
+                                  ws + l.gws + (size_t)b * l.sG, stream);
+      if (rc) return rc;
+    }
   }
   hipLaunchKernelGGL(batch_grad_finalize_kernel, dim3((ntheta * B + 255) / 256), dim3(256), 0, st, grads_dev, ntheta, B, info_dev);
   GPMP_HIP_TRY(hipGetLastError());

@@ -103,6 +103,11 @@ struct GramParams {
   double scale[GPMP_MAX_DIM];    // mode 0: 2 c / rho_j (the tile accumulates t^2 = (2 c h)^2); mode 1: 1 / rho_j
   double q[GPMP_MAX_P + 1];      // sigma^2 q_k:  K(h) = exp(-t/2) sum_k q_k t^k
   FastExp fe;
+  // batched over blockIdx.z (many small problems with the SAME parameters): problem b reads x + b * stride_x, writes
+  // K + b * stride_k and has ns[b] points (ns == NULL: n)
+  int nprob;
+  long stride_x, stride_k;
+  const int* ns;
 };
 
 // 128 x 64 output tile per 256-thread workgroup, 8 x 4 outputs per thread.
@@ -115,6 +120,12 @@ __global__ void __launch_bounds__(256) gram_kernel_v3(GramParams p) {
   const int tj = blockIdx.x, ti = blockIdx.y;
   const int row0 = ti * 128, col0 = tj * GT;
   if (p.lower_only && col0 > row0 + 127) return;
+  if (p.nprob > 1) {
+    p.x += (long)blockIdx.z * p.stride_x;
+    p.K += (long)blockIdx.z * p.stride_k;
+    if (p.ns != nullptr) p.n = p.m = p.ns[blockIdx.z];
+    if (row0 >= p.n || col0 >= p.m) return;
+  }
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   const double* __restrict__ yp = p.same ? p.x : p.y;
 
@@ -250,7 +261,7 @@ static void fill_fast_exp(FastExp& fe) {
 }
 
 static int launch_gram(const GramParams& gp, hipStream_t st) {
-  dim3 grid((gp.m + GT - 1) / GT, (gp.n + 127) / 128);
+  dim3 grid((gp.m + GT - 1) / GT, (gp.n + 127) / 128, gp.nprob > 1 ? gp.nprob : 1);
   if (gp.mode != 0) {
     hipLaunchKernelGGL((gram_kernel_v3<0, 1>), grid, dim3(256), 0, st, gp);
     return 0;
@@ -319,6 +330,11 @@ struct GradParams {
   int ntiles_side, ntiles;
   double sigma2;
   double* partial;  // [gridDim.x][DT + 2]
+  // batched over blockIdx.y (same parameters): problem b = Kinv + b * stride_kinv, x + b * stride_x, F / G + b * stride_f,
+  // partial + b * stride_partial, ns[b] points
+  int nprob;
+  long stride_kinv, stride_x, stride_f, stride_partial;
+  const int* ns;
   double invrho[GPMP_MAX_DIM];   // 2 c / rho_j: the tile accumulates t^2 = (2 c h)^2 and the weights are per (2 c delta_j)^2
   MaternSpec ms;
   FastExp fe;
@@ -350,6 +366,19 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
 #pragma unroll
   for (int k = 0; k < DT; ++k) gacc[k] = 0.0;
   double g0 = 0.0, gtr = 0.0;
+  if (p.nprob > 1) {
+    const int z = blockIdx.y;
+    p.Kinv += (long)z * p.stride_kinv;
+    p.x += (long)z * p.stride_x;
+    p.F += (long)z * p.stride_f;
+    p.G += (long)z * p.stride_f;
+    p.partial += (long)z * p.stride_partial;
+    if (p.ns != nullptr) {
+      p.n = p.ns[z];
+      p.ntiles_side = (p.n + GT - 1) / GT;
+      p.ntiles = p.ntiles_side * (p.ntiles_side + 1) / 2;
+    }
+  }
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     int ti = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
@@ -476,8 +505,10 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
 
 __global__ void grad_finalize_kernel(const double* __restrict__ partial, int nblocks, int width,
                                      int d, int noise, double sigma2, double nugget_scale,
-                                     double noise_var, double* __restrict__ g) {
-  // one thread per output column of `partial`
+                                     double noise_var, double* __restrict__ g, long stride_partial = 0, int stride_g = 0) {
+  // one thread per output column of `partial`; blockIdx.x = problem of a batched launch
+  partial += (long)blockIdx.x * stride_partial;
+  g += (long)blockIdx.x * stride_g;
   const int k = threadIdx.x;
   if (k >= width) return;
   double s = 0.0;
@@ -566,6 +597,7 @@ extern "C" int gpmp_matern_gram(const double* x, const double* y, int n, int m, 
   GPMP_ARG(ldk >= m, 12, "ldk < m");
   if (n == 0 || m == 0) return 0;
   GramParams gp;
+  gp.nprob = 1; gp.stride_x = gp.stride_k = 0; gp.ns = nullptr;
   gp.x = x; gp.y = y; gp.K = K; gp.ldk = ldk;
   gp.n = n; gp.m = m; gp.d = d;
   gp.same = (y == nullptr); gp.lower_only = (y == nullptr) ? lower_only : 0;
@@ -597,6 +629,7 @@ extern "C" int gpmp_scaled_distance(const double* x, const double* y, int n, int
   GPMP_ARG(D != nullptr && ldd >= m, 7, "D is NULL or ldd < m");
   if (n <= 0 || m <= 0) return 0;
   GramParams gp;
+  gp.nprob = 1; gp.stride_x = gp.stride_k = 0; gp.ns = nullptr;
   gp.x = x; gp.y = y; gp.K = D; gp.ldk = ldd;
   gp.n = n; gp.m = m; gp.d = d;
   gp.same = 0; gp.lower_only = 0;
@@ -656,7 +689,7 @@ int launch_grad(GradParams& gp, int nblocks, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((grad_trace_kernel<DT>), dim3(nblocks), dim3(256), lds, st, gp);
+  hipLaunchKernelGGL((grad_trace_kernel<DT>), dim3(nblocks, gp.nprob > 1 ? gp.nprob : 1), dim3(256), lds, st, gp);
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -666,6 +699,96 @@ extern "C" size_t gpmp_grad_ws_elems(int n, int d) {
   (void)n;
   return (size_t)GRAD_BLOCKS * (grad_tier(d) + 2);
 }
+
+namespace gpmp {
+// ---- batched over many small problems with the SAME parameters (drivers_batch.hip) ---------------------------------
+// Lower-tile Gram matrices of `nprob` problems (points x + b * stride_x, ns[b] of them; matrices K + b * stride_k) in ONE launch.
+int launch_gram_lower_batch(const double* x, long stride_x, const int* ns_dev, int nmax, int d, int p, const double* theta_host,
+                            int noise, double diag_add, double* K, long ldk, long stride_k, int nprob, hipStream_t st) {
+  GramParams gp;
+  gp.nprob = 1; gp.stride_x = gp.stride_k = 0; gp.ns = nullptr;
+  gp.x = x; gp.y = nullptr; gp.K = K; gp.ldk = ldk;
+  gp.n = nmax; gp.m = nmax; gp.d = d;
+  gp.same = 1; gp.lower_only = 1;
+  gp.aligned = ((reinterpret_cast<uintptr_t>(K) & 15) == 0) && ((ldk & 1) == 0) && ((stride_k & 1) == 0);
+  gp.mode = 0;
+  gp.p = p;
+  gp.diag_add = diag_add;
+  MaternSpec ms;
+  fill_matern(ms, p);
+  const double sigma2 = std::exp(theta_host[0]);
+  const int off = noise ? 2 : 1;
+  for (int k = 0; k < d; ++k) gp.scale[k] = 2.0 * ms.c * std::exp(theta_host[off + k]);
+  for (int k = 0; k <= GPMP_MAX_P; ++k) gp.q[k] = sigma2 * ms.q[k];
+  fill_fast_exp(gp.fe);
+  gp.nprob = nprob > 1 ? nprob : 2;      // (a batch of one still takes the batched addressing: ns is read)
+  gp.stride_x = stride_x; gp.stride_k = stride_k; gp.ns = ns_dev;
+  {
+    ProfScope ps(PK_GRAM, st, 4.0 * (double)nmax * (double)nmax * nprob);
+    dim3 grid((nmax + GT - 1) / GT, (nmax + 127) / 128, nprob);
+    switch (p) {
+      case 0: hipLaunchKernelGGL((gram_kernel_v3<0, 0>), grid, dim3(256), 0, st, gp); break;
+      case 1: hipLaunchKernelGGL((gram_kernel_v3<1, 0>), grid, dim3(256), 0, st, gp); break;
+      case 2: hipLaunchKernelGGL((gram_kernel_v3<2, 0>), grid, dim3(256), 0, st, gp); break;
+      case 3: hipLaunchKernelGGL((gram_kernel_v3<3, 0>), grid, dim3(256), 0, st, gp); break;
+      default: hipLaunchKernelGGL((gram_kernel_v3<-1, 0>), grid, dim3(256), 0, st, gp); break;
+    }
+  }
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// The gradient traces of `nprob` problems with the same parameters in ONE launch (+ one finalisation launch):
+// g_dev + b * ntheta <- sum M_b dK_b / dtheta (see gpmp_matern_grad_trace), ws: nprob * gpmp_grad_ws_elems(nmax, d) doubles.
+int launch_grad_trace_batch(const double* Kinv, long ldk, long stride_kinv, const double* x, long stride_x, const int* ns_dev, int nmax,
+                            int d, int p, const double* theta_host, int noise, const double* F, const double* G, int r, long ldf,
+                            long stride_f, double* g_dev, double* ws, int nprob, hipStream_t st) {
+  GradParams gp;
+  gp.Kinv = Kinv; gp.ldk = ldk; gp.x = x; gp.F = F; gp.G = G; gp.ldf = ldf;
+  gp.n = nmax; gp.d = d; gp.r = r;
+  gp.ntiles_side = (nmax + GT - 1) / GT;
+  gp.ntiles = gp.ntiles_side * (gp.ntiles_side + 1) / 2;
+  gp.sigma2 = std::exp(theta_host[0]);
+  gp.partial = ws;
+  const int off = noise ? 2 : 1;
+  fill_matern(gp.ms, p);
+  for (int k = 0; k < d; ++k) gp.invrho[k] = 2.0 * gp.ms.c * std::exp(theta_host[off + k]);
+  fill_fast_exp(gp.fe);
+  // few blocks per problem: the problems themselves fill the machine
+  int nblocks = gp.ntiles < 32 ? gp.ntiles : 32;
+  const int dt = grad_tier(d);
+  gp.nprob = nprob > 1 ? nprob : 2;
+  gp.stride_kinv = stride_kinv; gp.stride_x = stride_x; gp.stride_f = stride_f;
+  gp.stride_partial = (long)GRAD_BLOCKS * (dt + 2);
+  gp.ns = ns_dev;
+  int rc = 0;
+  {
+    GradParams g1 = gp;
+    const size_t lds = sizeof(double) * (2 * (size_t)dt * GT + 2 * (size_t)r * GT);
+    auto go = [&](auto kern) -> int {
+      GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      hipLaunchKernelGGL(kern, dim3(nblocks, nprob), dim3(256), lds, st, g1);
+      GPMP_HIP_TRY(hipGetLastError());
+      return 0;
+    };
+    switch (dt) {
+      case 4: rc = go(grad_trace_kernel<4>); break;
+      case 8: rc = go(grad_trace_kernel<8>); break;
+      case 16: rc = go(grad_trace_kernel<16>); break;
+      case 32: rc = go(grad_trace_kernel<32>); break;
+      default: rc = go(grad_trace_kernel<64>); break;
+    }
+  }
+  if (rc) return rc;
+  const double eps = 2.220446049250313e-16;
+  const double nugget_scale = noise ? 0.0 : 10.0 * eps;
+  const double noise_var = noise ? std::exp(theta_host[1]) : 0.0;
+  hipLaunchKernelGGL(grad_finalize_kernel, dim3(nprob), dim3(128), 0, st, ws, nblocks, dt + 2, d, noise, gp.sigma2, nugget_scale, noise_var,
+                     g_dev, gp.stride_partial, 1 + (noise ? 1 : 0) + d);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+}  // namespace gpmp
 
 extern "C" int gpmp_matern_grad_trace(const double* Kinv, long ldk, const double* x, int n, int d, int p,
                                       const double* theta_host, int noise, const double* F,
@@ -680,6 +803,7 @@ extern "C" int gpmp_matern_grad_trace(const double* Kinv, long ldk, const double
   GPMP_ARG(r == 0 || (F != nullptr && G != nullptr), 9, "F/G NULL with r > 0");
   GPMP_ARG(g_dev != nullptr && ws != nullptr, 13, "g or ws is NULL");
   GradParams gp;
+  gp.nprob = 1; gp.stride_kinv = gp.stride_x = gp.stride_f = gp.stride_partial = 0; gp.ns = nullptr;
   gp.Kinv = Kinv; gp.ldk = ldk; gp.x = x; gp.F = F; gp.G = G; gp.ldf = ldf;
   gp.n = n; gp.d = d; gp.r = r;
   gp.ntiles_side = (n + GT - 1) / GT;
