@@ -913,6 +913,11 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmParams p) {
 // them, so the in-place panel scaling stays race-free), operands HBM -> LDS by LDS-DMA (no staging registers) into
 // ONE 20 KB buffer with the swizzle of the v2 kernel, 32 accumulator VGPRs per wave.  It trades the deep prefetch of
 // gemm_nt_small_kernel (one exposed load latency per launch) for starting at once beside the big GEMM.
+// (waves_per_eu(10, 10) is how the 48-VGPR budget is imposed: 512 / 10 rounded down to the allocation granule.  The hardware
+//  runs at most 8 waves per SIMD, so the compiler reports the occupancy target as unreachable; the register budget is what
+//  the attribute is for, hence the diagnostic is silenced for this one kernel.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(10, 10))) gemm_nt_lean_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) double sA[SBM * BK];
   __shared__ __attribute__((aligned(16))) double sB[SBN * BK];
@@ -991,6 +996,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(10, 10
       }
     }
 }
+
+#pragma clang diagnostic pop
 
 template <bool AKC, bool BKC, bool CACC>
 int launch_t(const GemmParams& p, hipStream_t st) {
