@@ -154,3 +154,18 @@ def test_batch_criterion_fast_path_equals_one_at_a_time(env, golden):
             v2, g2, e2 = pre(t), grad(t).copy(), ev(t)
             assert abs(v1 - v2) < 1e-12 * abs(v2) and abs(e1 - e2) < 1e-12 * abs(e2) and rel_err(g1, g2) < 1e-10
         obj.use_batched_kernel = True
+
+
+@pytest.mark.parametrize("B,n,d,q", [(1, 5, 1, 0), (1, 129, 2, 1), (3, 4, 1, 3), (2, 1024, 6, 2), (17, 130, 3, 0)])
+def test_batch_driver_edge_shapes(env, B, n, d, q):
+    """one problem, tiny problems (n just above q), one-dimensional inputs, the largest slot size, a block boundary + 2"""
+    th = np.concatenate(([0.1], -np.log(0.3 + 0.25 * np.arange(d))))
+    data = [_data(n, d, 900 + 7 * b + n) for b in range(B)]
+    xs, zs = [a for a, _ in data], [b_ for _, b_ in data]
+    Ps = None if q == 0 else [np.hstack((np.ones((n, 1)), x, x ** 2))[:, :q] for x in xs]
+    vals, grads, info = _batch(env, xs, zs, Ps, th, shared=True)
+    assert np.all(info == 0)
+    for b in range(B):
+        v, g, i = _single(env, xs[b], zs[b], None if q == 0 else Ps[b], th)
+        assert i == 0 and abs(vals[b] - v) < 1e-10 * max(1.0, abs(v)), (b, vals[b], v)
+        assert rel_err(grads[b], g) < 1e-8, (b, grads[b], g)

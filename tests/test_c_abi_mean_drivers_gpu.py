@@ -167,3 +167,37 @@ def test_mean_drivers_failure_conventions(env, golden):
     torch, gnp, _lib, lib = env
     assert lib.gpmp_reml_ws_elems(100, 72) == 0                               # q beyond GPMP_MAX_RANK - 1
     assert lib.gpmp_reml(None, None, None, 1, 10, 2, 0, 2, None, 0, None, None, None, None) < 0
+
+
+@pytest.mark.parametrize("n,d,q", [(2, 1, 1), (5, 2, 0), (128, 3, 3), (129, 1, 2), (70, 4, 4)])
+def test_mean_drivers_small_and_boundary_sizes_vs_oracle(env, n, d, q):
+    """n just above q, exactly one diagonal block, one row into the second block: REML / NLL, gradient by central
+    differences of the driver's own value, LOO against the oracle's virtual-CV formulas"""
+    from oracle import gp_oracle as orc
+
+    rng = np.random.default_rng(100 * n + d)
+    x = rng.random((n, d))
+    z = np.sin(3 * x[:, 0]) + x.sum(axis=1) + 0.05 * rng.standard_normal(n)
+    th = np.concatenate(([0.2], -np.log(0.4 + 0.3 * np.arange(d))))
+    P = None if q == 0 else np.hstack((np.ones((n, 1)), x, x ** 2, x ** 3))[:, :q]
+    c = _Call(env, x, z, P, 2)
+    kern = lambda a, b, t, pairwise=False: orc.maternp_covariance(a, b, 2, t, pairwise)  # noqa: E731
+    if q == 0:
+        om = orc.OracleModel(None, kern, None, th, "zero")
+        ref = float(orc.negative_log_likelihood_zero_mean(om, th, x, z))
+    else:
+        om = orc.OracleModel(lambda a, prm: np.hstack((np.ones((len(a), 1)), a, a ** 2, a ** 3))[:, :q], kern, None, th, "linear_predictor")
+        ref = float(orc.negative_log_restricted_likelihood(om, th, x, z))
+    v, info = c.reml(th)
+    assert info == 0 and abs(v - ref) < 1e-10 * max(1.0, abs(ref)), (v, ref)
+    v2, g, info = c.value_grad(th)
+    assert info == 0 and v2 == v
+    h = 1e-4
+    for j in range(len(th)):
+        e = np.zeros(len(th))
+        e[j] = h
+        fd = (-c.reml(th + 2 * e)[0] + 8 * c.reml(th + e)[0] - 8 * c.reml(th - e)[0] + c.reml(th - 2 * e)[0]) / (12 * h)
+        assert abs(fd - g[j]) < 1e-6 * max(1.0, np.linalg.norm(g)), (j, fd, g[j])
+    (zl, s2, el), info = c.loo(th)
+    ozl, os2, oel = orc.loo(om, x, z)
+    assert info == 0 and rel_err(zl, ozl) < 1e-8 and rel_err(s2, os2) < 1e-8 and rel_err(el, oel) < 1e-8
