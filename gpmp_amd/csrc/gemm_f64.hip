@@ -634,18 +634,23 @@ struct LeafSolveParams {
   int m;            // right-hand sides; the last strip may be narrower than 128
 };
 
+// BNW = columns of a strip: 128 (waves 2 x 2, 64 x 64 each) or 64 (waves 4 x 1, 32 x 64 each).  The narrow form halves the
+// work of a workgroup and doubles their number: a leaf has only m / BNW workgroups, and at m = 10000 (config 2) 79 of them
+// leave two thirds of the machine idle for the 0.17 ms the four sequential products take.
+template <int BNW>
 __global__ void __launch_bounds__(256, 2) trsm_leaf_kernel(LeafSolveParams p) {
+  constexpr int MI = BNW == 128 ? 4 : 2;      // 16-row MFMA tiles per wave
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = BNW == 128 ? (wave >> 1) * 64 : wave * 32, wn = BNW == 128 ? (wave & 1) * 64 : 0;
   const int lr = lane & 15, lk = lane >> 4;
-  double* __restrict__ strip = p.B + (long)blockIdx.x * BN;
+  double* __restrict__ strip = p.B + (long)blockIdx.x * BNW;
   const unsigned lane_off = (unsigned)((wm + lk) * (int)p.ldb + wn + lr);
   // a narrow last strip (m even): column pairs past m are redirected to the strip's first pair, so every load stays
   // inside B, and only columns < m are stored -- columns are independent
-  const int ncv = (p.m - (int)blockIdx.x * BN) < BN ? (p.m - (int)blockIdx.x * BN) : BN;
+  const int ncv = (p.m - (int)blockIdx.x * BNW) < BNW ? (p.m - (int)blockIdx.x * BNW) : BNW;
 
   int voffA[2], voffB[2];
 #pragma unroll
@@ -657,8 +662,8 @@ __global__ void __launch_bounds__(256, 2) trsm_leaf_kernel(LeafSolveParams p) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(strip, 0, 0x7FFFFFFF, 0x00020000);
 
-  double fa[4][4], fb[4][4];
-  d4 acc[4][4];
+  double fa[4][MI], fb[4][4];
+  d4 acc[MI][4];
   for (int jb = 0; jb < p.nb; ++jb) {
     const int nk = (jb + 1) * (BM / BK);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
@@ -680,19 +685,19 @@ __global__ void __launch_bounds__(256, 2) trsm_leaf_kernel(LeafSolveParams p) {
       const double* sa = smem + buf * 2 * V2_TILE;
       const double* sb = sa + V2_TILE;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[ks][i] = sa[v2_frag_addr<true>(wm + i * 16 + lr, ks * 4 + lk)];
+      for (int i = 0; i < MI; ++i) fa[ks][i] = sa[v2_frag_addr<true>(wm + i * 16 + lr, ks * 4 + lk)];
 #pragma unroll
       for (int j = 0; j < 4; ++j) fb[ks][j] = sb[v2_frag_addr<false>(wn + j * 16 + lr, ks * 4 + lk)];
     };
     auto mfma_step = [&](int ks) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
     };
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
@@ -723,9 +728,9 @@ __global__ void __launch_bounds__(256, 2) trsm_leaf_kernel(LeafSolveParams p) {
     }
     // every wave has consumed block j of the strip (the barrier of the last k-tile): overwrite it
     double* cb = strip + (long)jb * BM * p.ldb;
-    if (ncv == BN) {
+    if (ncv == BNW) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           double* rp = cb + (long)(i * 16 + 4 * r) * p.ldb;
@@ -734,7 +739,7 @@ __global__ void __launch_bounds__(256, 2) trsm_leaf_kernel(LeafSolveParams p) {
         }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           double* rp = cb + (long)(i * 16 + 4 * r) * p.ldb;
@@ -1067,13 +1072,20 @@ int launch_trsm_leaf_forward(const double* L, long ldl, const double* dinv_leaf,
   static bool attr_done = false;
   const size_t lds2 = sizeof(double) * 4 * V2_TILE;
   if (!attr_done) {
-    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_leaf_kernel),
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_leaf_kernel<128>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_leaf_kernel<64>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     attr_done = true;
   }
+  // 64-column strips while 128-column ones would leave most of the machine idle (GPMP_TRSM_LEAF_NARROW_BELOW strips)
+  static int narrow_below = -1;
+  if (narrow_below < 0) { const char* e = getenv("GPMP_TRSM_LEAF_NARROW_BELOW"); narrow_below = e ? atoi(e) : 192; }
+  const int strips128 = (ncols + BN - 1) / BN;
   LeafSolveParams p{G, ldg, B, ldb, nb, ncols};
   ProfScope ps(PK_GEMM_NN, st, (double)ncols * (double)(nb * BM) * (double)((nb + 1) * BM));   // counted with the small-K NN work it replaces
-  hipLaunchKernelGGL(trsm_leaf_kernel, dim3((ncols + BN - 1) / BN), dim3(256), lds2, st, p);
+  if (strips128 < narrow_below) hipLaunchKernelGGL(trsm_leaf_kernel<64>, dim3((ncols + 63) / 64), dim3(256), lds2, st, p);
+  else hipLaunchKernelGGL(trsm_leaf_kernel<128>, dim3(strips128), dim3(256), lds2, st, p);
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -344,7 +344,10 @@ int state_for(hipStream_t st, StreamState& out, int& ncu) {
     StreamState ns{nullptr, nullptr};
     // [state words | sticky abort counter]: the counter survives the per-launch memset of the state words
     GPMP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ns.words), sizeof(unsigned int) * (TRSV_STATE_WORDS + 4)));
-    GPMP_HIP_TRY(hipMemset(ns.words, 0, sizeof(unsigned int) * (TRSV_STATE_WORDS + 4)));
+    // zeroed ON THE OWNING STREAM: a hipMemset would run on the null stream, which a non-blocking stream (every PyTorch
+    // side stream is one) does not wait for -- under load it could land in the middle of the first solve and reset the
+    // ticket and the flags under the running kernel (seen as an occasional wrong or given-up first solve of a stream)
+    GPMP_HIP_TRY(hipMemsetAsync(ns.words, 0, sizeof(unsigned int) * (TRSV_STATE_WORDS + 4), st));
     ns.sticky = ns.words + TRSV_STATE_WORDS;
     it = g_states.emplace(std::make_pair(dev, st), ns).first;
   }
@@ -435,9 +438,13 @@ int solve_status(hipStream_t st, int* status_host) {
   auto it = g_states.find({dev, st});
   unsigned int v = 0;
   if (it != g_states.end()) {
+    // everything on `st` itself: the null stream is not ordered with a non-blocking stream
+    GPMP_HIP_TRY(hipMemcpyAsync(&v, it->second.sticky, sizeof(v), hipMemcpyDeviceToHost, st));
     GPMP_HIP_TRY(hipStreamSynchronize(st));
-    GPMP_HIP_TRY(hipMemcpy(&v, it->second.sticky, sizeof(v), hipMemcpyDeviceToHost));
-    if (v != 0) GPMP_HIP_TRY(hipMemset(it->second.sticky, 0, sizeof(v)));
+    if (v != 0) {
+      GPMP_HIP_TRY(hipMemsetAsync(it->second.sticky, 0, sizeof(v), st));
+      GPMP_HIP_TRY(hipStreamSynchronize(st));
+    }
   }
   if (status_host) *status_host = (int)v;
   return (int)v;
