@@ -378,6 +378,8 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     const int w = p1 - p0;
     // -- helper: update next panel's columns with P_k, then factor it
     if (e_u2) GPMP_HIP_TRY(hipStreamWaitEvent(s1, e_u2, 0));
+    const int lean_panel = (n - p2 >= lean_above || (sa != nullptr && sa->every_panel && along_lean)) ? 1 : 0;
+    hipEvent_t e_main_go = e_f;
     rc = launch_gemm(true, true, n - p1, p2 - p1, w, -1.0, A + (long)p1 * lda + p0, lda, A + (long)p1 * lda + p0, lda,
                      1.0, A + (long)p1 * lda + p1, lda, lower, s1);
     if (rc) return rc;
@@ -386,7 +388,6 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     // 37 us when both start together); the trailing update has slack there
     static int main_after_la_below = -1;
     if (main_after_la_below < 0) { const char* e = getenv("GPMP_POTRF_MAIN_AFTER_LA_BELOW"); main_after_la_below = e ? atoi(e) : 4096; }
-    hipEvent_t e_main_go = e_f;
     if (n - p1 <= main_after_la_below) {
       e_main_go = g_la.next();
       GPMP_HIP_TRY(hipEventRecord(e_main_go, s1));
@@ -394,7 +395,7 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     // (the main stream's update of this iteration covers (n - p2)^2 / 2: with at least two rounds of tiles it holds every
     //  workgroup slot of the machine while this panel is factored)
     // (with the panel-by-panel solve the solve stream's GEMMs hold the slots instead)
-    rc = factor_panel(A, n, lda, dinv, info_dev, p1, p2, s1, (n - p2 >= lean_above || (sa != nullptr && sa->every_panel && along_lean)) ? 1 : 0);
+    rc = factor_panel(A, n, lda, dinv, info_dev, p1, p2, s1, lean_panel);
     if (rc) return rc;
     hipEvent_t e_f_next = g_la.next();
     GPMP_HIP_TRY(hipEventRecord(e_f_next, s1));

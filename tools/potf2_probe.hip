@@ -18,10 +18,12 @@ int main() {
     (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1); printf("rep %d: %.1f us\n", rep, ms * 1e3);
   }
-  long long tr[64];
+  long long tr[192];
   (void)hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_potf2_trace), sizeof(tr));
   auto us = [&](int s) { return (tr[s] - tr[0]) * 0.01; };
-  printf("load done %.1f | factor done %.1f | L stored %.1f | B done %.1f | C done %.1f | end %.1f\n", us(1), us(2), us(3), us(4), us(5), us(6));
-  for (int j = 0; j < 8; ++j) printf("  j=%d: A1 done %.1f  A2 done %.1f  A3 done %.1f\n", j, us(8 + 3 * j), us(9 + 3 * j), us(10 + 3 * j));
+  printf("load done %.1f | chain done %.1f | end (wave 0) %.1f\n", us(1), us(2), us(6));
+  for (int j = 0; j < 8; ++j) printf("  j=%d: A1 done %.1f  A2 done %.1f  A3(first block) done %.1f\n", j, us(8 + 3 * j), j < 7 ? us(9 + 3 * j) : 0.0, j < 7 ? us(10 + 3 * j) : 0.0);
+  printf("shadow: zero fill done (wave 7) %.1f\n", us(64));
+  for (int j = 1; j < 8; ++j) printf("  j=%d: wave 7: a3 %.1f invert %.1f crow %.1f | wave 4: a3 %.1f stores %.1f crow %.1f\n", j, us(64 + 4 * j), us(65 + 4 * j), us(66 + 4 * j), us(96 + 4 * j), us(97 + 4 * j), us(98 + 4 * j));
   return 0;
 }
