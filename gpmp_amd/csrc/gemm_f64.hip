@@ -47,6 +47,7 @@ struct GemmParams {
   int batch;    // gridDim.y independent products
   int batch2;   // gridDim.z independent problems (outer batch)
   int pair16;   // v2 epilogue: 16-byte stores after a lane-pair exchange
+  int prio;     // small NT kernels: raise the wave priority (GPMP_CHAIN_PRIO)
   long sa, sb, sc;   // element strides of A, B, C per batch index
   long sa2, sb2, sc2;   // ... per outer batch index (blockIdx.z)
 };
@@ -821,6 +822,9 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) double sB[2][SBN * SLD];
   const int row0 = blockIdx.y * SBM, col0 = blockIdx.x * SBN;
   if (p.lower_only && col0 > row0 + SBM - 1) return;
+  // these kernels carry the panel chain of the Cholesky: their waves go first where they share a SIMD with the trailing
+  // update's (whose 64-cycle MFMAs otherwise take turns with them one for one)
+  if (p.prio) __builtin_amdgcn_s_setprio(3);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wn = wave * 32;
@@ -928,6 +932,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(10, 10
   __shared__ __attribute__((aligned(16))) double sB[SBN * BK];
   const int row0 = blockIdx.y * SBM, col0 = blockIdx.x * SBN;
   if (p.lower_only && col0 > row0 + SBM - 1) return;
+  // these kernels carry the panel chain of the Cholesky: their waves go first where they share a SIMD with the trailing
+  // update's (whose 64-cycle MFMAs otherwise take turns with them one for one)
+  if (p.prio) __builtin_amdgcn_s_setprio(3);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wn = wave * 32;
@@ -1116,6 +1123,9 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   if (pair16 < 0) { const char* e = getenv("GPMP_GEMM_PAIR16"); pair16 = e ? atoi(e) : 1; }
   p.pair16 = pair16;
   p.lean = o.lean | g_machine_busy;
+  static int chain_prio = -1;
+  if (chain_prio < 0) { const char* e = getenv("GPMP_CHAIN_PRIO"); chain_prio = e ? atoi(e) : 1; }
+  p.prio = chain_prio;
   p.batch = o.batch > 1 ? o.batch : 1;
   p.sa = o.stride_a; p.sb = o.stride_b; p.sc = o.stride_c;
   p.batch2 = o.batch2 > 1 ? o.batch2 : 1;

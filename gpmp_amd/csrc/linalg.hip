@@ -200,6 +200,7 @@ int trsm_right(const double* L, int k, long ldl, const double* dinv, double* B, 
 // rest of the trailing matrix, so the MFMA pipe never waits for a panel except at the very end.
 struct LookAhead {
   hipStream_t helper = nullptr;
+  hipStream_t side = nullptr;      // later pieces of a split look-ahead update (see potrf_lookahead)
   std::vector<hipEvent_t> pool;
   size_t used = 0;
   hipEvent_t next() {
@@ -221,7 +222,19 @@ int g_la_device = -1;
 
 // Factor the panel of columns [p0, p1) (p0, p1 multiples of NB; rows p0 .. n): diagonal blocks in LDS,
 // panel scaling, rank-128 updates inside 512-column sub-panels and rank-512 updates between them.
-int factor_panel(double* A, int n, long lda, double* dinv, int* info_dev, int p0, int p1, hipStream_t st, int lean = 0) {
+// `ready` (optional): columns >= ready[i].col of the panel may only be touched after ready[i].ev (pieces of a split
+// look-ahead update that are still running on another stream), in increasing order of col.
+struct ColsReady { int col; hipEvent_t ev; };
+int factor_panel(double* A, int n, long lda, double* dinv, int* info_dev, int p0, int p1, hipStream_t st, int lean = 0,
+                 const ColsReady* ready = nullptr, int nready = 0) {
+  int iready = 0;
+  auto need_cols = [&](int hi) -> int {       // the next kernel touches columns < hi
+    while (iready < nready && ready[iready].col < hi) {
+      GPMP_HIP_TRY(hipStreamWaitEvent(st, ready[iready].ev, 0));
+      ++iready;
+    }
+    return 0;
+  };
   // lean: a machine-filling trailing update is running on the other stream -- the K = 128 products take the
   // small-footprint kernel that starts beside its resident workgroups instead of queueing for a slot
   GemmOpts lower, plain;
@@ -243,6 +256,8 @@ int factor_panel(double* A, int n, long lda, double* dinv, int* info_dev, int p0
       if (rc) return rc;
       const int ncols_in = imin(s1, n) - r1;
       if (ncols_in > 0) {
+        rc = need_cols(r1 + ncols_in);
+        if (rc) return rc;
         rc = launch_gemm(true, true, mrem, ncols_in, jb, -1.0, A21, lda, A21, lda, 1.0, A + (long)r1 * lda + r1, lda,
                          lower, st);
         if (rc) return rc;
@@ -250,13 +265,14 @@ int factor_panel(double* A, int n, long lda, double* dinv, int* info_dev, int p0
     }
     const int rest_cols = imin(p1, n) - s1;   // remaining columns of this (wide) panel
     if (rest_cols > 0) {
+      { int rcw = need_cols(s1 + rest_cols); if (rcw) return rcw; }
       // A[s1:, s1:p1] -= A[s1:, s0:s1] A[s1:p1, s0:s1]^T
       int rc = launch_gemm(true, true, n - s1, rest_cols, s1 - s0, -1.0, A + (long)s1 * lda + s0, lda,
                            A + (long)s1 * lda + s0, lda, 1.0, A + (long)s1 * lda + s1, lda, lower, st);
       if (rc) return rc;
     }
   }
-  return 0;
+  return need_cols(p1 + 1);                    // (every piece is waited for: the panel event stands for the whole panel)
 }
 
 int trsm_forward(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int tri,
@@ -316,6 +332,7 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     int lo = 0, hi = 0;
     GPMP_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
     GPMP_HIP_TRY(hipStreamCreateWithPriority(&g_la.helper, hipStreamNonBlocking, hi));
+    GPMP_HIP_TRY(hipStreamCreateWithPriority(&g_la.side, hipStreamNonBlocking, hi));
   }
   hipStream_t s1 = g_la.helper;
   g_la.used = 0;
@@ -376,13 +393,45 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   for (int k = 0; k + 1 < np; ++k) {
     const int p0 = pb[k], p1 = pb[k + 1], p2 = pb[k + 2];   // panel k = [p0, p1), next panel = [p1, p2)
     const int w = p1 - p0;
+    hipStream_t sside = g_la.side;
     // -- helper: update next panel's columns with P_k, then factor it
     if (e_u2) GPMP_HIP_TRY(hipStreamWaitEvent(s1, e_u2, 0));
     const int lean_panel = (n - p2 >= lean_above || (sa != nullptr && sa->every_panel && along_lean)) ? 1 : 0;
     hipEvent_t e_main_go = e_f;
-    rc = launch_gemm(true, true, n - p1, p2 - p1, w, -1.0, A + (long)p1 * lda + p0, lda, A + (long)p1 * lda + p0, lda,
-                     1.0, A + (long)p1 * lda + p1, lda, lower, s1);
-    if (rc) return rc;
+    // Wide panels: the look-ahead update is cut in three column pieces.  The chain stream does the first 128 columns and
+    // starts the diagonal block at once; the other two ([128, 512) and [512, 1024), the second sub-panel) follow on a side
+    // stream while the first diagonal blocks are factored, and factor_panel waits for each just before it touches those
+    // columns.  (At n = 16384 the panel, not the trailing update, is the longer of the two in EVERY step -- kernel trace: a
+    // 1024-column panel = 0.8-1.0 ms of look-ahead update + 8 x 0.3 ms -- so the 0.8 ms in front of the first potf2 were
+    // on the critical path.)
+    static int la_split = -1;
+    if (la_split < 0) { const char* e = getenv("GPMP_POTRF_LA_SPLIT"); la_split = e ? atoi(e) : 1; }
+    static int la_split_above = -1;       // (below, the pieces are too small to be worth two more events: n = 8192 loses 2 %)
+    if (la_split_above < 0) { const char* e = getenv("GPMP_POTRF_LA_SPLIT_ABOVE"); la_split_above = e ? atoi(e) : 8192; }
+    ColsReady ready[2];
+    int nready = 0;
+    if (la_split && p2 - p1 == 2 * OUTER_BLOCKS * NB && p2 <= n && n - p1 > la_split_above) {
+      const int cuts[4] = {p1, p1 + NB, p1 + OUTER_BLOCKS * NB, p2};
+      GPMP_HIP_TRY(hipStreamWaitEvent(sside, e_f, 0));
+      if (e_u2) GPMP_HIP_TRY(hipStreamWaitEvent(sside, e_u2, 0));
+      for (int q = 0; q < 3; ++q) {
+        const int ca = cuts[q], cb = cuts[q + 1];
+        hipStream_t sq = q == 0 ? s1 : sside;
+        rc = launch_gemm(true, true, n - ca, cb - ca, w, -1.0, A + (long)ca * lda + p0, lda, A + (long)ca * lda + p0, lda,
+                         1.0, A + (long)ca * lda + ca, lda, lower, sq);
+        if (rc) return rc;
+        if (q > 0) {
+          ready[nready].col = ca;
+          ready[nready].ev = g_la.next();
+          GPMP_HIP_TRY(hipEventRecord(ready[nready].ev, sside));
+          ++nready;
+        }
+      }
+    } else {
+      rc = launch_gemm(true, true, n - p1, p2 - p1, w, -1.0, A + (long)p1 * lda + p0, lda, A + (long)p1 * lda + p0, lda,
+                       1.0, A + (long)p1 * lda + p1, lda, lower, s1);
+      if (rc) return rc;
+    }
     // chain-bound tail: the trailing update of this step starts only when the look-ahead update above has finished, so
     // that the latter -- on the critical chain -- does not share the machine with it (kernel trace, n = 4096: 12 us alone,
     // 37 us when both start together); the trailing update has slack there
@@ -395,10 +444,18 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     // (the main stream's update of this iteration covers (n - p2)^2 / 2: with at least two rounds of tiles it holds every
     //  workgroup slot of the machine while this panel is factored)
     // (with the panel-by-panel solve the solve stream's GEMMs hold the slots instead)
-    rc = factor_panel(A, n, lda, dinv, info_dev, p1, p2, s1, lean_panel);
+    rc = factor_panel(A, n, lda, dinv, info_dev, p1, p2, s1, lean_panel, ready, nready);
     if (rc) return rc;
-    hipEvent_t e_f_next = g_la.next();
-    GPMP_HIP_TRY(hipEventRecord(e_f_next, s1));
+    // "panel k+1 factored": only recorded where somebody waits for it -- the trailing update of the next step (unless that
+    // one starts behind its look-ahead update anyway), the solve stream, the final join.  An event between two kernels of
+    // the chain stream costs ~5 us of packet processing (kernel trace: 9-11 us gaps around the look-ahead update against
+    // 0-1 us between kernels that follow each other directly).
+    const bool need_ef = sa != nullptr || k + 2 >= np || (n - p2 > main_after_la_below);
+    hipEvent_t e_f_next = e_f;
+    if (need_ef) {
+      e_f_next = g_la.next();
+      GPMP_HIP_TRY(hipEventRecord(e_f_next, s1));
+    }
     if (sa != nullptr && sa->every_panel) {
       // rows [r0, p2) of B: their update with the rows solved before was issued early (above); the diagonal part goes
       // behind the factorisation of the last of these panels, followed at once by the next piece's update

@@ -31,6 +31,13 @@
 //     L(j-1)   block column j-1 of the factor and T_(j-2)(j-2) -> global (waves 3..6)
 //   tail  B(7), C(6) and the sums of C(7) together, then the last multiplication by -T_77: ~3 us after the chain
 //         ends (round 1 ran B, C and the stores after the factorisation: 13 of the kernel's 46 us).
+// Beside a machine-filling trailing update the kernel takes 180-260 us instead of 31 (tools/potf2_probe.hip busy,
+// profiles/r2/potf2_phase_timeline_beside_gemm.log: every phase ~7 times longer, the register-only A1 included).  On gfx950
+// the f64 MFMA and the f64 vector ALU have the same peak rate -- they share the FP64 units -- so each dependent v_fma_f64 of the
+// chain waits for a gap between the co-resident GEMM wave's back-to-back 64-cycle MFMAs.  Three ways around it were built and
+// measured in round 2, none kept: CU-masked streams, a resident workgroup serving the blocks from a mailbox (the
+// blocks then take 45 us, but a workgroup that holds a compute unit for the whole factorisation slows the trailing update by 11 %),
+// and a CU partition.
 // Barriers inside the loop wait for LDS traffic only (lds_barrier): the stores to global memory ride along.
 // Phase timeline: tools/potf2_probe.hip (profiles/r2/potf2_phase_timeline_v2.log): load 4, eight steps of ~3.1 us
 // (A1 1.8, A2 1.0, A3 0.3), tail 2.8: 31 us of kernel against 40 (start of round 2) and 46 (round 1).
@@ -125,25 +132,18 @@ __device__ __forceinline__ void invert_diag_block(const double* S, double* Td, c
   }
 }
 
-// (at most 128 registers: two waves per SIMD of this kernel must fit beside ONE resident wave of the 232-register GEMM)
-__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) potf2_inv_kernel(double* __restrict__ A, long lda, int n_total,
-                                                            double* __restrict__ dinv, int* info, int offset,
-                                                            long prob_stride_a, long prob_stride_dinv) {
-  // batched over blockIdx.y: independent matrices (problems) prob_stride_a / prob_stride_dinv elements apart, one info word each
-  A += (long)blockIdx.y * prob_stride_a;
-  dinv += (long)blockIdx.y * prob_stride_dinv;
-  info += blockIdx.y;
-  const int jb = n_total < NB ? n_total : NB;
-
-  extern __shared__ __attribute__((aligned(16))) double S[];   // [NPACK][16][16] packed lower block triangle
+// The factorisation of one block by the 512 threads of a workgroup; S = 91,136 bytes of LDS.  Every wave's stores to A
+// and dinv have been ISSUED when it returns (a kernel end, or the caller's vmcnt(0) + fence, completes them).
+__device__ __forceinline__ void potf2_body(double* __restrict__ A, long lda, int jb, double* __restrict__ dinv, int* info, int offset,
+                                           double* S, const int t) {
   double* Td = S + NPACK * 256;                                // [NSB][16][16] diagonal inverse blocks
   double* dg = Td + NSB * 256;                                 // [NB] 1 / L_ii
-  const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lr = lane & 15, lk = lane >> 4;
 
   PF_MARK(0);
+  if (wave == 0) __builtin_amdgcn_s_setprio(3);     // the chain wave above the shadow waves (its SIMD is shared with wave 4)
   load_block(A, lda, jb, S, t);
 
   __syncthreads();
@@ -263,7 +263,6 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4,
 
   if (wave == 0) {
     // ================= chain wave =================
-    __builtin_amdgcn_s_setprio(3);           // its SIMD is shared with wave 4
 #pragma nounroll
     for (int j = 0; j < NSB; ++j) {
       const int j0 = j * SB;
@@ -458,6 +457,16 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4,
     if (wave >= 3 && wave <= 6) store_t_diag(7);
   }
   PF_MARK(6);
+}
+
+// (at most 128 registers: two waves per SIMD of this kernel must fit beside ONE resident wave of the 232-register GEMM)
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) potf2_inv_kernel(double* __restrict__ A, long lda, int n_total,
+                                                            double* __restrict__ dinv, int* info, int offset,
+                                                            long prob_stride_a, long prob_stride_dinv) {
+  // batched over blockIdx.y: independent matrices (problems) prob_stride_a / prob_stride_dinv elements apart, one info word each
+  extern __shared__ __attribute__((aligned(16))) double S[];   // [NPACK][16][16] packed lower block triangle + Td + dg
+  potf2_body(A + (long)blockIdx.y * prob_stride_a, lda, n_total < NB ? n_total : NB, dinv + (long)blockIdx.y * prob_stride_dinv,
+             info + blockIdx.y, offset, S, (int)threadIdx.x);
 }
 
 // inv(L_dd) of the diagonal blocks of an already factored matrix (one workgroup per block; phases B and C after one another)

@@ -35,6 +35,7 @@ static void run(const char* name, int ta, int tb, int M, int N, int K, int lower
 int main(int argc, char** argv) {
   int reps = argc > 1 ? atoi(argv[1]) : 5;
   int which = argc > 2 ? atoi(argv[2]) : -1;
+  if (getenv("BUSY")) gpmp_hint_machine_busy(atoi(getenv("BUSY")));
   if (which < 0 || which == 0) run("syrk trailing (potrf)", 0, 1, 32256, 32256, 512, 1, 1.0, reps);
   if (which < 0 || which == 1) run("syrk trailing mid", 0, 1, 16384, 16384, 512, 1, 1.0, reps);
   if (which < 0 || which == 2) run("trsm update (predict)", 0, 0, 16384, 49920, 512, 0, 1.0, reps);
@@ -45,6 +46,7 @@ int main(int argc, char** argv) {
   if (which < 0 || which == 7) run("small NT L2-resident K=4096", 0, 1, 2048, 2048, 4096, 0, 0.0, reps);
   if (which < 0 || which == 8) run("panel scale N=128 K=128", 0, 1, 32640, 128, 128, 0, 0.0, reps);
   if (which == 30) { for (int M : {128, 1024, 4096, 32640}) { run("panel scale NT N=128 K=128 b0", 0, 1, M, 128, 128, 0, 0.0, reps); run("rank-128 update NT N=384 b1", 0, 1, M, 384, 128, 0, 1.0, reps); run("NN K=128 N=4096 b1", 0, 0, M, 4096, 128, 0, 1.0, reps); } }
+  if (which == 40) { for (int M : {3584, 3072, 2560, 2048, 1792, 1536, 1024, 512}) run("syrk trailing, chain-bound tail K=256", 0, 1, M, M, 256, 1, 1.0, reps); }
   if (which == 20) { for (int K : {128, 256, 512, 1024, 2048, 4096}) { run("NN beta=1 K sweep", 0, 0, 16384, 16384, K, 0, 1.0, reps); run("NN beta=0 K sweep", 0, 0, 16384, 16384, K, 0, 0.0, reps); } }
   return 0;
 }
