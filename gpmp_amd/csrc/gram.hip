@@ -120,14 +120,20 @@ __global__ void __launch_bounds__(256) gram_kernel_v3(GramParams p) {
   const int tj = blockIdx.x, ti = blockIdx.y;
   const int row0 = ti * 128, col0 = tj * GT;
   if (p.lower_only && col0 > row0 + 127) return;
+  // (the parameter block is NEVER written: one store into the by-value struct and the compiler keeps a private copy of all of
+  //  it -- scale[], q[], the exp constants -- in scratch memory instead of scalar registers: 896 bytes per lane, kernel 4.5 x
+  //  slower, found by the round-2 rocprof pass)
+  const double* __restrict__ px = p.x;
+  double* __restrict__ pK = p.K;
+  int pn = p.n, pm = p.m;
   if (p.nprob > 1) {
-    p.x += (long)blockIdx.z * p.stride_x;
-    p.K += (long)blockIdx.z * p.stride_k;
-    if (p.ns != nullptr) p.n = p.m = p.ns[blockIdx.z];
-    if (row0 >= p.n || col0 >= p.m) return;
+    px += (long)blockIdx.z * p.stride_x;
+    pK += (long)blockIdx.z * p.stride_k;
+    if (p.ns != nullptr) pn = pm = p.ns[blockIdx.z];
+    if (row0 >= pn || col0 >= pm) return;
   }
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
-  const double* __restrict__ yp = p.same ? p.x : p.y;
+  const double* __restrict__ yp = p.same ? px : p.y;
 
   double acc[8][4];
 #pragma unroll
@@ -142,11 +148,11 @@ __global__ void __launch_bounds__(256) gram_kernel_v3(GramParams p) {
     // (global reads contiguous along k), LDS stores scatter over rows
     for (int idx = t; idx < 128 * kc; idx += 256) {
       const int r = idx / kc, k = idx - r * kc;
-      xs[k][r] = (row0 + r < p.n) ? p.scale[k0 + k] * p.x[(long)(row0 + r) * p.d + k0 + k] : 0.0;
+      xs[k][r] = (row0 + r < pn) ? p.scale[k0 + k] * px[(long)(row0 + r) * p.d + k0 + k] : 0.0;
     }
     for (int idx = t; idx < GT * kc; idx += 256) {
       const int r = idx / kc, k = idx - r * kc;
-      ys[k][r] = (col0 + r < p.m) ? p.scale[k0 + k] * yp[(long)(col0 + r) * p.d + k0 + k] : 0.0;
+      ys[k][r] = (col0 + r < pm) ? p.scale[k0 + k] * yp[(long)(col0 + r) * p.d + k0 + k] : 0.0;
     }
     __syncthreads();
     for (int k = 0; k < kc; ++k) {
@@ -168,10 +174,10 @@ __global__ void __launch_bounds__(256) gram_kernel_v3(GramParams p) {
     }
   }
 
-  const bool full = p.aligned && (row0 + 128 <= p.n) && (col0 + GT <= p.m);
+  const bool full = p.aligned && (row0 + 128 <= pn) && (col0 + GT <= pm);
   // tiles crossed by the diagonal (ii path): only they test row == col
   const bool diag_tile = p.same && (col0 < row0 + 128) && (col0 + GT > row0);
-  double* __restrict__ out = p.K + (long)(row0 + ty * 8) * p.ldk + col0 + 2 * tx;
+  double* __restrict__ out = pK + (long)(row0 + ty * 8) * p.ldk + col0 + 2 * tx;
   // leading coefficients of the two Horner chains live in VGPRs (their first fma would otherwise need two SGPR operands
   // and the compiler copies one of them next to every use)
   const int pdeg = (P >= 0) ? P : p.p;
@@ -238,11 +244,11 @@ __global__ void __launch_bounds__(256) gram_kernel_v3(GramParams p) {
     if (full) {
       *reinterpret_cast<d2*>(out) = (d2){v[0], v[1]};
       *reinterpret_cast<d2*>(out + 32) = (d2){v[2], v[3]};
-    } else if (row < p.n) {
+    } else if (row < pn) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int cc = (b >> 1) * 32 + 2 * tx + (b & 1);
-        if (col0 + cc < p.m) out[cc - 2 * tx] = v[b];
+        if (col0 + cc < pm) out[cc - 2 * tx] = v[b];
       }
     }
   }
@@ -366,21 +372,28 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
 #pragma unroll
   for (int k = 0; k < DT; ++k) gacc[k] = 0.0;
   double g0 = 0.0, gtr = 0.0;
+  // (locals, never a store into the parameter block: see gram_kernel_v3)
+  const double* __restrict__ pKinv = p.Kinv;
+  const double* __restrict__ px = p.x;
+  const double* __restrict__ pF = p.F;
+  const double* __restrict__ pG = p.G;
+  double* __restrict__ ppartial = p.partial;
+  int pn = p.n, pntiles_side = p.ntiles_side, pntiles = p.ntiles;
   if (p.nprob > 1) {
     const int z = blockIdx.y;
-    p.Kinv += (long)z * p.stride_kinv;
-    p.x += (long)z * p.stride_x;
-    p.F += (long)z * p.stride_f;
-    p.G += (long)z * p.stride_f;
-    p.partial += (long)z * p.stride_partial;
+    pKinv += (long)z * p.stride_kinv;
+    px += (long)z * p.stride_x;
+    pF += (long)z * p.stride_f;
+    pG += (long)z * p.stride_f;
+    ppartial += (long)z * p.stride_partial;
     if (p.ns != nullptr) {
-      p.n = p.ns[z];
-      p.ntiles_side = (p.n + GT - 1) / GT;
-      p.ntiles = p.ntiles_side * (p.ntiles_side + 1) / 2;
+      pn = p.ns[z];
+      pntiles_side = (pn + GT - 1) / GT;
+      pntiles = pntiles_side * (pntiles_side + 1) / 2;
     }
   }
 
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  for (int tile = blockIdx.x; tile < pntiles; tile += gridDim.x) {
     int ti = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
     while (ti * (ti + 1) / 2 > tile) --ti;
@@ -392,16 +405,16 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
       double vx = 0.0, vy = 0.0;
       if (k < p.d) {
         const double ir = p.invrho[k];
-        if (row0 + r < p.n) vx = ir * p.x[(long)(row0 + r) * p.d + k];
-        if (col0 + r < p.n) vy = ir * p.x[(long)(col0 + r) * p.d + k];
+        if (row0 + r < pn) vx = ir * px[(long)(row0 + r) * p.d + k];
+        if (col0 + r < pn) vy = ir * px[(long)(col0 + r) * p.d + k];
       }
       xs[k * GT + r] = vx;
       ys[k * GT + r] = vy;
     }
     for (int idx = t; idx < p.r * GT; idx += 256) {
       const int r = idx / p.r, a = idx % p.r;
-      fs[a * GT + r] = (row0 + r < p.n) ? p.F[(long)(row0 + r) * p.ldf + a] : 0.0;
-      gs[a * GT + r] = (col0 + r < p.n) ? p.G[(long)(col0 + r) * p.ldf + a] : 0.0;
+      fs[a * GT + r] = (row0 + r < pn) ? pF[(long)(row0 + r) * p.ldf + a] : 0.0;
+      gs[a * GT + r] = (col0 + r < pn) ? pG[(long)(col0 + r) * p.ldf + a] : 0.0;
     }
     __syncthreads();
 
@@ -440,9 +453,9 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
       for (int b = 0; b < 4; ++b) {
         const int col = col0 + tx * 4 + b;
         double wt = 0.0;
-        if (row < p.n && col < p.n) wt = col < row ? 2.0 : (col == row ? 1.0 : 0.0);
+        if (row < pn && col < pn) wt = col < row ? 2.0 : (col == row ? 1.0 : 0.0);
         double mval = 0.0;
-        if (wt != 0.0) mval = wt * (p.Kinv[(long)row * p.ldk + col] - w[a][b]);
+        if (wt != 0.0) mval = wt * (pKinv[(long)row * p.ldk + col] - w[a][b]);
         // K(h) = e^{-t/2} sum q_k t^k and (K'(h)/h) / (2c)^2 = e^{-t/2} sum_{k>=1} s_k t^{k-1} (p >= 1), t = 2 c h
         const double tt = fast_sqrt_pos(h2[a][b], p.fe.tiny);
         const double e = fast_exp_neg_half(p.fe, tt);
@@ -499,7 +512,7 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
   }
   __syncthreads();
   if (t < DT + 2) {
-    p.partial[(long)blockIdx.x * (DT + 2) + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    ppartial[(long)blockIdx.x * (DT + 2) + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
   }
 }
 
