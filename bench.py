@@ -360,12 +360,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # GPMP_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one
+    # GPU): the ranks share the GPUs there are.  The measured run is one rank per GPU over nccl (= RCCL).
+    backend = os.environ.get("GPMP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
+        os.environ["LOCAL_RANK"] = str(local_rank)       # (gpmp_amd.num picks its device from it)
     torch.cuda.set_device(local_rank)
     dist_on = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # launched by torch.distributed.run
     if dist_on:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     import gpmp_amd as gp
