@@ -1086,8 +1086,8 @@ int launch_trsm_leaf_forward(const double* L, long ldl, const double* dinv_leaf,
     attr_done = true;
   }
   // 64-column strips while 128-column ones would leave most of the machine idle (GPMP_TRSM_LEAF_NARROW_BELOW strips)
-  static int narrow_below = -1;
-  if (narrow_below < 0) { const char* e = getenv("GPMP_TRSM_LEAF_NARROW_BELOW"); narrow_below = e ? atoi(e) : 192; }
+  const char* nbe = getenv("GPMP_TRSM_LEAF_NARROW_BELOW");     // read at every call (tests exercise both strip widths)
+  const int narrow_below = nbe ? atoi(nbe) : 192;
   const int strips128 = (ncols + BN - 1) / BN;
   LeafSolveParams p{G, ldg, B, ldb, nb, ncols};
   ProfScope ps(PK_GEMM_NN, st, (double)ncols * (double)(nb * BM) * (double)((nb + 1) * BM));   // counted with the small-K NN work it replaces

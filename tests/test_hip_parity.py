@@ -414,12 +414,16 @@ def test_single_vector_solves_eight_streams_in_flight(gnp):
         assert torch.equal(got, refs[s % 4][1 if s >= 4 else 0]), s
 
 
+@pytest.mark.parametrize("strip", [64, 128])
 @pytest.mark.parametrize("n,m", [(1536, 700), (2048, 1024), (1280, 514), (1500, 900)])
-def test_forward_solve_many_rhs_fused_leaves(gnp, n, m):
-    """L^-1 B with the factor's scratch area (n > 1024): fused 512-row leaves incl. a narrow last column strip;
-    n = 1500 has a ragged last leaf (launch-per-block path) behind fused ones"""
+def test_forward_solve_many_rhs_fused_leaves(gnp, n, m, strip, monkeypatch):
+    """L^-1 B with the factor's scratch area (n > 1024): fused 512-row leaves incl. a narrow last column strip, on 64-column
+    strips (the default below 192 strips of 128) and on 128-column strips; n = 1500 has a ragged last leaf (launch-per-block
+    path) behind fused ones"""
     import scipy.linalg as sla
     from oracle import gp_oracle as orc
+
+    monkeypatch.setenv("GPMP_TRSM_LEAF_NARROW_BELOW", "1000000" if strip == 64 else "0")
 
     rng = np.random.default_rng(n + m)
     x = rng.random((n, 3))
