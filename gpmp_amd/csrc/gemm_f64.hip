@@ -581,13 +581,14 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
     // every k-tile: has a diagonal-block kernel announced itself on this compute unit?  (common.h; the load is issued before the
     // k-tile's operand loads and consumed behind its barrier, which waits for vmcnt(0) anyway)
     const unsigned int* yslot = p.yield_tab != nullptr ? p.yield_tab + cu_table_index() : nullptr;
+    int budget = 96;      // sleeps of ~3 us this workgroup may take in its whole life: a stale stamp (a kernel that died before
+                          // clearing it, seen "in the future" again when the 32-bit clock wraps) costs at most ~0.3 ms per workgroup
     for (; kt < nk; ++kt) {
       unsigned int stamp = 0u;
       if (yslot != nullptr) stamp = __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ktile(kt, kt + 1 < nk, [&] {
         unsigned int s = __builtin_amdgcn_readfirstlane(stamp);
         if (s != 0u) {
-          int budget = 64;                                     // x ~3 us: never longer than ~200 us
           while (s != 0u && (int)(s - (unsigned int)wall_clock64()) > 0 && --budget > 0) {
             __builtin_amdgcn_s_sleep(127);
             __builtin_amdgcn_s_sleep(127);
