@@ -20,22 +20,20 @@
 
 namespace gpmp {
 
-int g_machine_busy = 0;
+int g_machine_busy = 0;   // gpmp_hint_machine_busy: small NT products take the small-footprint kernel
 // compute-unit yield table (common.h): one device per process (as the helper streams of linalg.hip)
 unsigned int* cu_yield_table() {
-  static unsigned int* tab = nullptr;
-  static int state = 0;     // 0: not tried, 1: ready, -1: off / failed
-  if (state == 0) {
+  // (function-local static: initialised once, thread-safe; the one host synchronisation the library ever does)
+  static unsigned int* const tab = []() -> unsigned int* {
     const char* e = getenv("GPMP_CU_YIELD");
-    state = -1;
-    if (e == nullptr || atoi(e) != 0) {
-      if (hipMalloc(reinterpret_cast<void**>(&tab), sizeof(unsigned int) * CU_TABLE_ENTRIES) == hipSuccess &&
-          hipMemset(tab, 0, sizeof(unsigned int) * CU_TABLE_ENTRIES) == hipSuccess && hipDeviceSynchronize() == hipSuccess)
-        state = 1;
-    }
-  }
-  return state == 1 ? tab : nullptr;
-}   // gpmp_hint_machine_busy: small NT products take the small-footprint kernel
+    if (e != nullptr && atoi(e) == 0) return nullptr;
+    unsigned int* t = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&t), sizeof(unsigned int) * CU_TABLE_ENTRIES) != hipSuccess) return nullptr;
+    if (hipMemset(t, 0, sizeof(unsigned int) * CU_TABLE_ENTRIES) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+    return t;
+  }();
+  return tab;
+}
 
 namespace {
 
