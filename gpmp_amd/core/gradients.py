@@ -183,3 +183,15 @@ def _reml_batch(self, covparam, batches, want_grad=True):
 
 MLZeroMeanAnalytic.batch_values_and_gradients = _ml_batch
 REMLAnalytic.batch_values_and_gradients = _reml_batch
+
+
+def _many(self, P, xi, zi, want_grad=False):
+    """the criterion at every row of ``P`` on the same data: one batched call with per-problem parameters (the data are
+    replicated per row: at most 1024 x d doubles each).  None when the batched driver does not apply."""
+    P = numpy.atleast_2d(numpy.asarray(P, dtype=numpy.float64))
+    xi, zi = gnp.asarray(xi), gnp.asarray(zi)
+    return self.batch_values_and_gradients(P, [(xi, zi)] * P.shape[0], want_grad)
+
+
+MLZeroMeanAnalytic.many_values_and_gradients = _many
+REMLAnalytic.many_values_and_gradients = _many

@@ -218,6 +218,24 @@ class _RemapAnalytic:
         values, grads = out
         return values + prior, (grads + self.gnlp(np.asarray(covparam, dtype=np.float64)) if want_grad else None)
 
+    def many_values_and_gradients(self, P, xi, zi, want_grad=False):
+        """REMAP at every row of ``P`` on the same data (sampler pattern): the REMLs in one batched call, each row's prior
+        (O(d), host) added; a row outside the prior's support gets +inf and a zero gradient"""
+        P = np.atleast_2d(np.asarray(P, dtype=np.float64))
+        priors = np.array([float(self.nlp(p)) for p in P])
+        ok = np.isfinite(priors)
+        values = np.full(P.shape[0], np.inf)
+        grads = np.zeros_like(P) if want_grad else None
+        if ok.any():
+            out = self.reml.many_values_and_gradients(P[ok], xi, zi, want_grad)
+            if out is None:
+                return None
+            v, g = out
+            values[ok] = v + priors[ok]
+            if want_grad:
+                grads[ok] = g + np.array([self.gnlp(p) for p in P[ok]])
+        return values, grads
+
 
 def select_parameters_with_remap_gaussian_logsigma2_and_logrho_prior(
         model, xi=None, zi=None, dataloader=None, covparam0=None, info=False, verbosity=0, *, covparam0_prior=None,

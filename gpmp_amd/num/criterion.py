@@ -60,6 +60,40 @@ class DifferentiableSelectionCriterion:
                 return math.inf
             raise
 
+    def evaluate_many(self, P, want_grad=False):
+        """Criterion at MANY parameter vectors (rows of ``P``) on the same data -- what a multi-chain sampler asks for at
+        every step (the reference evaluates ``selection_criterion(p)`` chain after chain, gpmp/mcmc/param_posterior.py:229-278,
+        mcmc/metropolis_hastings.py).  With an analytic ML / REML criterion and at most 1024 observations all rows go through
+        ONE batched library call (gpmp_nll_grad_batch with per-problem parameters); otherwise they are evaluated one after the
+        other.  A row whose factorisation fails gets +inf (and a zero gradient), as ``evaluate_no_grad`` does.
+        Returns ``values`` (C,) or ``(values, grads)`` with ``grads`` (C, len(p))."""
+        P = numpy.atleast_2d(numpy.asarray(P, dtype=numpy.float64))
+        C = P.shape[0]
+        values = numpy.full(C, math.inf)
+        grads = numpy.zeros_like(P) if want_grad else None
+        fast = getattr(self._analytic, "many_values_and_gradients", None)
+        done = False
+        if fast is not None:
+            try:
+                out = fast(P, self.x, self.z, want_grad)
+            except Exception as exc:          # one bad row poisons a batched call: fall back to row-by-row below
+                if not _is_linalg_exception(exc):
+                    raise
+                out = None
+            if out is not None:
+                values, g = out
+                if want_grad:
+                    grads = g
+                done = True
+        if not done:
+            for c in range(C):
+                if want_grad and self._analytic is not None:
+                    values[c] = self.evaluate_pre_grad(P[c])
+                    grads[c] = self._gradient(P[c])
+                else:
+                    values[c] = self.evaluate_no_grad(P[c])
+        return (values, grads) if want_grad else values
+
     def _gradient(self, p):
         p_arr = numpy.asarray(p, dtype=numpy.float64)
         if self._p_value is None or not numpy.array_equal(p_arr, self._p_value):

@@ -156,6 +156,41 @@ def test_batch_criterion_fast_path_equals_one_at_a_time(env, golden):
         obj.use_batched_kernel = True
 
 
+def test_criterion_at_many_parameter_vectors_sampler_pattern(env, golden):
+    """criterion.evaluate_many(P): the chains of a sampler ask for the criterion at many parameter vectors on the SAME data
+    (gpmp/mcmc/param_posterior.py:229-278 evaluates them one after the other); one batched call must agree with the
+    one-at-a-time route, value and gradient, for ML, REML and REMAP, and a row that cannot be factored gets +inf"""
+    import gpmp_amd as gp
+    import gpmp_amd.num as gnp
+
+    g = golden("batch")
+    p = int(g["batch_p"])
+    xi, zi = g["batch_xi"][:300], g["batch_zi"][:300]
+    ones = lambda x, prm: gnp.ones((x.shape[0], 1))  # noqa: E731
+    k = gp.kernel.MaternCovariance(p)
+    base = np.asarray(g["batch_thetas"][0], dtype=float)
+    rng = np.random.default_rng(5)
+    P = base + 0.3 * rng.standard_normal((9, base.size))
+    for model, crit in ((gp.Model(None, k, None, None, "zero"), gp.kernel.negative_log_likelihood_zero_mean),
+                        (gp.Model(ones, k, None, None), gp.kernel.negative_log_restricted_likelihood)):
+        ev, pre, nograd, grad = gp.kernel.make_selection_criterion_with_gradient(model, crit, xi, zi)
+        obj = pre.__self__
+        vals, grads = obj.evaluate_many(P, want_grad=True)
+        only_vals = obj.evaluate_many(P)
+        for c in range(P.shape[0]):
+            v = pre(P[c])
+            gr = grad(P[c])
+            assert abs(vals[c] - v) < 1e-11 * abs(v) and abs(only_vals[c] - v) < 1e-11 * abs(v), (c, vals[c], v)
+            assert rel_err(grads[c], gr) < 1e-9, c
+        # a row far outside anything factorable (length scales of 1e-30 .. 1e+30 alternate): +inf for that row only
+        bad = P.copy()
+        bad[4, 1:] = np.where(np.arange(base.size - 1) % 2 == 0, 70.0, -70.0)
+        bad[4, 0] = 700.0
+        v_bad = obj.evaluate_many(bad)
+        ok = np.ones(P.shape[0], bool); ok[4] = False
+        assert np.allclose(v_bad[ok], vals[ok], rtol=1e-11) and (not np.isfinite(v_bad[4]) or abs(v_bad[4]) > 1e10)
+
+
 @pytest.mark.parametrize("B,n,d,q", [(1, 5, 1, 0), (1, 129, 2, 1), (3, 4, 1, 3), (2, 1024, 6, 2), (17, 130, 3, 0)])
 def test_batch_driver_edge_shapes(env, B, n, d, q):
     """one problem, tiny problems (n just above q), one-dimensional inputs, the largest slot size, a block boundary + 2"""
