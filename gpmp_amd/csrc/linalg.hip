@@ -662,15 +662,15 @@ extern "C" int gpmp_potrf_trsm_lower_async(double* A, int n, long lda, double* d
   // n = 4096), so the rows of every panel are solved behind that panel's factorisation on a third stream.
   const char* al = getenv("GPMP_POTRF_SOLVE_ALONG_BELOW");
   const int along_below = al ? atoi(al) : 8192;
-  if (m > 4 && n > 2 * OUTER_BLOCKS * NB && n <= along_below) {
+  if (m > TRSV_FEW_MAX && n > 2 * OUTER_BLOCKS * NB && n <= along_below) {
     SolveAlong sa;
     sa.B = B; sa.m = m; sa.ldb = ldb; sa.gws = gws; sa.every_panel = 1;
     return potrf_lookahead(A, n, lda, dinv, info_dev, st, &sa);
   }
-  if (!overlap || m <= 4 || n <= 8 * OUTER_BLOCKS * NB) {
+  if (!overlap || m <= TRSV_FEW_MAX || n <= 8 * OUTER_BLOCKS * NB) {
     int rc = (n <= 2 * OUTER_BLOCKS * NB) ? potrf_blocked(A, n, lda, dinv, info_dev, 0, st) : potrf_lookahead(A, n, lda, dinv, info_dev, st);
     if (rc || m == 0) return rc;
-    if (m <= 4) return trsv_few(A, n, lda, dinv, B, m, ldb, 0, st);
+    if (m <= TRSV_FEW_MAX) return trsv_few(A, n, lda, dinv, B, m, ldb, 0, st);
     return trsm_forward(A, n, lda, dinv, B, m, ldb, 0, 0, gws, st);
   }
   SolveAlong sa;
@@ -700,7 +700,7 @@ extern "C" int gpmp_trsm_lower(const double* L, int n, long ldl, const double* d
     if (rc) return rc;
     dinv = scratch;
   }
-  if (m <= 4) return trsv_few(L, n, ldl, dinv, B, m, ldb, trans, st);   // HBM-bound fused sweep
+  if (m <= TRSV_FEW_MAX) return trsv_few(L, n, ldl, dinv, B, m, ldb, trans, st);   // HBM-bound fused sweep
   // the panel scratch behind the block inverses (n > 1024, see gpmp_dinv_elems) of `scratch` enables the fused leaf
   double* gws = (scratch != nullptr && n > 2 * OUTER_BLOCKS * NB) ? scratch + (size_t)((n + NB - 1) / NB) * NB * NB : nullptr;
   return trans ? trsm_backward(L, n, ldl, dinv, B, m, ldb, st) : trsm_forward(L, n, ldl, dinv, B, m, ldb, 0, 0, gws, st);

@@ -1,4 +1,4 @@
-// Triangular solves with a few right-hand sides (m <= 4 per pass): the single-vector solves of the
+// Triangular solves with a few right-hand sides (m <= 16 per pass): the single-vector solves of the
 // likelihood (L^-1 z, gpmp/core/likelihood.py:46) and of the mean-space algebra (L^-1 [z, P]).
 // HBM-bound (every element of L is read once: 4 n^2 bytes), so it runs as one small kernel per 128-row
 // diagonal block instead of going through 128 x 128 MFMA tiles:
@@ -412,21 +412,29 @@ int run(const double* L, int n, long ldl, const double* dinv, double* B, int m, 
 
 }  // namespace
 
-// In-place op(L)^-1 B for an n x m B with m <= 4.
+// In-place op(L)^-1 B for an n x m B with m <= TRSV_FEW_MAX (16): the single right-hand sides of the likelihood, and
+// L^-1 [z, P] / L^-T (.) of the mean-space algebra with up to 15 mean columns (a linear mean in d = 8 has 9).  The sweep
+// reads L once whatever the number of columns; through the 128 x 128 MFMA tiles of the many-column solve, 10 columns cost
+// as much as 128 (predict with a linear mean at n = 4096 / m = 10000: 9.3 -> 7.x ms).
 int trsv_few(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int trans,
              hipStream_t st) {
   // one persistent launch from a few blocks up (GPMP_TRSV_PERSIST=0: the launch-per-block chain)
   const char* pe = getenv("GPMP_TRSV_PERSIST");     // read at every call (tests compare both routes)
   const int persist = pe ? atoi(pe) : 1;
   const int nblk = (n + NB - 1) / NB;
+  if (m > TRSV_FEW_MAX) { set_error("trsv_few: %d right-hand sides (at most %d)", m, TRSV_FEW_MAX); return -1; }
   if (persist && nblk >= 3 && nblk <= TRSV_MAXBLK) {
     if (m <= 1) return run_persist<1>(L, n, ldl, dinv, B, m, ldb, trans, st);
     if (m <= 2) return run_persist<2>(L, n, ldl, dinv, B, m, ldb, trans, st);
-    return run_persist<4>(L, n, ldl, dinv, B, m, ldb, trans, st);
+    if (m <= 4) return run_persist<4>(L, n, ldl, dinv, B, m, ldb, trans, st);
+    if (m <= 8) return run_persist<8>(L, n, ldl, dinv, B, m, ldb, trans, st);
+    return run_persist<16>(L, n, ldl, dinv, B, m, ldb, trans, st);
   }
   if (m <= 1) return run<1>(L, n, ldl, dinv, B, m, ldb, trans, st);
   if (m <= 2) return run<2>(L, n, ldl, dinv, B, m, ldb, trans, st);
-  return run<4>(L, n, ldl, dinv, B, m, ldb, trans, st);
+  if (m <= 4) return run<4>(L, n, ldl, dinv, B, m, ldb, trans, st);
+  if (m <= 8) return run<8>(L, n, ldl, dinv, B, m, ldb, trans, st);
+  return run<16>(L, n, ldl, dinv, B, m, ldb, trans, st);
 }
 
 // Number of single-vector solves on `stream` that gave up since the last call (0 in any healthy run); synchronises the

@@ -313,9 +313,9 @@ def test_trtri_doubling_vs_forward_solve_and_numpy(gnp, n):
 
 
 @pytest.mark.parametrize("n", [300, 1000, 4101, 9000])
-@pytest.mark.parametrize("r", [1, 2, 3, 4])
+@pytest.mark.parametrize("r", [1, 2, 3, 4, 7, 10, 16])
 def test_single_vector_solves_persistent_vs_chain(gnp, n, r):
-    """op(L)^-1 B for <= 4 right-hand sides: the one-launch kernel (workgroups hand x_k over through device memory) against
+    """op(L)^-1 B for <= 16 right-hand sides (the sweep that reads L once; 10 = [z, P] of a linear mean in d = 8): the one-launch kernel (workgroups hand x_k over through device memory) against
     the launch-per-block chain and against SciPy, forward and transposed, ragged last block included"""
     import os
     import scipy.linalg as sla
