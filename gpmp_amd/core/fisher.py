@@ -72,7 +72,7 @@ def fisher_information_cpd(model, xi, covparam=None, epsilon: float = 1e-3):
     P = _mean_values(model, xi, model.meanparam)
     U = F.solve(P)                                   # n x q
     S = gnp.matmul(P, U, ta=True)                    # q x q = P^T K^-1 P (library GEMM)
-    US = gnp.matmul(U, torch.linalg.inv(0.5 * (S + S.T)))   # n x q
+    US = gnp.matmul(U, gnp.small_spd_inverse(S, "P^T K^-1 P"))   # n x q
     B = []
     for D in _derivative_matrices(model, xi, theta, epsilon):
         KD = F.solve(D)

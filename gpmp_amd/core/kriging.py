@@ -55,10 +55,7 @@ class _Predictor:
             S = g[1:, 1:]
             self.S = 0.5 * (S + S.T)
             self.b = g[1:, 0]                               # Wp^T w
-            ev = torch.linalg.eigvalsh(self.S)              # q x q, plumbing-sized
-            if not float(ev[0]) > self.q * gnp.eps * float(ev[-1]):
-                raise numpy.linalg.LinAlgError("P^T K^-1 P is singular to working precision (rank-deficient mean design)")
-            self.Sinv = torch.linalg.inv(self.S)
+            self.Sinv = gnp.small_spd_inverse(self.S, "P^T K^-1 P")     # q x q, on the host (rank check included)
 
     def chunk(self, xt, want_lambda, want_var=True):
         model = self.model

@@ -49,7 +49,7 @@ def _loo_with_linear_predictor_mean_cpd(model, meanparam, covparam, xi, zi):
     G = gnp.coldots(U, Y)[:-1]                   # (1 + q) x q: rows z^T U, P^T U  (one pass over U)
     S = G[1:]                                    # q x q = P^T K^-1 P
     S = 0.5 * (S + S.T)
-    US = gnp.matmul(U, torch.linalg.inv(S))      # n x q on the library GEMM
+    US = gnp.matmul(U, gnp.small_spd_inverse(S, "P^T K^-1 P"))      # n x q on the library GEMM
     Qinv_z = Kinv_z - gnp.matmul(US, G[0])
     Qinv_diag = d - torch.sum(US * U, dim=1)
     eloo = Qinv_z / Qinv_diag

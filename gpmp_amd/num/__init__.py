@@ -144,6 +144,19 @@ def to_np(x):
     return numpy.asarray(x)
 
 
+def small_spd_inverse(S, what="matrix"):
+    """Inverse of a q x q symmetric positive definite matrix of the mean-space algebra (q = number of mean columns): the
+    q^2 numbers are taken to the host, checked for numerical rank (lambda_min > q eps lambda_max, the test the reference's
+    np.linalg.solve would fail) and inverted there -- as the reference does in NumPy (gpmp/core/kriging.py:141-159,
+    loo.py:118-124); a device-side eigensolver / LU for a 9 x 9 matrix is a dozen library kernels on the critical path."""
+    Sh = to_np(S).astype(numpy.float64)
+    Sh = 0.5 * (Sh + Sh.T)
+    ev = numpy.linalg.eigvalsh(Sh)
+    if not ev[0] > Sh.shape[0] * eps * ev[-1]:
+        raise numpy.linalg.LinAlgError(f"{what} is singular to working precision (rank-deficient mean design)")
+    return asarray(numpy.linalg.inv(Sh))
+
+
 def to_scalar(x):
     if isinstance(x, (int, float, bool)):
         return x
