@@ -125,10 +125,14 @@ int trtri_doubling_batch(const double* L, int n, long ldl, const double* dinv, d
                          long stride_t, hipStream_t st);
 // Gram matrices (lower tiles) / gradient traces of `nprob` problems that share ONE parameter vector, one launch each (gram.hip)
 int launch_gram_lower_batch(const double* x, long stride_x, const int* ns_dev, int nmax, int d, int p, const double* theta_host,
-                            int noise, double diag_add, double* K, long ldk, long stride_k, int nprob, hipStream_t st);
+                            int noise, double diag_add, double* K, long ldk, long stride_k, int nprob, hipStream_t st,
+                            const double* pp_dev = nullptr);
+// per-problem parameter blocks of the batched Gram / gradient-trace kernels (pp_dev: nprob blocks in device memory)
+int gram_param_block_elems();
+void fill_gram_param_block(double* blk, int d, int p, const double* theta, int noise, double diag_add);
 int launch_grad_trace_batch(const double* Kinv, long ldk, long stride_kinv, const double* x, long stride_x, const int* ns_dev, int nmax,
                             int d, int p, const double* theta_host, int noise, const double* F, const double* G, int r, long ldf,
-                            long stride_f, double* g_dev, double* ws, int nprob, hipStream_t st);
+                            long stride_f, double* g_dev, double* ws, int nprob, hipStream_t st, const double* pp_dev = nullptr);
 int lauum_lower_batch(const double* T, int n, long ldt, long stride_t, double* Kinv, long ldk, long stride_k, int nprob,
                       hipStream_t st);
 

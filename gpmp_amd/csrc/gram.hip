@@ -108,7 +108,12 @@ struct GramParams {
   int nprob;
   long stride_x, stride_k;
   const int* ns;
+  // per-problem PARAMETERS (sampler pattern: the same kernel, every problem its own theta): pp + b * PP_STRIDE holds
+  // [scale (GPMP_MAX_DIM) | q (GPMP_MAX_P + 1) | diag_add | sigma2 | noise variance]; nullptr: the values above
+  const double* pp;
 };
+constexpr int PP_Q = GPMP_MAX_DIM, PP_DIAG = GPMP_MAX_DIM + GPMP_MAX_P + 1, PP_SIGMA2 = PP_DIAG + 1, PP_NOISE = PP_DIAG + 2,
+              PP_STRIDE = PP_DIAG + 3;
 
 // 128 x 64 output tile per 256-thread workgroup, 8 x 4 outputs per thread.
 // Per entry: 2 d VALU instructions of distance + 9 (sqrt) + 19 (exp) + P + 1 (Matern polynomial, sigma^2 folded in).
@@ -132,6 +137,7 @@ __global__ void __launch_bounds__(256) gram_kernel_v3(GramParams p) {
     if (p.ns != nullptr) pn = pm = p.ns[blockIdx.z];
     if (row0 >= pn || col0 >= pm) return;
   }
+  const double* __restrict__ ppb = p.pp != nullptr ? p.pp + (long)blockIdx.z * PP_STRIDE : nullptr;   // wave-uniform
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   const double* __restrict__ yp = p.same ? px : p.y;
 
@@ -148,11 +154,11 @@ __global__ void __launch_bounds__(256) gram_kernel_v3(GramParams p) {
     // (global reads contiguous along k), LDS stores scatter over rows
     for (int idx = t; idx < 128 * kc; idx += 256) {
       const int r = idx / kc, k = idx - r * kc;
-      xs[k][r] = (row0 + r < pn) ? p.scale[k0 + k] * px[(long)(row0 + r) * p.d + k0 + k] : 0.0;
+      xs[k][r] = (row0 + r < pn) ? (ppb ? ppb[k0 + k] : p.scale[k0 + k]) * px[(long)(row0 + r) * p.d + k0 + k] : 0.0;
     }
     for (int idx = t; idx < GT * kc; idx += 256) {
       const int r = idx / kc, k = idx - r * kc;
-      ys[k][r] = (col0 + r < pm) ? p.scale[k0 + k] * yp[(long)(col0 + r) * p.d + k0 + k] : 0.0;
+      ys[k][r] = (col0 + r < pm) ? (ppb ? ppb[k0 + k] : p.scale[k0 + k]) * yp[(long)(col0 + r) * p.d + k0 + k] : 0.0;
     }
     __syncthreads();
     for (int k = 0; k < kc; ++k) {
@@ -181,7 +187,15 @@ __global__ void __launch_bounds__(256) gram_kernel_v3(GramParams p) {
   // leading coefficients of the two Horner chains live in VGPRs (their first fma would otherwise need two SGPR operands
   // and the compiler copies one of them next to every use)
   const int pdeg = (P >= 0) ? P : p.p;
-  double qtop = p.q[pdeg], c12 = p.fe.c[12];
+  // Matern coefficients and the diagonal term: from the kernel arguments, or from this problem's block (uniform either way)
+  constexpr int NQ = P >= 0 ? P + 1 : 1;
+  double qc[NQ];
+  if constexpr (P >= 0) {
+#pragma unroll
+    for (int k = 0; k <= P; ++k) qc[k] = ppb ? ppb[PP_Q + k] : p.q[k];
+  }
+  const double dadd = ppb ? ppb[PP_DIAG] : p.diag_add;
+  double qtop = ppb ? ppb[PP_Q + pdeg] : p.q[pdeg], c12 = p.fe.c[12];
   asm volatile("" : "+v"(qtop), "+v"(c12));
 #pragma unroll
   for (int a = 0; a < 8; ++a, out += p.ldk) {
@@ -217,11 +231,13 @@ __global__ void __launch_bounds__(256) gram_kernel_v3(GramParams p) {
 #pragma unroll
         for (int k = P - 1; k >= 0; --k)
 #pragma unroll
-          for (int b = 0; b < 4; ++b) poly[b] = fma(poly[b], g[b], p.q[k]);
+          for (int b = 0; b < 4; ++b) poly[b] = fma(poly[b], g[b], qc[k]);
       } else {
-        for (int k = pdeg - 1; k >= 0; --k)
+        for (int k = pdeg - 1; k >= 0; --k) {
+          const double qk = ppb ? ppb[PP_Q + k] : p.q[k];
 #pragma unroll
-          for (int b = 0; b < 4; ++b) poly[b] = fma(poly[b], g[b], p.q[k]);
+          for (int b = 0; b < 4; ++b) poly[b] = fma(poly[b], g[b], qk);
+        }
       }
 #pragma unroll
       for (int j = 11; j >= 0; --j)
@@ -239,7 +255,7 @@ __global__ void __launch_bounds__(256) gram_kernel_v3(GramParams p) {
     if (diag_tile) {
 #pragma unroll
       for (int b = 0; b < 4; ++b)
-        if (row == col0 + (b >> 1) * 32 + 2 * tx + (b & 1)) v[b] += p.diag_add;
+        if (row == col0 + (b >> 1) * 32 + 2 * tx + (b & 1)) v[b] += dadd;
     }
     if (full) {
       *reinterpret_cast<d2*>(out) = (d2){v[0], v[1]};
@@ -341,6 +357,7 @@ struct GradParams {
   int nprob;
   long stride_kinv, stride_x, stride_f, stride_partial;
   const int* ns;
+  const double* pp;              // per-problem parameter blocks (see GramParams), or nullptr
   double invrho[GPMP_MAX_DIM];   // 2 c / rho_j: the tile accumulates t^2 = (2 c h)^2 and the weights are per (2 c delta_j)^2
   MaternSpec ms;
   FastExp fe;
@@ -358,7 +375,9 @@ __device__ __forceinline__ double matern_dk_over_h(const MaternSpec& ms, double 
   return (2.0 * ms.c) * (2.0 * ms.c) * e * s;
 }
 
-template <int DT>
+// PP: length scales from the problem's parameter block in device memory instead of the kernel arguments (a run-time choice
+// between the two sources made the compiler copy the argument block to scratch memory: compile-time instead)
+template <int DT, bool PP = false>
 __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* xs = sm;                    // [DT][GT]
@@ -379,6 +398,8 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
   const double* __restrict__ pG = p.G;
   double* __restrict__ ppartial = p.partial;
   int pn = p.n, pntiles_side = p.ntiles_side, pntiles = p.ntiles;
+  const double* __restrict__ ppb = PP ? p.pp + (long)blockIdx.y * PP_STRIDE : nullptr;
+  (void)ppb;
   if (p.nprob > 1) {
     const int z = blockIdx.y;
     pKinv += (long)z * p.stride_kinv;
@@ -404,7 +425,8 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
       const int r = idx / DT, k = idx % DT;
       double vx = 0.0, vy = 0.0;
       if (k < p.d) {
-        const double ir = p.invrho[k];
+        double ir;
+        if constexpr (PP) ir = ppb[k]; else ir = p.invrho[k];
         if (row0 + r < pn) vx = ir * px[(long)(row0 + r) * p.d + k];
         if (col0 + r < pn) vy = ir * px[(long)(col0 + r) * p.d + k];
       }
@@ -518,10 +540,15 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
 
 __global__ void grad_finalize_kernel(const double* __restrict__ partial, int nblocks, int width,
                                      int d, int noise, double sigma2, double nugget_scale,
-                                     double noise_var, double* __restrict__ g, long stride_partial = 0, int stride_g = 0) {
+                                     double noise_var, double* __restrict__ g, long stride_partial = 0, int stride_g = 0,
+                                     const double* __restrict__ pp = nullptr) {
   // one thread per output column of `partial`; blockIdx.x = problem of a batched launch
   partial += (long)blockIdx.x * stride_partial;
   g += (long)blockIdx.x * stride_g;
+  if (pp != nullptr) {                        // per-problem parameters
+    sigma2 = pp[(long)blockIdx.x * PP_STRIDE + PP_SIGMA2];
+    noise_var = pp[(long)blockIdx.x * PP_STRIDE + PP_NOISE];
+  }
   const int k = threadIdx.x;
   if (k >= width) return;
   double s = 0.0;
@@ -610,7 +637,7 @@ extern "C" int gpmp_matern_gram(const double* x, const double* y, int n, int m, 
   GPMP_ARG(ldk >= m, 12, "ldk < m");
   if (n == 0 || m == 0) return 0;
   GramParams gp;
-  gp.nprob = 1; gp.stride_x = gp.stride_k = 0; gp.ns = nullptr;
+  gp.nprob = 1; gp.stride_x = gp.stride_k = 0; gp.ns = nullptr; gp.pp = nullptr;
   gp.x = x; gp.y = y; gp.K = K; gp.ldk = ldk;
   gp.n = n; gp.m = m; gp.d = d;
   gp.same = (y == nullptr); gp.lower_only = (y == nullptr) ? lower_only : 0;
@@ -642,7 +669,7 @@ extern "C" int gpmp_scaled_distance(const double* x, const double* y, int n, int
   GPMP_ARG(D != nullptr && ldd >= m, 7, "D is NULL or ldd < m");
   if (n <= 0 || m <= 0) return 0;
   GramParams gp;
-  gp.nprob = 1; gp.stride_x = gp.stride_k = 0; gp.ns = nullptr;
+  gp.nprob = 1; gp.stride_x = gp.stride_k = 0; gp.ns = nullptr; gp.pp = nullptr;
   gp.x = x; gp.y = y; gp.K = D; gp.ldk = ldd;
   gp.n = n; gp.m = m; gp.d = d;
   gp.same = 0; gp.lower_only = 0;
@@ -714,12 +741,26 @@ extern "C" size_t gpmp_grad_ws_elems(int n, int d) {
 }
 
 namespace gpmp {
+// One problem's parameter block (PP_STRIDE doubles, layout in GramParams) from its theta (host side).
+int gram_param_block_elems() { return PP_STRIDE; }
+void fill_gram_param_block(double* blk, int d, int p, const double* theta, int noise, double diag_add) {
+  MaternSpec ms;
+  fill_matern(ms, p);
+  const double sigma2 = std::exp(theta[0]);
+  const int off = noise ? 2 : 1;
+  for (int k = 0; k < GPMP_MAX_DIM; ++k) blk[k] = k < d ? 2.0 * ms.c * std::exp(theta[off + k]) : 0.0;
+  for (int k = 0; k <= GPMP_MAX_P; ++k) blk[PP_Q + k] = sigma2 * ms.q[k];
+  blk[PP_DIAG] = diag_add;
+  blk[PP_SIGMA2] = sigma2;
+  blk[PP_NOISE] = noise ? std::exp(theta[1]) : 0.0;
+}
 // ---- batched over many small problems with the SAME parameters (drivers_batch.hip) ---------------------------------
 // Lower-tile Gram matrices of `nprob` problems (points x + b * stride_x, ns[b] of them; matrices K + b * stride_k) in ONE launch.
 int launch_gram_lower_batch(const double* x, long stride_x, const int* ns_dev, int nmax, int d, int p, const double* theta_host,
-                            int noise, double diag_add, double* K, long ldk, long stride_k, int nprob, hipStream_t st) {
+                            int noise, double diag_add, double* K, long ldk, long stride_k, int nprob, hipStream_t st,
+                            const double* pp_dev) {
   GramParams gp;
-  gp.nprob = 1; gp.stride_x = gp.stride_k = 0; gp.ns = nullptr;
+  gp.nprob = 1; gp.stride_x = gp.stride_k = 0; gp.ns = nullptr; gp.pp = nullptr;
   gp.x = x; gp.y = nullptr; gp.K = K; gp.ldk = ldk;
   gp.n = nmax; gp.m = nmax; gp.d = d;
   gp.same = 1; gp.lower_only = 1;
@@ -736,6 +777,7 @@ int launch_gram_lower_batch(const double* x, long stride_x, const int* ns_dev, i
   fill_fast_exp(gp.fe);
   gp.nprob = nprob > 1 ? nprob : 2;      // (a batch of one still takes the batched addressing: ns is read)
   gp.stride_x = stride_x; gp.stride_k = stride_k; gp.ns = ns_dev;
+  gp.pp = pp_dev;
   {
     ProfScope ps(PK_GRAM, st, 4.0 * (double)nmax * (double)nmax * nprob);
     dim3 grid((nmax + GT - 1) / GT, (nmax + 127) / 128, nprob);
@@ -755,8 +797,9 @@ int launch_gram_lower_batch(const double* x, long stride_x, const int* ns_dev, i
 // g_dev + b * ntheta <- sum M_b dK_b / dtheta (see gpmp_matern_grad_trace), ws: nprob * gpmp_grad_ws_elems(nmax, d) doubles.
 int launch_grad_trace_batch(const double* Kinv, long ldk, long stride_kinv, const double* x, long stride_x, const int* ns_dev, int nmax,
                             int d, int p, const double* theta_host, int noise, const double* F, const double* G, int r, long ldf,
-                            long stride_f, double* g_dev, double* ws, int nprob, hipStream_t st) {
+                            long stride_f, double* g_dev, double* ws, int nprob, hipStream_t st, const double* pp_dev) {
   GradParams gp;
+  gp.pp = nullptr;
   gp.Kinv = Kinv; gp.ldk = ldk; gp.x = x; gp.F = F; gp.G = G; gp.ldf = ldf;
   gp.n = nmax; gp.d = d; gp.r = r;
   gp.ntiles_side = (nmax + GT - 1) / GT;
@@ -774,6 +817,7 @@ int launch_grad_trace_batch(const double* Kinv, long ldk, long stride_kinv, cons
   gp.stride_kinv = stride_kinv; gp.stride_x = stride_x; gp.stride_f = stride_f;
   gp.stride_partial = (long)GRAD_BLOCKS * (dt + 2);
   gp.ns = ns_dev;
+  gp.pp = pp_dev;
   int rc = 0;
   {
     GradParams g1 = gp;
@@ -784,12 +828,22 @@ int launch_grad_trace_batch(const double* Kinv, long ldk, long stride_kinv, cons
       GPMP_HIP_TRY(hipGetLastError());
       return 0;
     };
-    switch (dt) {
-      case 4: rc = go(grad_trace_kernel<4>); break;
-      case 8: rc = go(grad_trace_kernel<8>); break;
-      case 16: rc = go(grad_trace_kernel<16>); break;
-      case 32: rc = go(grad_trace_kernel<32>); break;
-      default: rc = go(grad_trace_kernel<64>); break;
+    if (pp_dev != nullptr) {
+      switch (dt) {
+        case 4: rc = go(grad_trace_kernel<4, true>); break;
+        case 8: rc = go(grad_trace_kernel<8, true>); break;
+        case 16: rc = go(grad_trace_kernel<16, true>); break;
+        case 32: rc = go(grad_trace_kernel<32, true>); break;
+        default: rc = go(grad_trace_kernel<64, true>); break;
+      }
+    } else {
+      switch (dt) {
+        case 4: rc = go(grad_trace_kernel<4>); break;
+        case 8: rc = go(grad_trace_kernel<8>); break;
+        case 16: rc = go(grad_trace_kernel<16>); break;
+        case 32: rc = go(grad_trace_kernel<32>); break;
+        default: rc = go(grad_trace_kernel<64>); break;
+      }
     }
   }
   if (rc) return rc;
@@ -797,7 +851,7 @@ int launch_grad_trace_batch(const double* Kinv, long ldk, long stride_kinv, cons
   const double nugget_scale = noise ? 0.0 : 10.0 * eps;
   const double noise_var = noise ? std::exp(theta_host[1]) : 0.0;
   hipLaunchKernelGGL(grad_finalize_kernel, dim3(nprob), dim3(128), 0, st, ws, nblocks, dt + 2, d, noise, gp.sigma2, nugget_scale, noise_var,
-                     g_dev, gp.stride_partial, 1 + (noise ? 1 : 0) + d);
+                     g_dev, gp.stride_partial, 1 + (noise ? 1 : 0) + d, pp_dev);
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -816,6 +870,7 @@ extern "C" int gpmp_matern_grad_trace(const double* Kinv, long ldk, const double
   GPMP_ARG(r == 0 || (F != nullptr && G != nullptr), 9, "F/G NULL with r > 0");
   GPMP_ARG(g_dev != nullptr && ws != nullptr, 13, "g or ws is NULL");
   GradParams gp;
+  gp.pp = nullptr;
   gp.nprob = 1; gp.stride_kinv = gp.stride_x = gp.stride_f = gp.stride_partial = 0; gp.ns = nullptr;
   gp.Kinv = Kinv; gp.ldk = ldk; gp.x = x; gp.F = F; gp.G = G; gp.ldf = ldf;
   gp.n = n; gp.d = d; gp.r = r;

@@ -13,7 +13,7 @@ d = 4
 th = np.concatenate(([0.0], -np.log(0.5 * (1.0 + np.arange(d) / d))))
 model = gp.Model(None, gp.kernel.MaternCovariance(2), None, th, "zero")
 ana = MLZeroMeanAnalytic(model)
-print("n      B   batched ms   problems/s   one-at-a-time ms   problems/s   speed-up")
+print("n      B   batched ms   problems/s   one-at-a-time ms   problems/s   speed-up   | per-problem parameters (sampler pattern): ms   problems/s")
 for n in (128, 256, 512, 1024):
     for B in (8, 64, 256):
         rng = np.random.default_rng(n + B)
@@ -39,4 +39,12 @@ for n in (128, 256, 512, 1024):
         torch.cuda.synchronize()
         ts = (time.perf_counter() - t0) / nseq * B
         assert abs(vals[nseq - 1] - v) < 1e-10 * abs(v) and np.max(np.abs(grads[nseq - 1] - gseq)) < 1e-8 * np.max(np.abs(gseq))
-        print(f"{n:5d} {B:4d}   {1e3*tb:9.2f}   {B/tb:10.0f}   {1e3*ts:16.2f}   {B/ts:10.0f}   {ts/tb:7.1f}x")
+        TH = th + 0.05 * rng.standard_normal((B, th.size))
+        batch_values_and_gradients(model, TH, batches, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            vp, gp_ = batch_values_and_gradients(model, TH, batches, True)
+        torch.cuda.synchronize()
+        tp = (time.perf_counter() - t0) / 3
+        print(f"{n:5d} {B:4d}   {1e3*tb:9.2f}   {B/tb:10.0f}   {1e3*ts:16.2f}   {B/ts:10.0f}   {ts/tb:7.1f}x   | {1e3*tp:9.2f}   {B/tp:10.0f}")
