@@ -361,14 +361,22 @@ extern "C" int gpmp_nll_grad_batch(const double* x, long stride_x, const double*
     // launches run (round 2, first version: one small Gram launch, one padding launch and two gradient launches per problem --
     // 29 k problems/s at n = 128 against 75 k with shared parameters)
     const int pps = gram_param_block_elems();
-    std::vector<double> blocks((size_t)pps * B);
+    // (the staging buffer lives until the copy has run: freed by a host function enqueued behind it -- the call stays
+    //  enqueue-only)
+    std::vector<double>* blocks = new std::vector<double>((size_t)pps * B);
     for (int b = 0; b < B; ++b) {
       const double* th = theta_host + (long)b * theta_stride;
       const double diag = noise ? std::exp(th[1]) : 10.0 * std::exp(th[0]) * DBL_EPSILON;      // matern.py:90
-      fill_gram_param_block(blocks.data() + (size_t)pps * b, d, p, th, noise, diag);
+      fill_gram_param_block(blocks->data() + (size_t)pps * b, d, p, th, noise, diag);
     }
-    GPMP_HIP_TRY(hipMemcpyAsync(ws + l.pp, blocks.data(), sizeof(double) * blocks.size(), hipMemcpyHostToDevice, st));
-    GPMP_HIP_TRY(hipStreamSynchronize(st));      // `blocks` is pageable host memory that dies with this scope
+    hipError_t ce = hipMemcpyAsync(ws + l.pp, blocks->data(), sizeof(double) * blocks->size(), hipMemcpyHostToDevice, st);
+    if (ce == hipSuccess) ce = hipLaunchHostFunc(st, [](void* v) { delete static_cast<std::vector<double>*>(v); }, blocks);
+    if (ce != hipSuccess) {
+      (void)hipStreamSynchronize(st);
+      delete blocks;
+      set_error("HIP error %s staging the per-problem parameters", hipGetErrorString(ce));
+      return -100;
+    }
     int rc0 = launch_gram_lower_batch(x, stride_x, ns, nmax, d, p, theta_host, noise, 0.0, K, l.ld, (long)l.sK, B, st, ws + l.pp);
     if (rc0) return rc0;
     if (ragged) {
