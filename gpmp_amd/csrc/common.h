@@ -51,23 +51,6 @@ struct ProfScope {
 // lower_only: tiles strictly above the diagonal are skipped.  kstart_row: the k loop of tile row i
 // starts at row0(i) (lauum; K and M index the same axis).  kend_row: the k loop of tile row i ends
 // at row0(i) + 128 (triangular A: A(i,l) = 0 for l > i).
-// ---- compute-unit yield table (gemm_f64.hip / potf2.hip) ----------------------------------------------------------------
-// gfx950's f64 MFMA and f64 vector ALU share the FP64 units: beside a GEMM wave's back-to-back 64-cycle MFMAs every dependent
-// v_fma_f64 of the diagonal-block kernel waits for a gap, and the kernel takes 180-260 us instead of 31.  The kernel therefore
-// announces itself in a table indexed by the hardware id of its compute unit -- an EXPIRING stamp (wall clock + 80 us, cleared
-// when the kernel ends, so a kernel that dies leaves nothing behind) -- and the LDS-direct GEMM looks at its own compute unit's
-// entry every fourth k-tile (one 4-byte load issued a k-tile ahead, consumed behind the barrier that waits for vmcnt(0) anyway)
-// and sleeps while the stamp is in the future.  Cost for the GEMM: two workgroups idle for the 31 us of a diagonal block.
-constexpr int CU_TABLE_ENTRIES = 4096;      // XCC_ID (4 bits) x HW_ID[15:8] (CU, SH, SE)
-unsigned int* cu_yield_table();             // device pointer (allocated and zeroed on first use), or nullptr when GPMP_CU_YIELD=0
-#if defined(__HIPCC__)
-__device__ __forceinline__ int cu_table_index() {
-  const unsigned int hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));     // HW_REG_HW_ID, bits [15:8]
-  const unsigned int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID, bits [3:0]
-  return (int)((xcc << 8) | hw);
-}
-#endif
-
 struct GemmOpts {
   int lower_only = 0;
   int kstart_row = 0;

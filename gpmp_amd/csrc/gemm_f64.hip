@@ -21,19 +21,6 @@
 namespace gpmp {
 
 int g_machine_busy = 0;   // gpmp_hint_machine_busy: small NT products take the small-footprint kernel
-// compute-unit yield table (common.h): one device per process (as the helper streams of linalg.hip)
-unsigned int* cu_yield_table() {
-  // (function-local static: initialised once, thread-safe; the one host synchronisation the library ever does)
-  static unsigned int* const tab = []() -> unsigned int* {
-    const char* e = getenv("GPMP_CU_YIELD");
-    if (e != nullptr && atoi(e) == 0) return nullptr;
-    unsigned int* t = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&t), sizeof(unsigned int) * CU_TABLE_ENTRIES) != hipSuccess) return nullptr;
-    if (hipMemset(t, 0, sizeof(unsigned int) * CU_TABLE_ENTRIES) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
-    return t;
-  }();
-  return tab;
-}
 
 namespace {
 
@@ -61,7 +48,6 @@ struct GemmParams {
   int batch2;   // gridDim.z independent problems (outer batch)
   int pair16;   // v2 epilogue: 16-byte stores after a lane-pair exchange
   int prio;     // small NT kernels: raise the wave priority (GPMP_CHAIN_PRIO)
-  const unsigned int* yield_tab;   // v2: compute-unit yield table (common.h), or nullptr
   long sa, sb, sc;   // element strides of A, B, C per batch index
   long sa2, sb2, sc2;   // ... per outer batch index (blockIdx.z)
 };
@@ -546,6 +532,8 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
     mfma_step(3);
   };
 
+  auto nothing = [] {};
+
   if (nk > 0) {
     issue(0, 0);
     __syncthreads();
@@ -576,25 +564,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
         kt = 16;
       }
     }
-    // every k-tile: has a diagonal-block kernel announced itself on this compute unit?  (common.h; the load is issued before the
-    // k-tile's operand loads and consumed behind its barrier, which waits for vmcnt(0) anyway)
-    const unsigned int* yslot = p.yield_tab != nullptr ? p.yield_tab + cu_table_index() : nullptr;
-    int budget = 96;      // sleeps of ~3 us this workgroup may take in its whole life: a stale stamp (a kernel that died before
-                          // clearing it, seen "in the future" again when the 32-bit clock wraps) costs at most ~0.3 ms per workgroup
-    for (; kt < nk; ++kt) {
-      unsigned int stamp = 0u;
-      if (yslot != nullptr) stamp = __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ktile(kt, kt + 1 < nk, [&] {
-        unsigned int s = __builtin_amdgcn_readfirstlane(stamp);
-        if (s != 0u) {
-          while (s != 0u && (int)(s - (unsigned int)wall_clock64()) > 0 && --budget > 0) {
-            __builtin_amdgcn_s_sleep(127);
-            __builtin_amdgcn_s_sleep(127);
-            s = __builtin_amdgcn_readfirstlane(__hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          }
-        }
-      });
-    }
+    for (; kt < nk; ++kt) ktile(kt, kt + 1 < nk, nothing);
   }
 
   if (!edge && (CACC || beta == 0.0) && pair_stores) {
@@ -1157,7 +1127,6 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   static int chain_prio = -1;
   if (chain_prio < 0) { const char* e = getenv("GPMP_CHAIN_PRIO"); chain_prio = e ? atoi(e) : 1; }
   p.prio = chain_prio;
-  p.yield_tab = cu_yield_table();
   p.batch = o.batch > 1 ? o.batch : 1;
   p.sa = o.stride_a; p.sb = o.stride_b; p.sc = o.stride_c;
   p.batch2 = o.batch2 > 1 ? o.batch2 : 1;

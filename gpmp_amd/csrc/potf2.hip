@@ -34,10 +34,11 @@
 // Beside a machine-filling trailing update the kernel takes 180-260 us instead of 31 (tools/potf2_probe.hip busy,
 // profiles/r2/potf2_phase_timeline_beside_gemm.log: every phase ~7 times longer, the register-only A1 included).  On gfx950
 // the f64 MFMA and the f64 vector ALU have the same peak rate -- they share the FP64 units -- so each dependent v_fma_f64 of the
-// chain waits for a gap between the co-resident GEMM wave's back-to-back 64-cycle MFMAs.  Kept against it: the kernel stamps its
-// compute unit in the yield table (common.h) and the GEMM workgroups there sleep while it runs (body 36 us beside a GEMM).  Built,
-// measured and dropped: CU-masked streams, a CU partition, and a resident workgroup serving the blocks from a mailbox
-// (the blocks then take 45 us, but a workgroup that holds a compute unit for the whole factorisation slows the trailing update by 11 %).
+// chain waits for a gap between the co-resident GEMM wave's back-to-back 64-cycle MFMAs.  Four ways around it were built and
+// measured in round 2, none kept: CU-masked streams, a CU partition, a resident workgroup serving the blocks from a
+// mailbox (the blocks then take 45 us, but a workgroup that holds a compute unit for the whole factorisation slows the trailing
+// update by 11 %), and a per-compute-unit yield table that makes the co-resident GEMM workgroups sleep (kernel body 36 us beside a
+// GEMM, but the check costs the GEMM's k-loop 2 % and the wait for a workgroup slot, ~150 us, stays).
 // Barriers inside the loop wait for LDS traffic only (lds_barrier): the stores to global memory ride along.
 // Phase timeline: tools/potf2_probe.hip (profiles/r2/potf2_phase_timeline_v2.log): load 4, eight steps of ~3.1 us
 // (A1 1.8, A2 1.0, A3 0.3), tail 2.8: 31 us of kernel against 40 (start of round 2) and 46 (round 1).
@@ -462,22 +463,11 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ A, long lda, int
 // (at most 128 registers: two waves per SIMD of this kernel must fit beside ONE resident wave of the 232-register GEMM)
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) potf2_inv_kernel(double* __restrict__ A, long lda, int n_total,
                                                             double* __restrict__ dinv, int* info, int offset,
-                                                            long prob_stride_a, long prob_stride_dinv, unsigned int* yield_tab) {
+                                                            long prob_stride_a, long prob_stride_dinv) {
   // batched over blockIdx.y: independent matrices (problems) prob_stride_a / prob_stride_dinv elements apart, one info word each
   extern __shared__ __attribute__((aligned(16))) double S[];   // [NPACK][16][16] packed lower block triangle + Td + dg
-  // announce the kernel on its compute unit: the GEMM workgroups that share it sleep until the stamp expires or is cleared
-  unsigned int* yslot = yield_tab != nullptr ? yield_tab + cu_table_index() : nullptr;
-  if (yslot != nullptr && threadIdx.x == 0) {
-    unsigned int stamp = (unsigned int)wall_clock64() + 8000u;      // 80 us of the 100 MHz clock
-    stamp = stamp == 0u ? 1u : stamp;
-    __hip_atomic_store(yslot, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   potf2_body(A + (long)blockIdx.y * prob_stride_a, lda, n_total < NB ? n_total : NB, dinv + (long)blockIdx.y * prob_stride_dinv,
              info + blockIdx.y, offset, S, (int)threadIdx.x);
-  if (yslot != nullptr) {
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(yslot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 // inv(L_dd) of the diagonal blocks of an already factored matrix (one workgroup per block; phases B and C after one another)
@@ -561,7 +551,7 @@ int launch_factor(double* A, long lda, int jb, double* dinv, int* info_dev, int 
   {
     ProfScope ps(PK_POTF2, st, (double)nprob);
     hipLaunchKernelGGL(potf2_inv_kernel, dim3(1, nprob), dim3(THREADS), POTF2_LDS, st, A, lda, jb, dinv, info_dev, offset,
-                       prob_stride_a, prob_stride_dinv, nprob == 1 ? cu_yield_table() : nullptr);
+                       prob_stride_a, prob_stride_dinv);
   }
   GPMP_HIP_TRY(hipGetLastError());
   return 0;

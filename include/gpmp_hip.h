@@ -15,10 +15,8 @@
  *    on `stream` (a hipStream_t passed as void*; NULL = the default stream); scalar results
  *    (info, log-det, gradient) land in caller-provided DEVICE words.
  *  - Callers (the torch allocator) own every matrix, vector and workspace; workspace sizes come from the
- *    gpmp_*_ws_* / gpmp_dinv_elems queries.  The library itself allocates two small things: the 16.4 KB flag block of the
- *    one-launch triangular solve, once per (device, stream) that uses it (see gpmp_solve_status), and a 16 KB table through
- *    which the diagonal-block kernel of the Cholesky asks the GEMM workgroups of its compute unit to pause (once per process,
- *    at the first product or factorisation: the only call that synchronises the device), plus host-side helper streams /
+ *    gpmp_*_ws_* / gpmp_dinv_elems queries.  The library itself allocates only the 16.4 KB flag block of the one-launch
+ *    triangular solve, once per (device, stream) that uses it (see gpmp_solve_status), plus host-side helper streams /
  *    events.  One device per process and one calling thread at a time per stream.
  *  - covparam layout (gpmp/kernel/matern.py:78-79,88-89): theta = [log sigma^2, log(1/rho_1..d)];
  *    with `noise` != 0 the layout is [log sigma^2, log sigma_noise^2, log(1/rho_1..d)]
