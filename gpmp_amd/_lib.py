@@ -52,6 +52,8 @@ SIGNATURES = {
     "gpmp_nll_zero_mean": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
     "gpmp_predict_ws_elems": (c_size_t, [c_int, c_int]),
     "gpmp_predict_zero_mean": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "gpmp_predict_mean_ws_elems": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "gpmp_predict_mean": (c_int, [_P, _P, _P, c_long, _P, _P, c_long, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "gpmp_reml_ws_elems": (c_size_t, [c_int, c_int]),
     "gpmp_reml": (c_int, [_P, _P, _P, c_long, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
     "gpmp_nll_grad_ws_elems": (c_size_t, [c_int, c_int, c_int]),

@@ -272,6 +272,64 @@ int factor_and_meanspace(const MeanLayout& l, const double* x, const double* z, 
   return 0;
 }
 
+// ---- prediction with a linear mean (universal kriging, gpmp/core/kriging.py:69-167 restated over the Schur complement) -------
+// Per prediction point j, with V = L^-1 K(xi, xt), W = L^-1 [z, P] = [w, Wp], S = Wp^T Wp, c = S^-1 Wp^T w, D = V^T W:
+//   r_j = D[1:, j] - Pt[j, :]          (what the Lagrange multipliers mu_j = S^-1 r_j have to absorb)
+//   mean_j = D[0, j] - c . r_j,        var_j = sigma^2 - (colsumsq(V)_j - r_j^T S^-1 r_j)
+__global__ void __launch_bounds__(256) predict_mean_finalize_kernel(const double* __restrict__ D, long ldd, const double* __restrict__ Pt,
+                                                                    long ldpt, int m, int q, const double* __restrict__ Sinv, long lds,
+                                                                    const double* __restrict__ small, double sigma2, int clamp,
+                                                                    const int* info, double* __restrict__ zpm, double* __restrict__ zpv) {
+  extern __shared__ double pm_lds[];           // Sinv (q x q) | c (q)
+  double* Si = pm_lds;
+  double* cs = pm_lds + (size_t)q * q;
+  for (int idx = threadIdx.x; idx < q * q; idx += blockDim.x) Si[idx] = Sinv[(long)(idx / q) * lds + idx % q];
+  for (int a = threadIdx.x; a < q; a += blockDim.x) cs[a] = small[SM_C + a];
+  __syncthreads();
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  double mean = D[j], quad = 0.0;
+  for (int a = 0; a < q; ++a) {
+    const double ra = D[(long)(1 + a) * ldd + j] - Pt[(long)j * ldpt + a];
+    mean -= cs[a] * ra;
+    double ta = 0.0;
+    for (int b = 0; b < q; ++b) ta += Si[a * q + b] * (D[(long)(1 + b) * ldd + j] - Pt[(long)j * ldpt + b]);
+    quad += ra * ta;
+  }
+  double v = sigma2 - (D[(long)(1 + q) * ldd + j] - quad);
+  if (clamp && v < 0.0) v = 0.0;
+  const bool bad = *info != 0;
+  const double nan = __builtin_nan("");
+  zpm[j] = bad ? nan : mean;
+  zpv[j] = bad ? nan : v;
+}
+
+struct PredictMeanLayout {
+  long ldn, ldm, ldq;
+  size_t K, dinv, Kit, Y, Gm, PtP, Sinv, small, D, cd, total;
+};
+PredictMeanLayout predict_mean_layout(int n, int m, int q) {
+  PredictMeanLayout l;
+  l.ldn = pad16(n);
+  l.ldm = pad16(m);
+  l.ldq = pad16(1 + q);
+  size_t o = 0;
+  auto take = [&](size_t cnt) { size_t at = o; o += (size_t)pad16((long)cnt); return at; };
+  l.K = take((size_t)n * l.ldn);
+  l.dinv = take(gpmp_dinv_elems(n));
+  l.Kit = take((size_t)n * l.ldm);
+  l.Y = take((size_t)n * l.ldq);
+  l.Gm = take((size_t)(2 + q) * l.ldq);
+  l.PtP = take((size_t)(1 + q) * l.ldq);
+  l.Sinv = take((size_t)(q > 0 ? q : 1) * l.ldq);
+  l.small = take(SM_TOTAL);
+  l.D = take((size_t)(2 + q) * l.ldm);
+  const size_t cols = (size_t)(m > 1 + q ? m : 1 + q);
+  l.cd = take(cols * (size_t)gpmp_coldots_ws_rows(n));
+  l.total = o;
+  return l;
+}
+
 }  // namespace
 }  // namespace gpmp
 
@@ -366,6 +424,68 @@ extern "C" int gpmp_loo(const double* x, const double* z, const double* P, long 
   if (rc) return rc;
   hipLaunchKernelGGL(rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, X, l.ldq, ws + l.Sinv, l.ldq, ws + l.small, q, n,
                      (double*)nullptr, (double*)nullptr, l.ldq, ws + l.dcol, z, info_dev, zloo_dev, sigma2loo_dev, eloo_dev);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" size_t gpmp_predict_mean_ws_elems(int n, int m, int q) {
+  return (n > 0 && m > 0 && q >= 1 && q <= QMAX) ? predict_mean_layout(n, m, q).total : 0;
+}
+
+extern "C" int gpmp_predict_mean(const double* xi, const double* zi, const double* Pi, long ldpi, const double* xt, const double* Pt,
+                                 long ldpt, int n, int m, int d, int q, int p, const double* theta_host, int noise,
+                                 int zero_neg_variances, double* ws, double* zpm_dev, double* zpv_dev, int* info_dev,
+                                 gpmp_stream_t stream) {
+  GPMP_ARG(xi != nullptr, 1, "xi is NULL");
+  GPMP_ARG(zi != nullptr, 2, "zi is NULL");
+  GPMP_ARG(q >= 1 && q <= QMAX, 11, "q outside [1, GPMP_MAX_RANK - 1] (q = 0: gpmp_predict_zero_mean)");
+  GPMP_ARG(Pi != nullptr && ldpi >= q, 3, "Pi is NULL or ldpi < q");
+  GPMP_ARG(xt != nullptr, 5, "xt is NULL");
+  GPMP_ARG(Pt != nullptr && ldpt >= q, 6, "Pt is NULL or ldpt < q");
+  GPMP_ARG(n > q, 8, "n <= q");
+  GPMP_ARG(m > 0, 9, "m <= 0");
+  GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 10, "d outside [1, GPMP_MAX_DIM]");
+  GPMP_ARG(theta_host != nullptr, 13, "theta is NULL");
+  GPMP_ARG(ws != nullptr, 16, "ws is NULL");
+  GPMP_ARG(zpm_dev != nullptr && zpv_dev != nullptr, 17, "output is NULL");
+  GPMP_ARG(info_dev != nullptr, 19, "info_dev is NULL");
+  hipStream_t st = as_stream(stream);
+  const PredictMeanLayout l = predict_mean_layout(n, m, q);
+  double* K = ws + l.K;
+  double* dinv = ws + l.dinv;
+  double* Kit = ws + l.Kit;
+  double* Y = ws + l.Y;
+  const double sigma2 = std::exp(theta_host[0]);
+  const double diag = noise ? std::exp(theta_host[1]) : 10.0 * sigma2 * DBL_EPSILON;   // matern.py:90
+  int rc = gpmp_matern_gram(xi, nullptr, n, n, d, p, theta_host, noise, diag, 1, K, l.ldn, stream);
+  if (rc) return rc;
+  rc = gpmp_matern_gram(xi, xt, n, m, d, p, theta_host, noise, 0.0, 0, Kit, l.ldm, stream);
+  if (rc) return rc;
+  rc = gpmp_potrf_trsm_lower_async(K, n, l.ldn, dinv, info_dev, Kit, m, l.ldm, stream);          // V = L^-1 K(xi, xt), in place
+  if (rc) return rc;
+  hipLaunchKernelGGL(pack_zp_kernel, dim3((n + 255) / 256), dim3(256), 0, st, zi, Pi, ldpi, n, q, Y, l.ldq);
+  GPMP_HIP_TRY(hipGetLastError());
+  rc = gpmp_trsm_lower(K, n, l.ldn, dinv, Y, 1 + q, l.ldq, 0, nullptr, stream);                   // W = L^-1 [z, P]
+  if (rc) return rc;
+  rc = gpmp_coldots(Y, n, 1 + q, l.ldq, Y, 1 + q, l.ldq, ws + l.Gm, l.ldq, ws + l.cd, stream);    // W^T W
+  if (rc) return rc;
+  rc = gpmp_coldots(Pi, n, q, ldpi, Pi, q, ldpi, ws + l.PtP, l.ldq, ws + l.cd, stream);
+  if (rc) return rc;
+  {
+    const size_t ms_bytes = sizeof(double) * (2 * QLD * (QLD + 1) + 3 * QLD);
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(meanspace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)ms_bytes));
+    hipLaunchKernelGGL(meanspace_kernel, dim3(1), dim3(256), ms_bytes, st, ws + l.Gm, l.ldq, ws + l.PtP, l.ldq, q, n, ws + l.small,
+                       ws + l.Sinv, l.ldq, info_dev);
+    GPMP_HIP_TRY(hipGetLastError());
+  }
+  rc = gpmp_coldots(Kit, n, m, l.ldm, Y, 1 + q, l.ldq, ws + l.D, l.ldm, ws + l.cd, stream);       // V^T [w, Wp] and colsumsq(V)
+  if (rc) return rc;
+  const size_t fin_bytes = sizeof(double) * ((size_t)q * q + q);
+  GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(predict_mean_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(double) * ((size_t)QMAX * QMAX + QMAX))));
+  hipLaunchKernelGGL(predict_mean_finalize_kernel, dim3((m + 255) / 256), dim3(256), fin_bytes, st, ws + l.D, l.ldm, Pt, ldpt, m, q,
+                     ws + l.Sinv, l.ldq, ws + l.small, sigma2, zero_neg_variances, info_dev, zpm_dev, zpv_dev);
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -256,6 +256,21 @@ int gpmp_loo(const double* x, const double* z, const double* P, long ldp, int n,
              const double* theta_host, int noise, double* ws, double* zloo_dev, double* sigma2loo_dev, double* eloo_dev,
              int* info_dev, gpmp_stream_t stream);
 
+/* Posterior mean and variance at m points with a LINEAR mean whose parameters are unknown (universal kriging):
+ * kriging_predictor (gpmp/core/kriging.py:69-167) + _compute_posterior_variance (kriging.py:170-199) + the clamp of
+ * Model.predict (gpmp/core/model.py:290-296), restated over the Schur complement S = P^T K^-1 P so
+ * that no (n + q) x (n + q) system is formed: one solve V = L^-1 K(xi, xt), W = L^-1 [zi, Pi], then per point
+ *   r = V^T Wp - pt,   zpm = V^T w - (S^-1 Wp^T w) . r,   zpv = sigma^2 - (colsumsq(V) - r^T S^-1 r).
+ * Pi: n x q (ldpi) and Pt: m x q (ldpt) are the mean design at the observation / prediction points, 1 <= q < GPMP_MAX_RANK
+ * (q = 0: gpmp_predict_zero_mean).  *info_dev as gpmp_reml (k in [1, n]: K not positive definite; n + k: the mean design is
+ * rank deficient to working precision); when it is non-zero both outputs are NaN.
+ * ws: gpmp_predict_mean_ws_elems(n, m, q) doubles.  Enqueue only. */
+size_t gpmp_predict_mean_ws_elems(int n, int m, int q);
+int gpmp_predict_mean(const double* xi, const double* zi, const double* Pi, long ldpi, const double* xt, const double* Pt,
+                      long ldpt, int n, int m, int d, int q, int p, const double* theta_host, int noise,
+                      int zero_neg_variances, double* ws, double* zpm_dev, double* zpv_dev, int* info_dev,
+                      gpmp_stream_t stream);
+
 /* ---- many small problems at once (mini-batch criteria, posterior samplers) ------------------------------------- */
 
 /* B independent criteria -- the zero-mean NLL (q = 0) or REML with a mean design of q <= 3 columns -- and, when

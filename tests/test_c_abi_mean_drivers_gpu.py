@@ -121,6 +121,61 @@ def test_loo_driver_vs_reference(env, golden, tag):
         assert rel_err(el, g[f"loo_{tag}_{mt}_eloo"]) < 1e-8, mt
 
 
+def _predict_mean_call(env, xi, zi, Pi, xt, Pt, theta, p, noise=0, clamp=1):
+    torch, gnp, _lib, lib = env
+    dev = gnp._dev()
+    n, d = xi.shape
+    m, q = xt.shape[0], Pi.shape[1]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)  # noqa: E731
+    XI, ZI, PI, XT, PT = t(xi), t(zi), t(Pi), t(xt), t(Pt)
+    ws = torch.empty(int(lib.gpmp_predict_mean_ws_elems(n, m, q)), dtype=torch.float64, device=dev)
+    zpm = torch.empty(m, dtype=torch.float64, device=dev)
+    zpv = torch.empty(m, dtype=torch.float64, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.gpmp_predict_mean(gnp._ptr(XI), gnp._ptr(ZI), gnp._ptr(PI), q, gnp._ptr(XT), gnp._ptr(PT), q, n, m, d, q, p,
+                                     _lib.host_vec(theta), noise, clamp, gnp._ptr(ws), gnp._ptr(zpm), gnp._ptr(zpv), gnp._ptr(info),
+                                     gnp._stream()), "gpmp_predict_mean")
+    return gnp.to_np(zpm), gnp.to_np(zpv), int(info.item())
+
+
+@pytest.mark.parametrize("tag", ["s", "m"])
+@pytest.mark.parametrize("mean", ["const", "lin"])
+def test_predict_mean_driver_vs_reference(env, golden, tag, mean):
+    """gpmp_predict_mean (universal kriging in one C call) against the reference's Model.predict with a constant and a
+    linear mean (gpmp/core/kriging.py:69-199, model.py:227-307; fixtures from the NumPy backend)"""
+    g = golden("predict")
+    xi, zi, xt = g[f"pred_{tag}_xi"], g[f"pred_{tag}_zi"], g[f"pred_{tag}_xt"]
+    theta, p = g[f"pred_{tag}_theta"], int(g[f"pred_{tag}_p"])
+    design = (lambda x: np.ones((x.shape[0], 1))) if mean == "const" else (lambda x: np.hstack((np.ones((x.shape[0], 1)), x)))
+    zpm, zpv, info = _predict_mean_call(env, xi, zi, design(xi), xt, design(xt), theta, p)
+    assert info == 0
+    assert np.max(np.abs(zpm - g[f"pred_{tag}_{mean}_zpm"])) < 1e-9 * np.max(np.abs(zi))
+    assert np.max(np.abs(zpv - np.maximum(g[f"pred_{tag}_{mean}_zpv"], 0.0))) < 1e-9 * math.exp(theta[0])
+
+
+def test_predict_mean_driver_blocked_size_and_failure_conventions(env):
+    """n above the diagonal-block / fused-leaf boundaries against the Python predictor; a duplicated mean column reports
+    n + k through info and fills the outputs with NaN"""
+    import gpmp_amd as gp
+    import gpmp_amd.num as gnp
+
+    rng = np.random.default_rng(31)
+    n, m, d, p = 1500, 700, 3, 2
+    xi, xt = rng.random((n, d)), rng.random((m, d))
+    zi = np.sin(4 * xi[:, 0]) + xi.sum(axis=1) + 0.5
+    theta = np.array([0.3, 1.2, 0.8, 1.6])
+    lin = lambda x: np.hstack((np.ones((x.shape[0], 1)), x))  # noqa: E731
+    zpm, zpv, info = _predict_mean_call(env, xi, zi, lin(xi), xt, lin(xt), theta, p)
+    model = gp.Model(lambda x, prm: gnp.hstack((gnp.ones((x.shape[0], 1)), gnp.asarray(x))), gp.kernel.MaternCovariance(p), None, theta)
+    rm, rv = model.predict(xi, zi, xt)
+    assert info == 0
+    assert np.max(np.abs(zpm - rm)) < 1e-9 * np.max(np.abs(zi)) and np.max(np.abs(zpv - rv)) < 1e-9 * math.exp(theta[0])
+    Pd = np.hstack((lin(xi), xi[:, :1]))           # last column duplicates column 1
+    Ptd = np.hstack((lin(xt), xt[:, :1]))
+    zpm, zpv, info = _predict_mean_call(env, xi, zi, Pd, xt, Ptd, theta, p)
+    assert info > n and np.isnan(zpm).all() and np.isnan(zpv).all()
+
+
 def test_mean_drivers_at_blocked_sizes_vs_python_path(env):
     """n beyond one diagonal block / one panel (ragged), q = 0, 1 and d + 1, against the Python layer's own route"""
     torch, gnp, _lib, lib = env
