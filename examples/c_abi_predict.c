@@ -74,5 +74,15 @@ int main(int argc, char** argv) {
   double hz[3], hs[3];
   CK(hipMemcpy(hz, zl, sizeof(double) * 3, hipMemcpyDeviceToHost)); CK(hipMemcpy(hs, s2, sizeof(double) * 3, hipMemcpyDeviceToHost));
   for (int i = 0; i < 3; ++i) printf("loo[%d]: zloo %.12e  s2loo %.6e\n", i, hz[i], hs[i]);
+
+  /* prediction with that constant mean of unknown level (universal kriging): the mean design at the prediction points too */
+  double *Pt = malloc(sizeof(double) * m), *dPt, *ws3;
+  for (int i = 0; i < m; ++i) Pt[i] = 1.0;
+  CK(hipMalloc((void**)&dPt, sizeof(double) * m)); CK(hipMemcpy(dPt, Pt, sizeof(double) * m, hipMemcpyHostToDevice));
+  CK(hipMalloc((void**)&ws3, sizeof(double) * gpmp_predict_mean_ws_elems(n, m, q)));
+  GK(gpmp_predict_mean(dxi, dzi, dP, 1, dxt, dPt, 1, n, m, d, q, p, theta, 0, 1, ws3, zpm, zpv, info, NULL));
+  CK(hipMemcpy(hm, zpm, sizeof(double) * k, hipMemcpyDeviceToHost)); CK(hipMemcpy(hv, zpv, sizeof(double) * k, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost));
+  for (int i = 0; i < k; ++i) printf("uk[%d]: ukm %.12e  ukv %.6e\n", i, hm[i], hv[i]);
   return hinfo != 0;
 }

@@ -524,6 +524,10 @@ def test_c_host_example_matches_python_path(gp, gnp):
     s2_c = [float(v_) for v_ in re.findall(r"s2loo ([-+0-9.eE]+)", out)]
     np.testing.assert_allclose(zloo_c, gnp.to_np(zl)[:3], rtol=1e-9)
     np.testing.assert_allclose(s2_c, gnp.to_np(sl)[:3], rtol=1e-5)
+    # ... and the universal-kriging prediction with that mean
+    um, uv = mc.predict(xi, zi, xt)
+    np.testing.assert_allclose([float(v_) for v_ in re.findall(r"ukm ([-+0-9.eE]+)", out)], um[:4], rtol=0, atol=1e-9)
+    np.testing.assert_allclose([float(v_) for v_ in re.findall(r"ukv ([-+0-9.eE]+)", out)], uv[:4], rtol=1e-5, atol=1e-12)
 
 
 def test_c_abi_nll_driver_reports_failure_as_inf(gnp):
