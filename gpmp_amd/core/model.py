@@ -52,9 +52,14 @@ class Model:
     def predict(self, xi, zi, xt, return_lambdas=False, zero_neg_variances=True, convert_in=True, convert_out=True):
         """Posterior mean and variance at xt given (xi, zi) -- gpmp/core/model.py:227-307."""
         xi, zi, xt = utils.ensure_shapes_and_type(xi=xi, zi=zi, xt=xt, convert=convert_in)
-        zi_centered, zt_prior_mean, lambda_t, zt_posterior_variance, zt_kriging_mean = kriging.select_predictor(
-            self, xi, zi, xt, return_lambdas=return_lambdas
-        )
+        fused = None if return_lambdas else kriging.fused_prediction(self, xi, zi, xt)
+        if fused is not None:
+            lambda_t = None
+            zt_kriging_mean, zt_posterior_variance, zt_prior_mean = fused
+        else:
+            zi_centered, zt_prior_mean, lambda_t, zt_posterior_variance, zt_kriging_mean = kriging.select_predictor(
+                self, xi, zi, xt, return_lambdas=return_lambdas
+            )
         if bool(gnp.any(zt_posterior_variance < 0.0)):
             warnings.warn("Negative variances detected. Consider using jitter.", RuntimeWarning)
         if zero_neg_variances:

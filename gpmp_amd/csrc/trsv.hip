@@ -414,8 +414,8 @@ int run(const double* L, int n, long ldl, const double* dinv, double* B, int m, 
 
 // In-place op(L)^-1 B for an n x m B with m <= TRSV_FEW_MAX (16): the single right-hand sides of the likelihood, and
 // L^-1 [z, P] / L^-T (.) of the mean-space algebra with up to 15 mean columns (a linear mean in d = 8 has 9).  The sweep
-// reads L once whatever the number of columns; through the 128 x 128 MFMA tiles of the many-column solve, 10 columns cost
-// as much as 128 (predict with a linear mean at n = 4096 / m = 10000: 9.3 -> 7.x ms).
+// reads L once per pass of up to 8 columns; through the 128 x 128 MFMA tiles of the many-column solve, 10 columns cost as much
+// as 128 (predict with a linear mean at n = 4096 / m = 10000: 9.3 -> 6.8 ms).
 int trsv_few(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int trans,
              hipStream_t st) {
   // one persistent launch from a few blocks up (GPMP_TRSV_PERSIST=0: the launch-per-block chain)
@@ -423,18 +423,24 @@ int trsv_few(const double* L, int n, long ldl, const double* dinv, double* B, in
   const int persist = pe ? atoi(pe) : 1;
   const int nblk = (n + NB - 1) / NB;
   if (m > TRSV_FEW_MAX) { set_error("trsv_few: %d right-hand sides (at most %d)", m, TRSV_FEW_MAX); return -1; }
+  // more than 8 columns: passes of 8 (and a last one of 1 / 2 / 4 / 8).  Each pass reads L again, but the sweep's inner loop
+  // is LDS-bound beyond 8 columns (every fma fetches its x entry from LDS): measured at n = 4096 / 16384, forward:
+  // 4 columns 0.21 / 0.93 ms, 8 columns 0.36 / 1.46 ms, a 16-column instantiation 0.96 / 3.9 ms.
+  if (m > 8) {
+    int rc = trsv_few(L, n, ldl, dinv, B, 8, ldb, trans, st);
+    if (rc) return rc;
+    return trsv_few(L, n, ldl, dinv, B + 8, m - 8, ldb, trans, st);
+  }
   if (persist && nblk >= 3 && nblk <= TRSV_MAXBLK) {
     if (m <= 1) return run_persist<1>(L, n, ldl, dinv, B, m, ldb, trans, st);
     if (m <= 2) return run_persist<2>(L, n, ldl, dinv, B, m, ldb, trans, st);
     if (m <= 4) return run_persist<4>(L, n, ldl, dinv, B, m, ldb, trans, st);
-    if (m <= 8) return run_persist<8>(L, n, ldl, dinv, B, m, ldb, trans, st);
-    return run_persist<16>(L, n, ldl, dinv, B, m, ldb, trans, st);
+    return run_persist<8>(L, n, ldl, dinv, B, m, ldb, trans, st);
   }
   if (m <= 1) return run<1>(L, n, ldl, dinv, B, m, ldb, trans, st);
   if (m <= 2) return run<2>(L, n, ldl, dinv, B, m, ldb, trans, st);
   if (m <= 4) return run<4>(L, n, ldl, dinv, B, m, ldb, trans, st);
-  if (m <= 8) return run<8>(L, n, ldl, dinv, B, m, ldb, trans, st);
-  return run<16>(L, n, ldl, dinv, B, m, ldb, trans, st);
+  return run<8>(L, n, ldl, dinv, B, m, ldb, trans, st);
 }
 
 // Number of single-vector solves on `stream` that gave up since the last call (0 in any healthy run); synchronises the

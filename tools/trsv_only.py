@@ -12,7 +12,7 @@ for n in [int(a) for a in sys.argv[1:]] or [32768, 16384, 4096, 5000]:
     K = MaternCovariance(2).gram_lower(xi, theta)
     torch.diagonal(K).add_(1e-4)
     F = gnp.cholesky_factor(K, overwrite=True)
-    for R in (1, 2, 4):
+    for R in (1, 4, 8, 10, 16):
         B = gnp.asarray(rng.standard_normal((n, R)) if R > 1 else rng.standard_normal(n))
         out = {}
         for mode in ("0", "1"):
