@@ -301,7 +301,7 @@ def fused_prediction(model, xi, zi, xt):
     cov = model.covariance
     if os.environ.get("GPMP_PREDICT_FUSED", "1") == "0" or not isinstance(cov, MaternCovariance):
         return None
-    if model.meantype not in ("zero", "parameterized", "linear_predictor"):
+    if model.meantype not in ("zero", "parameterized", "linear_predictor") or model.covparam is None:
         return None
     if not (isinstance(xi, torch.Tensor) and isinstance(xt, torch.Tensor)) or xt is xi:     # (xt is xi: the reference's identity
         return None                                                                        #  dispatch puts the nugget on K(xi, xt))
