@@ -156,3 +156,34 @@ def test_config4_inverse_trace_identity_n16384_d20(gp):
     e = gnp.to_np(gnp.matmul(row, K))
     e[r] -= 1.0
     assert np.max(np.abs(e)) < 1e-6
+
+
+@pytest.mark.parametrize("n", [9347, 12800, 20000])
+def test_cholesky_residual_between_the_stated_sizes(n):
+    """Sizes that mix every regime of the look-ahead factorisation in one run -- 1024-column panels with their look-ahead update
+    cut in pieces (more than 8192 rows left), the 512 / 256-column tail, a ragged last block (9347 = 73 * 128 + 3) -- checked
+    through the residual of sampled rows, || (L L^T - K)[rows] || / || K ||, and one solve against that residual's scale."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gpmp_amd as gp
+    import gpmp_amd.num as gnp
+
+    d = 6
+    rng = np.random.default_rng(n)
+    xi = gnp.asarray(rng.random((n, d)))
+    th = np.concatenate(([0.2], -np.log(0.4 * (1.0 + np.arange(d) / d))))
+    cov = gp.kernel.MaternCovariance(2)
+    K = cov(xi, None, th)
+    F = gnp.cholesky_factor(K.clone())
+    L = F.L
+    rows = torch.as_tensor(np.sort(rng.choice(n, 384, replace=False)), device=L.device)
+    cols = torch.arange(n, device=L.device)
+    Lr = torch.where(cols[None, :] <= rows[:, None], L[rows], torch.zeros((), dtype=L.dtype, device=L.device))
+    R = gnp.matmul(Lr, torch.tril(L).T.contiguous()) - K[rows]
+    assert float(R.abs().max()) / float(K.abs().max()) < 5e-13
+    b = gnp.asarray(rng.standard_normal(n))
+    x = F.solve(b)
+    r = gnp.matmul(K, x.reshape(-1, 1)).reshape(-1) - b
+    assert float(r.abs().max()) < 1e-7 * float(b.abs().max())
