@@ -176,6 +176,31 @@ def test_predict_mean_driver_blocked_size_and_failure_conventions(env):
     assert info > n and np.isnan(zpm).all() and np.isnan(zpv).all()
 
 
+@pytest.mark.parametrize("noise", [0, 1])
+def test_predict_mean_driver_more_than_eight_columns_and_noise(env, noise, monkeypatch):
+    """q = 10 mean columns (a linear mean in d = 9: [z, P] is 11 columns, two passes of the few-column sweep) and the noisy
+    kernel, against the general array-level route of Model.predict (the fused route switched off)"""
+    import gpmp_amd as gp
+    import gpmp_amd.num as gnp
+
+    rng = np.random.default_rng(77 + noise)
+    n, m, d, p = 700, 333, 9, 1
+    xi, xt = rng.random((n, d)), rng.random((m, d))
+    zi = np.cos(3 * xi[:, 0]) + xi @ np.linspace(0.5, 1.5, d) + 0.05 * rng.standard_normal(n)
+    theta = np.concatenate(([0.1], [-3.0] if noise else [], -np.log(0.7 * np.ones(d))))
+    lin = lambda x: np.hstack((np.ones((x.shape[0], 1)), x))  # noqa: E731
+    zpm, zpv, info = _predict_mean_call(env, xi, zi, lin(xi), xt, lin(xt), theta, p, noise=noise)
+    assert info == 0
+    monkeypatch.setenv("GPMP_PREDICT_FUSED", "0")
+    model = gp.Model(lambda x, prm: gnp.hstack((gnp.ones((x.shape[0], 1)), gnp.asarray(x))), gp.kernel.MaternCovariance(p, noise=bool(noise)),
+                     None, theta)
+    rm, rv = model.predict(xi, zi, xt)
+    assert np.max(np.abs(zpm - rm)) < 1e-9 * np.max(np.abs(zi)) and np.max(np.abs(zpv - rv)) < 1e-9 * math.exp(theta[0])
+    monkeypatch.setenv("GPMP_PREDICT_FUSED", "1")
+    fm, fv = model.predict(xi, zi, xt)                  # and the fused route of Model.predict itself
+    assert np.max(np.abs(fm - rm)) < 1e-9 * np.max(np.abs(zi)) and np.max(np.abs(fv - rv)) < 1e-9 * math.exp(theta[0])
+
+
 def test_mean_drivers_at_blocked_sizes_vs_python_path(env):
     """n beyond one diagonal block / one panel (ragged), q = 0, 1 and d + 1, against the Python layer's own route"""
     torch, gnp, _lib, lib = env
