@@ -1,0 +1,152 @@
+"""Seeded random sweep over the model-level surface of the path: ragged shapes, every regularity p the kernels know, the
+three mean types, with and without a noise parameter -- predict, NLL / REML, leave-one-out and the analytic gradient, each
+against the oracle on the same inputs.  Tolerances scale with cond(K) * eps, the condition number taken from
+the oracle's own K.
+
+Reference behaviour: gpmp/core/model.py:227-343, core/likelihood.py:18-129, core/loo.py:21-130, kernel/matern.py:32-141,
+num/torch_backend.py:547-604 (gradient of the criterion)."""
+import math
+
+import numpy as np
+import pytest
+
+from tests.helpers import constant_mean, linear_mean, param_mean
+
+pytestmark = pytest.mark.gpu
+
+EPS = np.finfo(np.float64).eps
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gpmp_amd
+
+    return gpmp_amd
+
+
+@pytest.fixture(scope="module")
+def gnp(gp):
+    import gpmp_amd.num as gnp
+
+    return gnp
+
+
+def _dev_constant_mean(x, param):
+    import gpmp_amd.num as gnp
+
+    return gnp.ones((x.shape[0], 1))
+
+
+def _dev_linear_mean(x, param):
+    import gpmp_amd.num as gnp
+
+    return gnp.hstack((gnp.ones((x.shape[0], 1)), gnp.asarray(x)))
+
+
+def _cases():
+    rng = np.random.default_rng(20260403)
+    shapes = [(1, 1, 1), (2, 1, 1), (3, 7, 2), (17, 1, 3), (127, 33, 1), (128, 128, 2), (129, 5, 9), (255, 301, 4), (384, 2, 6),
+              (513, 77, 3), (640, 129, 8), (700, 255, 2)]
+    out = []
+    for i in range(36):
+        n, m, d = shapes[i % len(shapes)]
+        if i >= len(shapes):        # later passes: perturb the shapes
+            n = int(max(1, n + rng.integers(-3, 4)))
+            m = int(max(1, m + rng.integers(-2, 3)))
+        p = int(rng.integers(0, 5)) if i % 3 else 2
+        meantype = ("zero", "const", "linear", "param")[int(rng.integers(0, 4))]
+        if meantype == "linear" and n <= d + 1:
+            meantype = "const"
+        if meantype == "const" and n < 2:
+            meantype = "zero"
+        noise = bool(rng.integers(0, 2))
+        out.append((i, n, m, d, p, meantype, noise))
+    return out
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-n{c[1]}m{c[2]}d{c[3]}p{c[4]}-{c[5]}{'-noise' if c[6] else ''}" for c in CASES])
+def test_model_surface_against_oracle(gp, gnp, case):
+    from oracle import gp_oracle as orc
+    from gpmp_amd.core.gradients import MLZeroMeanAnalytic, REMLAnalytic
+
+    i, n, m, d, p, meantype, noise = case
+    rng = np.random.default_rng(1000 + i)
+    xi, xt = rng.random((n, d)), rng.random((m, d))
+    zi = np.sin(2 * np.pi * xi[:, 0]) + xi[:, 1:].sum(axis=1) + 0.05 * rng.standard_normal(n)
+    rho = 0.25 + 0.5 * rng.random(d)
+    s2 = math.exp(rng.uniform(-1.0, 1.0))
+    th = np.concatenate(([math.log(s2)], [math.log(s2) - rng.uniform(4.0, 9.0)] if noise else [], -np.log(rho)))
+    mean = {"zero": None, "const": constant_mean, "linear": linear_mean, "param": param_mean}[meantype]
+    mtype = {"zero": "zero", "const": "linear_predictor", "linear": "linear_predictor", "param": "parameterized"}[meantype]
+    mparam = np.array([0.3, -0.7]) if meantype == "param" else None
+
+    ocov = (lambda x, y, c, pairwise=False: orc.noisy_maternp_covariance(x, y, p, c, pairwise)) if noise else \
+           (lambda x, y, c, pairwise=False: orc.maternp_covariance(x, y, p, c, pairwise))
+    om = orc.OracleModel(mean, ocov, mparam, th, mtype)
+    dmean = {"zero": None, "const": _dev_constant_mean, "linear": _dev_linear_mean, "param": param_mean}[meantype]
+    model = gp.Model(dmean, gp.kernel.MaternCovariance(p, noise=noise), mparam, th, mtype)
+
+    K = ocov(xi, xi, th)
+    cond = float(np.linalg.cond(K))
+    tol = max(1e-11, 200.0 * cond * EPS)
+    if tol > 1e-3:
+        pytest.skip(f"cond(K) = {cond:.1e}: nothing to compare at fp64")
+    zs = max(1.0, float(np.abs(zi).max()))
+
+    # ---- predict: mean, variance (clamped like model.py:290-296)
+    rm, rv = orc.predict(om, xi, zi, xt)[:2]
+    zpm, zpv = model.predict(xi, zi, xt)
+    assert zpm.shape == (m,) and zpv.shape == (m,)
+    np.testing.assert_allclose(zpm, rm, rtol=0, atol=tol * zs)
+    np.testing.assert_allclose(zpv, rv, rtol=0, atol=tol * s2 * (1.0 + (mtype == "linear_predictor") * 10.0))
+    # ... and with the weights asked for (the general route)
+    zpm2, zpv2, lam = model.predict(xi, zi, xt, return_lambdas=True)
+    np.testing.assert_allclose(zpm2, rm, rtol=0, atol=tol * zs)
+    np.testing.assert_allclose(zpv2, rv, rtol=0, atol=tol * s2 * (1.0 + (mtype == "linear_predictor") * 10.0))
+    assert lam.shape == (n, m)
+
+    # ---- likelihood criteria
+    if mtype == "zero":
+        ref = float(orc.negative_log_likelihood_zero_mean(om, th, xi, zi))
+        got = float(model.negative_log_likelihood_zero_mean(th, xi, zi))
+    elif mtype == "parameterized":
+        ref = float(orc.negative_log_likelihood(om, mparam, th, xi, zi))
+        got = float(model.negative_log_likelihood(mparam, th, xi, zi))
+    else:
+        ref = float(orc.negative_log_restricted_likelihood(om, th, xi, zi))
+        got = float(model.negative_log_restricted_likelihood(th, xi, zi))
+    assert abs(got - ref) <= tol * max(1.0, abs(ref), float(n))
+
+    # ---- leave-one-out
+    if n >= 2 + (d + 1 if meantype == "linear" else 1):
+        zl_r, s2_r, el_r = orc.loo(om, xi, zi)
+        zl, s2l, el = (gnp.to_np(a).reshape(-1) for a in model.loo(xi, zi))
+        np.testing.assert_allclose(el, el_r, rtol=0, atol=tol * 20 * max(1.0, float(np.abs(el_r).max())))
+        np.testing.assert_allclose(s2l, s2_r, rtol=tol * 20, atol=tol * s2)
+        np.testing.assert_allclose(zl, zl_r, rtol=0, atol=tol * 20 * max(1.0, float(np.abs(el_r).max()), zs))
+
+    # ---- analytic gradient of the criterion (p = 0: |h| has a kink at 0, the reference differentiates it by autograd only)
+    if p == 0:
+        return
+    nidx = 1 if noise else None
+    if mtype == "zero":
+        v_r, g_r = orc.nll_zero_mean_value_and_grad(xi, zi, p, th, nidx)
+        crit = MLZeroMeanAnalytic(model)
+    elif mtype == "parameterized":
+        v_r, g_r = orc.nll_zero_mean_value_and_grad(xi, zi - param_mean(xi, mparam).reshape(-1), p, th, nidx)
+        crit = MLZeroMeanAnalytic(model, mean_offset=lambda x: param_mean(x, mparam).reshape(-1))
+    else:
+        v_r, g_r = orc.reml_value_and_grad(xi, zi, mean(xi, None), p, th, nidx)
+        crit = REMLAnalytic(model)
+    v, st = crit.value_and_state(th, gnp.asarray(xi), gnp.asarray(zi))
+    g = np.asarray(gnp.to_np(crit.gradient_from_state(st))).reshape(-1)
+    assert abs(float(v) - v_r) <= tol * max(1.0, abs(v_r), float(n))
+    gs = max(1.0, float(np.abs(g_r).max()))
+    np.testing.assert_allclose(g, g_r, rtol=0, atol=max(1e-8, 1e3 * tol) * gs)
