@@ -818,11 +818,14 @@ __global__ void __launch_bounds__(256) build_leaf_g_kernel(LeafGParams p) {
 // used, so one load latency is exposed per launch.  Edge tiles and lower-only products are predicated.
 constexpr int SBM = 32, SBN = 128, SLD = 18;   // tile shape, padded row stride of a [rows][16] operand image
 
+// SBMT = 16: half-height tiles for launches of fewer than ~one workgroup per compute unit (twice the workgroups, half the
+// MFMA time of each: the chain-bound tail of the Cholesky)
+template <int SBMT>
 __global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) double sA[2][SBM * SLD];
+  __shared__ __attribute__((aligned(16))) double sA[2][SBMT * SLD];
   __shared__ __attribute__((aligned(16))) double sB[2][SBN * SLD];
-  const int row0 = blockIdx.y * SBM, col0 = blockIdx.x * SBN;
-  if (p.lower_only && col0 > row0 + SBM - 1) return;
+  const int row0 = blockIdx.y * SBMT, col0 = blockIdx.x * SBN;
+  if (p.lower_only && col0 > row0 + SBMT - 1) return;
   // these kernels carry the panel chain of the Cholesky: their waves go first where they share a SIMD with the trailing
   // update's (whose 64-cycle MFMAs otherwise take turns with them one for one)
   if (p.prio) __builtin_amdgcn_s_setprio(3);
@@ -832,7 +835,7 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmParams p) {
   const int lr = lane & 15, lk = lane >> 4;
   // staging: thread t owns k quad (t & 3) of row (t >> 2) of A (t < 128) and of rows (t >> 2), (t >> 2) + 64 of B
   const int srow = t >> 2, skq = (t & 3) * 4;
-  const bool has_a = t < 4 * SBM;
+  const bool has_a = t < 4 * SBMT;
   int ar = row0 + (has_a ? srow : 0), br0 = col0 + srow, br1 = col0 + srow + 64;
   ar = ar < p.M ? ar : p.M - 1;     // clamped rows only feed outputs that are never stored
   br0 = br0 < p.N ? br0 : p.N - 1;
@@ -841,9 +844,10 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmParams p) {
   const double* __restrict__ bp0 = p.B + (long)br0 * p.ldb + skq;
   const double* __restrict__ bp1 = p.B + (long)br1 * p.ldb + skq;
 
-  d4 acc[2][2];
+  constexpr int MI = SBMT / 16;
+  d4 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
@@ -880,13 +884,13 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmParams p) {
         __syncthreads();   // image q complete; image q-1 (other buffer) was released by the previous barrier
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          double fa[2], fb[2];
+          double fa[MI], fb[2];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) fa[i] = sA[buf][(16 * i + lr) * SLD + 4 * ks + lk];
+          for (int i = 0; i < MI; ++i) fa[i] = sA[buf][(16 * i + lr) * SLD + 4 * ks + lk];
 #pragma unroll
           for (int j = 0; j < 2; ++j) fb[j] = sB[buf][(wn + 16 * j + lr) * SLD + 4 * ks + lk];
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
@@ -897,7 +901,7 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmParams p) {
 
   const double alpha = p.alpha, beta = p.beta;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = row0 + 16 * i + 4 * r + lk;
@@ -1051,7 +1055,14 @@ int launch_t(const GemmParams& p, hipStream_t st) {
     ProfScope ps((AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN)) + ((v2ok && !small_nt) ? 8 : 0), st,
                  2.0 * (double)p.ntiles * BM * BN * kavg * p.batch * p.batch2);
     if (lean_nt) hipLaunchKernelGGL(gemm_nt_lean_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
-    else if (small_nt) hipLaunchKernelGGL(gemm_nt_small_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
+    else if (small_nt) {
+      // fewer 32-row tiles than ~compute units: 16-row tiles (read at every call: tests exercise both heights)
+      const char* h16 = getenv("GPMP_GEMM_SMALL_ROWS16_BELOW");
+      const long below16 = h16 ? atol(h16) : 160;
+      const long wg32 = (long)((p.N + SBN - 1) / SBN) * ((p.M + SBM - 1) / SBM);
+      if (wg32 < below16) hipLaunchKernelGGL(gemm_nt_small_kernel<16>, dim3((p.N + SBN - 1) / SBN, (p.M + 15) / 16), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL(gemm_nt_small_kernel<SBM>, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
+    }
     else if (v2ok) hipLaunchKernelGGL((gemm_f64_kernel_v2<AKC, BKC, CACC>), dim3(p.ntiles, p.batch, p.batch2), dim3(256), lds2, st, p);
     else hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC, CACC>), dim3(p.ntiles, p.batch, p.batch2), dim3(256), lds, st, p);
   }

@@ -320,10 +320,16 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   static int w256_below = -1, w128_below = -1;
   if (w256_below < 0) { const char* e = getenv("GPMP_POTRF_W256_BELOW"); w256_below = e ? atoi(e) : 4096; }
   if (w128_below < 0) { const char* e = getenv("GPMP_POTRF_W128_BELOW"); w128_below = e ? atoi(e) : 0; }
+  // (option, off: the last columns as ONE panel -- its look-ahead update is then the whole trailing update and the panel is
+  //  the blocked factorisation of what is left, all on the chain stream.  On its own the blocked route wins up to 2048
+  //  columns (potrf_lower), as the tail of this one it changes nothing: n = 4096: 2.19 vs 2.20 ms, 8192: 6.75 vs 6.75.)
+  const char* tbe = getenv("GPMP_POTRF_TAIL_BLOCKED_BELOW");   // (read at every call)
+  const int tail_blocked = (sa != nullptr && sa->every_panel) ? 0 : (tbe ? atoi(tbe) : 0);
   std::vector<int> pb;
   for (int p = 0; p < n;) {
     pb.push_back(p);
     const int rest = n - p;
+    if (p > 0 && rest <= tail_blocked) break;
     p += rest > wide_thresh ? 2 * OUTER_BLOCKS * NB : (rest <= w128_below ? NB : (rest <= w256_below ? 2 * NB : OUTER_BLOCKS * NB));
   }
   pb.push_back(n);
@@ -512,9 +518,17 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   return 0;
 }
 
+// One stream, no look-ahead, up to 2048 columns: nothing runs beside the chain's kernels there, and the look-ahead's second
+// stream only adds event packets and a trailing update that slows the chain (measured in one process, both routes:
+// n = 1536: 0.69 vs 0.77 ms, 2048: 0.96 vs 1.01, 3072: 1.68 vs 1.57, 4096: 2.47 vs 2.17).
+inline int potrf_one_stream_max() {
+  const char* be = getenv("GPMP_POTRF_BLOCKED_BELOW");   // (read at every call: tests exercise both routes)
+  return be ? atoi(be) : 4 * OUTER_BLOCKS * NB;
+}
+
 int potrf_lower(double* A, int n, long lda, double* dinv, int* info_dev, hipStream_t st) {
   GPMP_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
-  if (n <= 2 * OUTER_BLOCKS * NB) return potrf_blocked(A, n, lda, dinv, info_dev, 0, st);
+  if (n <= potrf_one_stream_max()) return potrf_blocked(A, n, lda, dinv, info_dev, 0, st);
   return potrf_lookahead(A, n, lda, dinv, info_dev, st);
 }
 
@@ -662,13 +676,15 @@ extern "C" int gpmp_potrf_trsm_lower_async(double* A, int n, long lda, double* d
   // n = 4096), so the rows of every panel are solved behind that panel's factorisation on a third stream.
   const char* al = getenv("GPMP_POTRF_SOLVE_ALONG_BELOW");
   const int along_below = al ? atoi(al) : 8192;
-  if (m > TRSV_FEW_MAX && n > 2 * OUTER_BLOCKS * NB && n <= along_below) {
+  const char* aa = getenv("GPMP_POTRF_SOLVE_ALONG_ABOVE");
+  const int along_above = aa ? atoi(aa) : 2 * OUTER_BLOCKS * NB;
+  if (m > TRSV_FEW_MAX && n > along_above && n <= along_below) {
     SolveAlong sa;
     sa.B = B; sa.m = m; sa.ldb = ldb; sa.gws = gws; sa.every_panel = 1;
     return potrf_lookahead(A, n, lda, dinv, info_dev, st, &sa);
   }
   if (!overlap || m <= TRSV_FEW_MAX || n <= 8 * OUTER_BLOCKS * NB) {
-    int rc = (n <= 2 * OUTER_BLOCKS * NB) ? potrf_blocked(A, n, lda, dinv, info_dev, 0, st) : potrf_lookahead(A, n, lda, dinv, info_dev, st);
+    int rc = (n <= potrf_one_stream_max()) ? potrf_blocked(A, n, lda, dinv, info_dev, 0, st) : potrf_lookahead(A, n, lda, dinv, info_dev, st);
     if (rc || m == 0) return rc;
     if (m <= TRSV_FEW_MAX) return trsv_few(A, n, lda, dinv, B, m, ldb, 0, st);
     return trsm_forward(A, n, lda, dinv, B, m, ldb, 0, 0, gws, st);

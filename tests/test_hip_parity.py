@@ -139,6 +139,43 @@ def test_dgemm_lean_kernel(gnp, M, N, K, lower):
         assert rel_err(got, ref) < 1e-13
 
 
+@pytest.mark.parametrize("rows16", ["0", "100000"])
+@pytest.mark.parametrize("M,N,K,lower,inplace", [(900, 128, 128, 0, 1), (50, 128, 128, 0, 1), (333, 384, 128, 1, 0), (1000, 256, 256, 1, 0),
+                                                  (17, 70, 48, 0, 0), (640, 640, 512, 1, 0)])
+def test_dgemm_latency_kernel_tile_heights(gnp, M, N, K, lower, inplace, rows16):
+    """the latency NT kernel of the panel chain with 32-row and with 16-row tiles (GPMP_GEMM_SMALL_ROWS16_BELOW, read at every
+    call): plain, lower-only tile skip, and the in-place panel scaling C == A with N == K == 128"""
+    import os
+    from gpmp_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(M + 7 * N + K)
+    A, B, C0 = rng.standard_normal((M, K)), rng.standard_normal((N, K)), rng.standard_normal((M, N))
+    At, Bt, Ct = (gnp.as_matrix(gnp.asarray(a), copy=True) for a in (A, B, C0))
+    os.environ["GPMP_GEMM_SMALL_ROWS16_BELOW"] = rows16
+    try:
+        if inplace:
+            _lib.check(lib.gpmp_dgemm(0, 1, M, N, K, 1.0, gnp._ptr(At), gnp._ld(At), gnp._ptr(Bt), gnp._ld(Bt), 0.0, gnp._ptr(At), gnp._ld(At),
+                                      0, gnp._stream()), "gpmp_dgemm")
+            assert rel_err(gnp.to_np(At), A @ B.T) < 1e-13
+            return
+        _lib.check(lib.gpmp_dgemm(0, 1, M, N, K, -1.5, gnp._ptr(At), gnp._ld(At), gnp._ptr(Bt), gnp._ld(Bt), 0.5, gnp._ptr(Ct), gnp._ld(Ct),
+                                  lower, gnp._stream()), "gpmp_dgemm")
+    finally:
+        os.environ.pop("GPMP_GEMM_SMALL_ROWS16_BELOW", None)
+    got, ref = gnp.to_np(Ct), -1.5 * A @ B.T + 0.5 * C0
+    if lower:
+        h = 16 if rows16 != "0" else 32
+        needed = (np.arange(N)[None, :] // 128) <= (np.arange(M)[:, None] // 128)                       # 128-tiles on / below the diagonal
+        skipped = (np.arange(N)[None, :] // 128) * 128 > (np.arange(M)[:, None] // h) * h + h - 1       # what this tile height skips
+        assert rel_err(got[needed], ref[needed]) < 1e-13
+        assert not (needed & skipped).any()
+        assert np.array_equal(got[skipped], C0[skipped])                                                 # untouched
+        assert rel_err(got[~skipped], ref[~skipped]) < 1e-13
+    else:
+        assert rel_err(got, ref) < 1e-13
+
+
 @pytest.mark.parametrize("M,K", [(700, 1024), (260, 384), (130, 130)])
 def test_dgemm_upper_triangular_right_operand(gnp, M, K):
     """flag bit 2: C = A T^T with T lower triangular (the k loop of a tile column stops at the diagonal); the strict upper
@@ -277,12 +314,15 @@ def test_factor_and_solve_in_one_call(gnp, n, m):
             for k_ in env:
                 os.environ.pop(k_, None)
         L1 = np.tril(gnp.to_np(F1.L))
-        assert np.array_equal(L0, L1)                  # same kernels, same order: bit-identical factor
+        if n > 2048 or env:
+            assert np.array_equal(L0, L1)              # same kernels, same order: bit-identical factor
+        else:                                          # up to 2048 columns the factorisation alone takes the one-stream route,
+            assert rel_err(L1, L0) < 1e-12             # the factor-and-solve call the look-ahead one (panel-by-panel solve)
         assert rel_err(gnp.to_np(V1), V0) < 1e-12
         assert rel_err(L1 @ gnp.to_np(V1), B) < 1e-9
     # the factor object returned by the fused call serves further solves
     z = rng.standard_normal(n)
-    np.testing.assert_allclose(gnp.to_np(F1.solve(gnp.asarray(z))), gnp.to_np(F0.solve(gnp.asarray(z))), rtol=1e-10, atol=1e-12)
+    assert rel_err(gnp.to_np(F1.solve(gnp.asarray(z))), gnp.to_np(F0.solve(gnp.asarray(z)))) < 1e-10     # (cond(K) ~ 1e6)
 
 
 @pytest.mark.parametrize("n", [100, 129, 300, 1000, 1500, 2049, 3333, 5000])
@@ -625,6 +665,28 @@ def test_cholesky_and_solves_vs_lapack(gp, gnp, n):
     assert rel_err(Ki, np.linalg.inv(K)) < 1e-7
     F = gnp.cholesky_factor(gnp.asarray(K))
     assert abs(F.logdet() - np.linalg.slogdet(K)[1]) < 1e-9 * max(1.0, abs(np.linalg.slogdet(K)[1]))
+
+
+@pytest.mark.parametrize("n", [1100, 1537, 2048, 2300])
+def test_cholesky_one_stream_and_lookahead_routes_agree(gnp, n):
+    """potrf_lower takes the one-stream blocked route up to 2048 columns and the look-ahead route above
+    (GPMP_POTRF_BLOCKED_BELOW, read at every call): both must give the LAPACK factor, on either side of the switch"""
+    import os
+    from oracle import gp_oracle as orc
+
+    x, _ = make_xz(n, 3, n)
+    K = orc.maternp_covariance(x, None, 2, theta_aniso(3, scale=0.4)) + 1e-6 * np.eye(n)
+    Lref = np.linalg.cholesky(K)
+    got = {}
+    for route, below in (("one_stream", "4096"), ("lookahead", "1024")):
+        os.environ["GPMP_POTRF_BLOCKED_BELOW"] = below
+        try:
+            got[route] = np.tril(gnp.to_np(gnp.cholesky_factor(gnp.asarray(K)).L))
+        finally:
+            os.environ.pop("GPMP_POTRF_BLOCKED_BELOW", None)
+        assert rel_err(got[route], Lref) < 1e-10
+        assert rel_err(got[route] @ got[route].T, K) < 1e-14
+    assert rel_err(got["one_stream"], got["lookahead"]) < 1e-12
 
 
 def test_cholesky_not_positive_definite_raises_linalgerror(gp, gnp, golden):
