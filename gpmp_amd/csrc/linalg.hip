@@ -309,15 +309,15 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   // panel boundaries: 1024-wide panels while the trailing matrix is large (rank-1024 updates run at
   // ~89 % of the MFMA peak against ~84 % for rank-512, and the longer panel still hides behind them),
   // 512-wide afterwards (shorter latency-bound tail)
-  static int wide_thresh = -1, lean_above = -1;
+  int wide_thresh = -1, lean_above = -1;          // (switches are read at every call: A/B inside one process)
   if (wide_thresh < 0) { const char* e = getenv("GPMP_POTRF_WIDE_ABOVE"); wide_thresh = e ? atoi(e) : 4096; }
   if (lean_above < 0) { const char* e = getenv("GPMP_POTRF_LEAN_ABOVE"); lean_above = e ? atoi(e) : 4096; }
-  static int along_lean = -1;
+  int along_lean = -1;
   if (along_lean < 0) { const char* e = getenv("GPMP_POTRF_ALONG_LEAN"); along_lean = e ? atoi(e) : 0; }
   // ... and narrower still once the trailing matrix is so small that the panel chain is all that is left: with 256- or
   // 128-column panels the in-panel rank-128 updates and most of the look-ahead update move from the chain (helper stream)
   // to the trailing update on the caller's stream, which has the machine to itself there
-  static int w256_below = -1, w128_below = -1;
+  int w256_below = -1, w128_below = -1;
   if (w256_below < 0) { const char* e = getenv("GPMP_POTRF_W256_BELOW"); w256_below = e ? atoi(e) : 4096; }
   if (w128_below < 0) { const char* e = getenv("GPMP_POTRF_W128_BELOW"); w128_below = e ? atoi(e) : 0; }
   // (option, off: the last columns as ONE panel -- its look-ahead update is then the whole trailing update and the panel is
@@ -385,7 +385,7 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     return rcu;
   };
   if (sa != nullptr && sa->every_panel) {
-    static int along_env = -1;
+    int along_env = -1;
     if (along_env < 0) { const char* e = getenv("GPMP_POTRF_ALONG_ROWS"); along_env = e ? atoi(e) : 0; }
     // (a quarter of the matrix at a time measured best: 2048 -> 512, 4096 -> 1024, 8192 -> 2048 rows per piece)
     along_rows = along_env > 0 ? along_env : imax(OUTER_BLOCKS * NB, (n / 4) / (OUTER_BLOCKS * NB) * (OUTER_BLOCKS * NB));
@@ -410,9 +410,9 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     // columns.  (At n = 16384 the panel, not the trailing update, is the longer of the two in EVERY step -- kernel trace: a
     // 1024-column panel = 0.8-1.0 ms of look-ahead update + 8 x 0.3 ms -- so the 0.8 ms in front of the first potf2 were
     // on the critical path.)
-    static int la_split = -1;
+    int la_split = -1;
     if (la_split < 0) { const char* e = getenv("GPMP_POTRF_LA_SPLIT"); la_split = e ? atoi(e) : 1; }
-    static int la_split_above = -1;       // (below, the pieces are too small to be worth two more events: n = 8192 loses 2 %)
+    int la_split_above = -1;       // (below, the pieces are too small to be worth two more events: n = 8192 loses 2 %)
     if (la_split_above < 0) { const char* e = getenv("GPMP_POTRF_LA_SPLIT_ABOVE"); la_split_above = e ? atoi(e) : 8192; }
     ColsReady ready[2];
     int nready = 0;
@@ -441,7 +441,7 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     // chain-bound tail: the trailing update of this step starts only when the look-ahead update above has finished, so
     // that the latter -- on the critical chain -- does not share the machine with it (kernel trace, n = 4096: 12 us alone,
     // 37 us when both start together); the trailing update has slack there
-    static int main_after_la_below = -1;
+    int main_after_la_below = -1;
     if (main_after_la_below < 0) { const char* e = getenv("GPMP_POTRF_MAIN_AFTER_LA_BELOW"); main_after_la_below = e ? atoi(e) : 4096; }
     if (n - p1 <= main_after_la_below) {
       e_main_go = g_la.next();
