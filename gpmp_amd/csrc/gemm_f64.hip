@@ -642,6 +642,7 @@ struct LeafSolveParams {
 template <int BNW>
 __global__ void __launch_bounds__(256, 2) trsm_leaf_kernel(LeafSolveParams p) {
   constexpr int MI = BNW == 128 ? 4 : 2;      // 16-row MFMA tiles per wave
+  constexpr int NJ = BNW == 128 ? 4 : BNW / 16;   // 16-column MFMA tiles per wave (strips of 64 / 32 / 16 columns: waves 4 x 1)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -664,8 +665,8 @@ __global__ void __launch_bounds__(256, 2) trsm_leaf_kernel(LeafSolveParams p) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(strip, 0, 0x7FFFFFFF, 0x00020000);
 
-  double fa[4][MI], fb[4][4];
-  d4 acc[MI][4];
+  double fa[4][MI], fb[4][NJ];
+  d4 acc[MI][NJ];
   for (int jb = 0; jb < p.nb; ++jb) {
     const int nk = (jb + 1) * (BM / BK);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
@@ -689,19 +690,19 @@ __global__ void __launch_bounds__(256, 2) trsm_leaf_kernel(LeafSolveParams p) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) fa[ks][i] = sa[v2_frag_addr<true>(wm + i * 16 + lr, ks * 4 + lk)];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[ks][j] = sb[v2_frag_addr<false>(wn + j * 16 + lr, ks * 4 + lk)];
+      for (int j = 0; j < NJ; ++j) fb[ks][j] = sb[v2_frag_addr<false>(wn + j * 16 + lr, ks * 4 + lk)];
     };
     auto mfma_step = [&](int ks) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
     };
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int j = 0; j < NJ; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
     issue(0, 0);
     __syncthreads();
@@ -737,7 +738,7 @@ __global__ void __launch_bounds__(256, 2) trsm_leaf_kernel(LeafSolveParams p) {
         for (int r = 0; r < 4; ++r) {
           double* rp = cb + (long)(i * 16 + 4 * r) * p.ldb;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) rp[lane_off + j * 16] = acc[i][j][r];
+          for (int j = 0; j < NJ; ++j) rp[lane_off + j * 16] = acc[i][j][r];
         }
     } else {
 #pragma unroll
@@ -746,7 +747,7 @@ __global__ void __launch_bounds__(256, 2) trsm_leaf_kernel(LeafSolveParams p) {
         for (int r = 0; r < 4; ++r) {
           double* rp = cb + (long)(i * 16 + 4 * r) * p.ldb;
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < NJ; ++j)
             if (wn + j * 16 + lr < ncv) rp[lane_off + j * 16] = acc[i][j][r];
         }
     }
@@ -1095,16 +1096,32 @@ int launch_trsm_leaf_forward(const double* L, long ldl, const double* dinv_leaf,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_leaf_kernel<64>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_leaf_kernel<32>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_leaf_kernel<16>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     attr_done = true;
   }
-  // 64-column strips while 128-column ones would leave most of the machine idle (GPMP_TRSM_LEAF_NARROW_BELOW strips)
-  const char* nbe = getenv("GPMP_TRSM_LEAF_NARROW_BELOW");     // read at every call (tests exercise both strip widths)
+  // A leaf has one workgroup per strip, each walking the nb blocks one after the other (MFMA-bound on its compute unit:
+  // 68 us for a 64-column strip of a 512-row leaf): the strips are narrowed until there are about GPMP_TRSM_LEAF_MIN_STRIPS of
+  // them.  (GPMP_TRSM_LEAF_NARROW_BELOW, the older switch: 128-column strips from this many up; both read at every call.)
+  const char* nbe = getenv("GPMP_TRSM_LEAF_NARROW_BELOW");
   const int narrow_below = nbe ? atoi(nbe) : 192;
+  const char* mse = getenv("GPMP_TRSM_LEAF_MIN_STRIPS");
+  const int min_strips = mse ? atoi(mse) : 256;
   const int strips128 = (ncols + BN - 1) / BN;
+  int bnw = 128;
+  if (strips128 < narrow_below) {
+    bnw = 64;
+    while (bnw > 16 && (ncols + bnw - 1) / bnw < min_strips) bnw >>= 1;
+  }
   LeafSolveParams p{G, ldg, B, ldb, nb, ncols};
   ProfScope ps(PK_GEMM_NN, st, (double)ncols * (double)(nb * BM) * (double)((nb + 1) * BM));   // counted with the small-K NN work it replaces
-  if (strips128 < narrow_below) hipLaunchKernelGGL(trsm_leaf_kernel<64>, dim3((ncols + 63) / 64), dim3(256), lds2, st, p);
-  else hipLaunchKernelGGL(trsm_leaf_kernel<128>, dim3(strips128), dim3(256), lds2, st, p);
+  const dim3 grid((ncols + bnw - 1) / bnw);
+  if (bnw == 128) hipLaunchKernelGGL(trsm_leaf_kernel<128>, grid, dim3(256), lds2, st, p);
+  else if (bnw == 64) hipLaunchKernelGGL(trsm_leaf_kernel<64>, grid, dim3(256), lds2, st, p);
+  else if (bnw == 32) hipLaunchKernelGGL(trsm_leaf_kernel<32>, grid, dim3(256), lds2, st, p);
+  else hipLaunchKernelGGL(trsm_leaf_kernel<16>, grid, dim3(256), lds2, st, p);
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }

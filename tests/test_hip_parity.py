@@ -454,16 +454,18 @@ def test_single_vector_solves_eight_streams_in_flight(gnp):
         assert torch.equal(got, refs[s % 4][1 if s >= 4 else 0]), s
 
 
-@pytest.mark.parametrize("strip", [64, 128])
+@pytest.mark.parametrize("strip", [16, 32, 64, 128])
 @pytest.mark.parametrize("n,m", [(1536, 700), (2048, 1024), (1280, 514), (1500, 900)])
 def test_forward_solve_many_rhs_fused_leaves(gnp, n, m, strip, monkeypatch):
-    """L^-1 B with the factor's scratch area (n > 1024): fused 512-row leaves incl. a narrow last column strip, on 64-column
-    strips (the default below 192 strips of 128) and on 128-column strips; n = 1500 has a ragged last leaf (launch-per-block
-    path) behind fused ones"""
+    """L^-1 B with the factor's scratch area (n > 1024): fused 512-row leaves incl. a narrow last column strip, on 128-column
+    strips and on the narrowed ones (64 / 32 / 16 columns: chosen so that a leaf has about GPMP_TRSM_LEAF_MIN_STRIPS workgroups);
+    n = 1500 has a ragged last leaf (launch-per-block path) behind fused ones"""
     import scipy.linalg as sla
     from oracle import gp_oracle as orc
 
-    monkeypatch.setenv("GPMP_TRSM_LEAF_NARROW_BELOW", "1000000" if strip == 64 else "0")
+    monkeypatch.setenv("GPMP_TRSM_LEAF_NARROW_BELOW", "0" if strip == 128 else "1000000")
+    # strips of `strip` columns: the narrowing stops at the first width with at least MIN_STRIPS strips
+    monkeypatch.setenv("GPMP_TRSM_LEAF_MIN_STRIPS", {128: "0", 64: "0", 32: str((m + 31) // 32), 16: "1000000"}[strip])
 
     rng = np.random.default_rng(n + m)
     x = rng.random((n, 3))
