@@ -99,7 +99,7 @@ class REMLAnalytic:
 
 
 # ---- many small problems in one call ------------------------------------------------------------------
-BATCH_MAX_N = 1024      # GPMP_BATCH_MAX_N
+BATCH_MAX_N = 2048      # GPMP_BATCH_MAX_N
 BATCH_MAX_Q = 3
 
 
@@ -111,7 +111,7 @@ def batch_values_and_gradients(model, covparams, batches, want_grad=True, use_me
     ``batches``: list of (x_b, z_b) device arrays; ``covparams``: one parameter vector (shared) or a (B, ntheta) array.
     ``use_mean``: REML with ``model.mean`` as the linear predictor (q <= 3 columns), else the zero-mean NLL.
     Returns ``(values, grads)`` as NumPy arrays ((B,), (B, ntheta) or None), or ``None`` when the batch does not
-    qualify (not a declared Matern covariance, a batch above 1024 points, more than 3 mean columns): the caller then
+    qualify (not a declared Matern covariance, a batch above 2048 points, more than 3 mean columns): the caller then
     evaluates the batches one after the other.  A failed factorisation raises ``HipLinAlgError`` like the array path."""
     cov = model.covariance
     if not isinstance(cov, MaternCovariance) or len(batches) == 0:
@@ -187,7 +187,7 @@ REMLAnalytic.batch_values_and_gradients = _reml_batch
 
 def _many(self, P, xi, zi, want_grad=False):
     """the criterion at every row of ``P`` on the same data: one batched call with per-problem parameters (the data are
-    replicated per row: at most 1024 x d doubles each).  None when the batched driver does not apply."""
+    replicated per row: at most 2048 x d doubles each).  None when the batched driver does not apply."""
     P = numpy.atleast_2d(numpy.asarray(P, dtype=numpy.float64))
     xi, zi = gnp.asarray(xi), gnp.asarray(zi)
     return self.batch_values_and_gradients(P, [(xi, zi)] * P.shape[0], want_grad)

@@ -5,7 +5,7 @@
 //   * posterior samplers / multi-chain optimisers -- log_prob = -criterion at many parameter vectors on the same data
 //     (gpmp/mcmc/param_posterior.py:229-278): ONE data set, B parameter vectors.
 // Per problem the reference runs cdist -> Matern -> cholesky -> 2 solve_triangular (-> autograd backward); on the GPU
-// a problem of n <= 1024 points is far too small to fill the machine (0.2 - 0.7 ms each, latency-bound), so problems
+// a problem of n <= 2048 points is far too small to fill the machine (0.2 - 2 ms each, latency-bound), so problems
 // are stacked: one padded n_max x n_max slot each (identity padding: log-det and quadratic form unchanged), and
 //   Gram build          B small launches of the fused distance + Matern kernel (lower tiles, own parameters / own points)
 //   Cholesky            the blocked right-looking factorisation with every kernel batched over the problems

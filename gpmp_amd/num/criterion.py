@@ -63,7 +63,7 @@ class DifferentiableSelectionCriterion:
     def evaluate_many(self, P, want_grad=False):
         """Criterion at MANY parameter vectors (rows of ``P``) on the same data -- what a multi-chain sampler asks for at
         every step (the reference evaluates ``selection_criterion(p)`` chain after chain, gpmp/mcmc/param_posterior.py:229-278,
-        mcmc/metropolis_hastings.py).  With an analytic ML / REML criterion and at most 1024 observations all rows go through
+        mcmc/metropolis_hastings.py).  With an analytic ML / REML criterion and at most 2048 observations all rows go through
         ONE batched library call (gpmp_nll_grad_batch with per-problem parameters); otherwise they are evaluated one after the
         other.  A row whose factorisation fails gets +inf (and a zero gradient), as ``evaluate_no_grad`` does.
         Returns ``values`` (C,) or ``(values, grads)`` with ``grads`` (C, len(p))."""
@@ -155,7 +155,7 @@ class BatchDifferentiableSelectionCriterion:
 
     def _batched(self, p_arr, batches, want_grad):
         """All batches in ONE library call (gpmp_nll_grad_batch: every kernel batched over the problems) when the
-        analytic object offers it and the batches qualify (declared Matern covariance, <= 1024 points per batch,
+        analytic object offers it and the batches qualify (declared Matern covariance, <= 2048 points per batch,
         <= 3 mean columns); None otherwise -> the batches are evaluated one after the other."""
         fn = getattr(self._analytic, "batch_values_and_gradients", None)
         if fn is None or not self.use_batched_kernel:

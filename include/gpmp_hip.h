@@ -37,7 +37,7 @@ typedef void* gpmp_stream_t;
 #define GPMP_MAX_DIM 64      /* largest input dimension d handled by the Gram kernels */
 #define GPMP_MAX_P 16        /* largest Matern half-integer index p (nu = p + 1/2) */
 #define GPMP_MAX_RANK 72     /* largest low-rank correction width in gpmp_matern_grad_trace */
-#define GPMP_BATCH_MAX_N 1024 /* largest (padded) problem size of the batched small-problem driver */
+#define GPMP_BATCH_MAX_N 2048 /* largest (padded) problem size of the batched small-problem driver */
 
 int gpmp_hip_abi_version(void);
 /* Last error text of the calling thread (HIP error string or argument message). */

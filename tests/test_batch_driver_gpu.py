@@ -75,7 +75,7 @@ def _data(n, d, seed):
 
 
 @pytest.mark.parametrize("q", [0, 1, 3])
-@pytest.mark.parametrize("sizes", [(300, 128, 77, 257, 300), (1024, 1000, 513), (90, 64, 31), (640, 640, 640, 640, 640, 640, 640)])
+@pytest.mark.parametrize("sizes", [(300, 128, 77, 257, 300), (1024, 1000, 513), (90, 64, 31), (640, 640, 640, 640, 640, 640, 640), (2048, 1300, 1537)])
 def test_batch_driver_ragged_sizes_shared_parameters(env, sizes, q):
     d = 3
     th = np.concatenate(([0.2], -np.log(0.3 + 0.2 * np.arange(d))))
@@ -88,8 +88,11 @@ def test_batch_driver_ragged_sizes_shared_parameters(env, sizes, q):
     assert np.all(info == 0)
     for b in range(len(sizes)):
         v, g, i = _single(env, xs[b], zs[b], None if q == 0 else Ps[b], th)
-        assert i == 0 and abs(vals[b] - v) < 1e-11 * abs(v), (b, vals[b], v)
-        assert rel_err(grads[b], g) < 1e-9, (b, grads[b], g)
+        # (d = 3: above ~1000 points K is ill-conditioned at these length scales, and the one-stream / look-ahead routes of the two
+        #  drivers round differently: 2e-9 relative on the value at n = 2048)
+        tol_v, tol_g = (1e-11, 1e-9) if max(sizes) <= 1024 else (1e-8, 1e-6)
+        assert i == 0 and abs(vals[b] - v) < tol_v * abs(v), (b, vals[b], v)
+        assert rel_err(grads[b], g) < tol_g, (b, grads[b], g)
 
 
 def test_batch_driver_many_parameter_vectors_one_data_set(env):
@@ -130,7 +133,7 @@ def test_batch_driver_failure_is_per_problem(env, golden):
         v, gr, _ = _single(env, xs[b], zs[b], None, thetas[b])
         assert abs(vals[b] - v) < 1e-8 * abs(v) and rel_err(grads[b], gr) < 1e-6      # (ill-conditioned at these length scales)
     torch, gnp, _lib, lib = env
-    assert lib.gpmp_batch_ws_elems(2048, 3, 0, 4, 1) == 0 and lib.gpmp_batch_ws_elems(512, 3, 4, 4, 1) == 0
+    assert lib.gpmp_batch_ws_elems(2049, 3, 0, 4, 1) == 0 and lib.gpmp_batch_ws_elems(512, 3, 4, 4, 1) == 0
 
 
 def test_batch_criterion_fast_path_equals_one_at_a_time(env, golden):
@@ -191,7 +194,7 @@ def test_criterion_at_many_parameter_vectors_sampler_pattern(env, golden):
         assert np.allclose(v_bad[ok], vals[ok], rtol=1e-11) and (not np.isfinite(v_bad[4]) or abs(v_bad[4]) > 1e10)
 
 
-@pytest.mark.parametrize("B,n,d,q", [(1, 5, 1, 0), (1, 129, 2, 1), (3, 4, 1, 3), (2, 1024, 6, 2), (17, 130, 3, 0)])
+@pytest.mark.parametrize("B,n,d,q", [(1, 5, 1, 0), (1, 129, 2, 1), (3, 4, 1, 3), (2, 1024, 6, 2), (17, 130, 3, 0), (2, 2048, 6, 1)])
 def test_batch_driver_edge_shapes(env, B, n, d, q):
     """one problem, tiny problems (n just above q), one-dimensional inputs, the largest slot size, a block boundary + 2"""
     th = np.concatenate(([0.1], -np.log(0.3 + 0.25 * np.arange(d))))

@@ -30,7 +30,7 @@ class _Analytic:
     def many_values_and_gradients(self, P, x, z, want_grad):
         self.calls += 1
         if self.batched == "none":
-            return None                              # the batched driver does not apply (e.g. n > 1024)
+            return None                              # the batched driver does not apply (e.g. n > 2048)
         if np.any(P[:, 0] < 0):
             raise np.linalg.LinAlgError("Matrix is not positive definite: batched problem failed")
         v = np.sum((P - 1.0) ** 2, axis=1) + x + z

@@ -14,8 +14,9 @@ th = np.concatenate(([0.0], -np.log(0.5 * (1.0 + np.arange(d) / d))))
 model = gp.Model(None, gp.kernel.MaternCovariance(2), None, th, "zero")
 ana = MLZeroMeanAnalytic(model)
 print("n      B   batched ms   problems/s   one-at-a-time ms   problems/s   speed-up   | per-problem parameters (sampler pattern): ms   problems/s")
-for n in (128, 256, 512, 1024):
-    for B in (8, 64, 256):
+sizes = [int(a) for a in sys.argv[1:]] or [128, 256, 512, 1024]
+for n in sizes:
+    for B in ((8, 64, 256) if n <= 1024 else (4, 16)):
         rng = np.random.default_rng(n + B)
         batches = []
         for b in range(B):
