@@ -18,6 +18,8 @@ namespace {
 
 inline int imin(int a, int b) { return a < b ? a : b; }
 inline int imax(int a, int b) { return a > b ? a : b; }
+// switch from the environment, read at every call (A/B runs inside one process, tests that exercise both settings)
+inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 // Blocked (two-level) leaf of the recursive factorisation; row0 = global index of A[0][0] (for info).
 int potrf_blocked(double* A, int n, long lda, double* dinv, int* info_dev, int row0, hipStream_t st,
@@ -309,22 +311,16 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   // panel boundaries: 1024-wide panels while the trailing matrix is large (rank-1024 updates run at
   // ~89 % of the MFMA peak against ~84 % for rank-512, and the longer panel still hides behind them),
   // 512-wide afterwards (shorter latency-bound tail)
-  int wide_thresh = -1, lean_above = -1;          // (switches are read at every call: A/B inside one process)
-  if (wide_thresh < 0) { const char* e = getenv("GPMP_POTRF_WIDE_ABOVE"); wide_thresh = e ? atoi(e) : 4096; }
-  if (lean_above < 0) { const char* e = getenv("GPMP_POTRF_LEAN_ABOVE"); lean_above = e ? atoi(e) : 4096; }
-  int along_lean = -1;
-  if (along_lean < 0) { const char* e = getenv("GPMP_POTRF_ALONG_LEAN"); along_lean = e ? atoi(e) : 0; }
+  const int wide_thresh = env_int("GPMP_POTRF_WIDE_ABOVE", 4096), lean_above = env_int("GPMP_POTRF_LEAN_ABOVE", 4096);
+  const int along_lean = env_int("GPMP_POTRF_ALONG_LEAN", 0);
   // ... and narrower still once the trailing matrix is so small that the panel chain is all that is left: with 256- or
   // 128-column panels the in-panel rank-128 updates and most of the look-ahead update move from the chain (helper stream)
   // to the trailing update on the caller's stream, which has the machine to itself there
-  int w256_below = -1, w128_below = -1;
-  if (w256_below < 0) { const char* e = getenv("GPMP_POTRF_W256_BELOW"); w256_below = e ? atoi(e) : 4096; }
-  if (w128_below < 0) { const char* e = getenv("GPMP_POTRF_W128_BELOW"); w128_below = e ? atoi(e) : 0; }
+  const int w256_below = env_int("GPMP_POTRF_W256_BELOW", 4096), w128_below = env_int("GPMP_POTRF_W128_BELOW", 0);
   // (option, off: the last columns as ONE panel -- its look-ahead update is then the whole trailing update and the panel is
   //  the blocked factorisation of what is left, all on the chain stream.  On its own the blocked route wins up to 2048
   //  columns (potrf_lower), as the tail of this one it changes nothing: n = 4096: 2.19 vs 2.20 ms, 8192: 6.75 vs 6.75.)
-  const char* tbe = getenv("GPMP_POTRF_TAIL_BLOCKED_BELOW");   // (read at every call)
-  const int tail_blocked = (sa != nullptr && sa->every_panel) ? 0 : (tbe ? atoi(tbe) : 0);
+  const int tail_blocked = (sa != nullptr && sa->every_panel) ? 0 : env_int("GPMP_POTRF_TAIL_BLOCKED_BELOW", 0);
   std::vector<int> pb;
   for (int p = 0; p < n;) {
     pb.push_back(p);
@@ -385,8 +381,7 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     return rcu;
   };
   if (sa != nullptr && sa->every_panel) {
-    int along_env = -1;
-    if (along_env < 0) { const char* e = getenv("GPMP_POTRF_ALONG_ROWS"); along_env = e ? atoi(e) : 0; }
+    const int along_env = env_int("GPMP_POTRF_ALONG_ROWS", 0);
     // (a quarter of the matrix at a time measured best: 2048 -> 512, 4096 -> 1024, 8192 -> 2048 rows per piece)
     along_rows = along_env > 0 ? along_env : imax(OUTER_BLOCKS * NB, (n / 4) / (OUTER_BLOCKS * NB) * (OUTER_BLOCKS * NB));
     GPMP_HIP_TRY(hipStreamWaitEvent(g_solve_stream, e_f, 0));
@@ -410,10 +405,8 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     // columns.  (At n = 16384 the panel, not the trailing update, is the longer of the two in EVERY step -- kernel trace: a
     // 1024-column panel = 0.8-1.0 ms of look-ahead update + 8 x 0.3 ms -- so the 0.8 ms in front of the first potf2 were
     // on the critical path.)
-    int la_split = -1;
-    if (la_split < 0) { const char* e = getenv("GPMP_POTRF_LA_SPLIT"); la_split = e ? atoi(e) : 1; }
-    int la_split_above = -1;       // (below, the pieces are too small to be worth two more events: n = 8192 loses 2 %)
-    if (la_split_above < 0) { const char* e = getenv("GPMP_POTRF_LA_SPLIT_ABOVE"); la_split_above = e ? atoi(e) : 8192; }
+    const int la_split = env_int("GPMP_POTRF_LA_SPLIT", 1);
+    const int la_split_above = env_int("GPMP_POTRF_LA_SPLIT_ABOVE", 8192);   // (below, the pieces are too small to be worth two more events: n = 8192 loses 2 %)
     ColsReady ready[2];
     int nready = 0;
     if (la_split && p2 - p1 == 2 * OUTER_BLOCKS * NB && p2 <= n && n - p1 > la_split_above) {
@@ -441,8 +434,7 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     // chain-bound tail: the trailing update of this step starts only when the look-ahead update above has finished, so
     // that the latter -- on the critical chain -- does not share the machine with it (kernel trace, n = 4096: 12 us alone,
     // 37 us when both start together); the trailing update has slack there
-    int main_after_la_below = -1;
-    if (main_after_la_below < 0) { const char* e = getenv("GPMP_POTRF_MAIN_AFTER_LA_BELOW"); main_after_la_below = e ? atoi(e) : 4096; }
+    const int main_after_la_below = env_int("GPMP_POTRF_MAIN_AFTER_LA_BELOW", 4096);
     if (n - p1 <= main_after_la_below) {
       e_main_go = g_la.next();
       GPMP_HIP_TRY(hipEventRecord(e_main_go, s1));
@@ -522,8 +514,7 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
 // stream only adds event packets and a trailing update that slows the chain (measured in one process, both routes:
 // n = 1536: 0.69 vs 0.77 ms, 2048: 0.96 vs 1.01, 3072: 1.68 vs 1.57, 4096: 2.47 vs 2.17).
 inline int potrf_one_stream_max() {
-  const char* be = getenv("GPMP_POTRF_BLOCKED_BELOW");   // (read at every call: tests exercise both routes)
-  return be ? atoi(be) : 4 * OUTER_BLOCKS * NB;
+  return env_int("GPMP_POTRF_BLOCKED_BELOW", 4 * OUTER_BLOCKS * NB);
 }
 
 int potrf_lower(double* A, int n, long lda, double* dinv, int* info_dev, hipStream_t st) {
