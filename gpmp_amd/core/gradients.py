@@ -13,6 +13,7 @@ pass (gpmp_matern_grad_trace) that recomputes the scaled differences on the fly 
 low-rank part  sum_a F[i,a] G[k,a]  in registers -- K and dK are never stored.
 """
 import math
+import os
 
 import numpy
 import torch
@@ -135,6 +136,27 @@ def batch_values_and_gradients(model, covparams, batches, want_grad=True, use_me
     if min(ns) <= q:
         return None
     dev = xs[0].device
+    # the workspace grows with B (two nmax x nmax matrices per problem with gradients: 70 MB at 2048 points): a call is cut into
+    # pieces whose workspace fits a quarter of the free device memory (at most 32 GiB)
+    per_problem = 8 * int(lib.gpmp_batch_ws_elems(nmax, d, q, 1, 1 if want_grad else 0))
+    budget = 1 << 30
+    if dev.type == "cuda":
+        budget = min(int(torch.cuda.mem_get_info(dev)[0]) // 4, 32 << 30)
+    if os.environ.get("GPMP_BATCH_WS_BUDGET_MB"):            # (tests: force the piecewise route)
+        budget = int(float(os.environ["GPMP_BATCH_WS_BUDGET_MB"]) * (1 << 20))
+    b_piece = max(1, budget // max(per_problem, 1))
+    if B > b_piece:
+        th_all = numpy.asarray(covparams, dtype=numpy.float64)
+        vals, grads = [], []
+        for b0 in range(0, B, b_piece):
+            sl = slice(b0, min(B, b0 + b_piece))
+            out = batch_values_and_gradients(model, th_all if th_all.ndim == 1 else th_all[sl], batches[sl], want_grad, use_mean, mean_offset)
+            if out is None:
+                return None
+            vals.append(out[0])
+            if want_grad:
+                grads.append(out[1])
+        return numpy.concatenate(vals), (numpy.concatenate(grads, axis=0) if want_grad else None)
     X = torch.zeros((B, nmax, d), dtype=torch.float64, device=dev)
     Z = torch.zeros((B, nmax), dtype=torch.float64, device=dev)
     Pm = torch.zeros((B, nmax, max(q, 1)), dtype=torch.float64, device=dev)
