@@ -411,7 +411,12 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     int nready = 0;
     if (la_split && p2 - p1 == 2 * OUTER_BLOCKS * NB && p2 <= n && n - p1 > la_split_above) {
       const int cuts[4] = {p1, p1 + NB, p1 + OUTER_BLOCKS * NB, p2};
-      GPMP_HIP_TRY(hipStreamWaitEvent(sside, e_f, 0));
+      // the side stream reads panel k: it waits for an event recorded HERE, behind that panel on the chain stream (e_f is
+      // only renewed where somebody else waits for it -- need_ef below -- and may be an older panel's; found by
+      // tests/test_switches_gpu.py with the split enabled below 4096 rows, where the shipped thresholds never combine the two)
+      hipEvent_t e_panel = g_la.next();
+      GPMP_HIP_TRY(hipEventRecord(e_panel, s1));
+      GPMP_HIP_TRY(hipStreamWaitEvent(sside, e_panel, 0));
       if (e_u2) GPMP_HIP_TRY(hipStreamWaitEvent(sside, e_u2, 0));
       for (int q = 0; q < 3; ++q) {
         const int ca = cuts[q], cb = cuts[q + 1];
