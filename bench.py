@@ -10,9 +10,20 @@ One STEP = one pass of the hot path over one batch of synthetic inputs already r
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): d = 8, Matern-5/2
 anisotropic, n = 32768 observations, m = 50000 prediction points per GPU, fp64.
 Multi-GPU (weak scaling): the prediction set shards over ranks (m points per rank), the observations
-are replicated and every rank factors K itself -- no collective on the data path.
+are replicated and EVERY rank factors K itself -- no collective on the data path.  `extra.strong_scaling`
+is the same step with a FIXED total of m points split over the ranks.
 
 value = (N * m) / (max over ranks of the time of K steps / K)   [points/s].
+
+Processes.  `--gpus N` with N > 1 and no RANK in the environment: this process is a LAUNCHER that makes no GPU call
+(it does not even import torch): it starts N worker processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+set, each in its own session), relays rank 0's JSON line as its own last stdout line and leaves with a non-zero code if
+any worker failed.  Launched under `torch.distributed.run` the N ranks are the workers; a WORLD_SIZE that differs from
+--gpus is an error (exit 2), never a silent one-rank run.
+At N > 1 the 2-D block-cyclic Cholesky of BASELINE.json configs[4] runs BY DEFAULT after the headline, in a separate
+group of N fresh processes under a time limit (GPMP_BENCH_DIST_TIMEOUT): a wedged or failing collective there costs
+`extra.dist_potrf` (status + the phase in flight are recorded) and the exit code (3 = timeout, 4 = error), not the
+headline line.
 """
 import argparse
 import json
@@ -79,25 +90,29 @@ def _host_threads():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(n, m, d, threads, m_sample=512, n_sample=8192):
+def cpu_baseline(n, m, d, threads, m_sample=4096, n_sample=8192):
     """The oracle (NumPy / SciPy restatement of the reference's NumPy backend: cdist -> Matern ufuncs -> cholesky ->
     2 x solve_triangular -> einsum) on the host cores, on a BOUNDED sample of the headline workload.  The reference's Gram
     build is single-threaded (SciPy cdist + ~7 full-size NumPy temporaries: 1.6 s at n = 4096, i.e. ~100 s at n = 32768,
-    twice per step), so the full step cannot be run inside a benchmark; what is run, ~20-30 s of CPU work:
+    twice per step), so the full step cannot be run inside a benchmark; what is run, ~30-60 s of CPU work:
       * Cholesky at the FULL n (LAPACK dpotrf through numpy.linalg.cholesky, all BLAS threads) -- also the host potrf figure;
       * Gram(xi, xi), Gram(xi, xt_s), the two triangular solves + reductions for m_sample points and the NLL solves at
-        n_sample = min(n, 8192) observations of the same synthetic set.
-    The step time at the full size is then assembled from these with their exact complexities -- Gram(xi,xi) ~ n^2,
-    Gram(xi,xt) ~ n m, solves ~ n^2 m, NLL solves ~ n^2:
+        n_sample = min(n, 8192) observations of the same synthetic set.  m_sample = 4096 columns (round 2: 512, a skinny
+        trsm at 0.15 TFLOP/s that made the CPU look several times slower than a BLAS-3 run): the solves are timed on their
+        own and their measured TFLOP/s is printed.
+    `value` is NOT a measured step: the step time at the full size is ASSEMBLED from these measured pieces with their exact
+    complexities -- Gram(xi,xi) ~ n^2, Gram(xi,xt) ~ n m, solves ~ n^2 m, NLL solves ~ n^2:
         T = 2 (Gram_ii (n/n_s)^2 + Cholesky(n)) + NLL_tail (n/n_s)^2 + m/m_s (Gram_it (n/n_s) + Solve (n/n_s)^2)
-    and value = m / T.  Every term is a measured oracle call; only the scaling is arithmetic, and it is stated in `sample`."""
+    and value = m / T; `assembled` says so, `measured_s` holds every measured piece, `extrapolated_s` the scaled terms.
+    (One full-size CPU run of the same step is recorded in DESIGN section 5 beside this model figure.)"""
     from scipy.linalg import solve_triangular
 
     from oracle import gp_oracle as orc
 
     ns = min(n, n_sample)
+    ms = min(m, m_sample)
     xi, zi, xt, theta = synth(n, m, d, 0)
-    xi_s, zi_s, xs = xi[:ns], zi[:ns], xt[:m_sample]
+    xi_s, zi_s, xs = xi[:ns], zi[:ns], xt[:ms]
     t = {}
     np.linalg.cholesky(orc.maternp_covariance(xi[:512], None, 2, theta))    # BLAS thread pool / page-in warm-up, untimed
 
@@ -112,13 +127,18 @@ def cpu_baseline(n, m, d, threads, m_sample=512, n_sample=8192):
     del K
     Kit = tick("gram_it", lambda: orc.maternp_covariance(xi_s, xs, 2, theta))               # kriging.py:60
 
-    def solves():                                                                            # numpy_backend.py:467-468, kriging.py:193-194, model.py:298
+    def trsm_pair():                                                                         # numpy_backend.py:467-468
         y = solve_triangular(L, Kit, lower=True)
-        lam = solve_triangular(L.T, y, lower=False)
+        return solve_triangular(L.T, y, lower=False)
+
+    lam = tick("trsm_pair", trsm_pair)
+
+    def reductions():                                                                        # kriging.py:193-194, model.py:298
         var = orc.maternp_covariance(xs, None, 2, theta, True) - np.einsum("i..., i...", lam, Kit)
         return np.einsum("i..., i...", lam, zi_s), var
 
-    tick("solve_sample", solves)
+    tick("reductions", reductions)
+    del lam
 
     def nll_tail():                                                                          # likelihood.py:46-51
         a = solve_triangular(L.T, solve_triangular(L, zi_s, lower=True), lower=False)
@@ -135,16 +155,22 @@ def cpu_baseline(n, m, d, threads, m_sample=512, n_sample=8192):
     else:
         t["cholesky"] = t["cholesky_ns"]
     r = n / ns
-    per_point = (t["gram_it"] * r + t["solve_sample"] * r * r) / m_sample
-    step = 2.0 * (t["gram_ii"] * r * r + t["cholesky"]) + t["nll_tail"] * r * r + m * per_point
-    return {"value": m / step, "unit": "points/s", "cores": threads, "kind": "port",
+    trsm_tflops = 2.0 * ns * ns * ms / t["trsm_pair"] / 1e12
+    ext = {"gram_ii_x2": 2.0 * t["gram_ii"] * r * r, "cholesky_x2 (measured at the full n)": 2.0 * t["cholesky"],
+           "nll_tail": t["nll_tail"] * r * r, "gram_it": t["gram_it"] * r * m / ms,
+           "trsm_pair": t["trsm_pair"] * r * r * m / ms, "reductions": t["reductions"] * r * m / ms}
+    step = sum(ext.values())
+    return {"value": m / step, "unit": "points/s", "cores": threads, "kind": "port", "assembled": True,
             "sample": f"oracle (SciPy cdist + Matern ufuncs + LAPACK), d={d}: Cholesky at the full n={n} ({t['cholesky']:.1f} s); Gram(xi,xi) "
-                      f"({t['gram_ii']:.1f} s), Gram(xi,xt), 2 triangular solves + reductions for {m_sample} of the {m} points and the NLL "
-                      f"solves at n_s={ns}; step time assembled with the exact complexities (Gram_ii, solves, NLL ~ (n/n_s)^2; Gram_it ~ n/n_s; "
-                      f"per-point part x m/{m_sample}): {step:.0f} s per predict+NLL step; CPU work done {sum(t.values()):.0f} s; "
+                      f"({t['gram_ii']:.1f} s), Gram(xi,xt), 2 triangular solves ({trsm_tflops:.2f} TFLOP/s measured) + reductions for "
+                      f"{ms} of the {m} points and the NLL solves at n_s={ns}; NOT a measured step: step time ASSEMBLED with the exact "
+                      f"complexities (Gram_ii, solves, NLL ~ (n/n_s)^2; Gram_it, reductions ~ n/n_s; per-point parts x m/{ms}): "
+                      f"{step:.0f} s per predict+NLL step; CPU work done {sum(t.values()):.0f} s; "
                       f"BLAS threads={threads} (cdist and the ufuncs are single-threaded)",
+            "cpu_trsm_tflops": trsm_tflops,
             "host_potrf": {"n": n, "s": t["cholesky"], "tflops": n ** 3 / 3.0 / t["cholesky"] / 1e12},
-            "phases_s": {k_: round(v_, 3) for k_, v_ in t.items()}}
+            "measured_s": {k_: round(v_, 3) for k_, v_ in t.items()},
+            "extrapolated_s": {k_: round(v_, 2) for k_, v_ in ext.items()}}
 
 
 def config2_extra(model, d, threads, with_cpu):
@@ -261,13 +287,196 @@ def config4_extra(threads, with_cpu):
     return out
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# process groups: launcher side (NO GPU call in this section -- it runs in processes that never import torch)
+# ------------------------------------------------------------------------------------------------------------------
+EXIT_TIMEOUT, EXIT_ERROR = 3, 4
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv, timeout_s, env_extra=None, grace_s=15.0):
+    """Start ``n`` fresh worker processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their
+    environment, one session each so that a worker and anything it started can be killed as a group), wait for them under a
+    time limit and return {"status": "ok" | "timeout" | "error", "rc": [...], "pids": [...], "stdout0": rank 0's stdout,
+    "seconds": wall time}.  A worker that leaves with a non-zero code ends the group: its peers (possibly waiting for it
+    inside a collective) get ``grace_s`` seconds, then SIGKILL.  On a timeout every worker's process group is killed.
+    stderr of the workers is inherited; stdout of ranks > 0 goes to stderr."""
+    import signal
+    import subprocess
+    import threading
+
+    port = _free_port()
+    procs, chunks = [], []
+    for r in range(n):
+        # (when rank 0 of a torch.distributed.run launch starts this group, the agent's variables must not leak into it:
+        #  TORCHELASTIC_USE_AGENT_STORE would make the children look for the agent's store on OUR port)
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_ASYNC", "GROUP_", "ROLE_"))}
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GPMP_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, start_new_session=True,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None))
+
+    def drain(stream):            # a reader thread: rank 0 can never block on a full pipe
+        for raw in iter(stream.readline, b""):
+            chunks.append(raw.decode(errors="replace"))
+
+    reader = threading.Thread(target=drain, args=(procs[0].stdout,), daemon=True)
+    reader.start()
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)        # p is its session's leader: pgid == pid
+                except (ProcessLookupError, PermissionError):
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
+
+    t0 = time.monotonic()
+    status, first_bad, first_rc = "ok", None, None
+    while True:
+        rcs = [p.poll() for p in procs]
+        now = time.monotonic()
+        if all(rc is not None for rc in rcs):
+            if any(rc != 0 for rc in rcs):
+                status = "error"
+                if first_rc is None:
+                    first_rc = next(rc for rc in rcs if rc != 0)
+            break
+        if first_bad is None and any(rc not in (None, 0) for rc in rcs):
+            first_bad = now
+            first_rc = next(rc for rc in rcs if rc not in (None, 0))     # the failure that came first (its peers fail after it)
+        if first_bad is not None and now - first_bad > grace_s:
+            status = "error"
+            kill_all()
+            break
+        if now - t0 > timeout_s:
+            status = "timeout"
+            kill_all()
+            break
+        time.sleep(0.1)
+    reader.join(timeout=5)
+    return {"status": status, "rc": [p.poll() for p in procs], "first_bad_rc": first_rc, "pids": [p.pid for p in procs],
+            "stdout0": "".join(chunks), "seconds": time.monotonic() - t0}
+
+
+def _last_json_line(text):
+    for ln in reversed(text.splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                continue
+    return None
+
+
+def run_dist_extra_group(n_ranks):
+    """BASELINE.json configs[4] as an extra: N FRESH processes (never the ones that ran the headline), a progress file that
+    rank 0 rewrites at every phase change, and a time limit enforced from outside -- so whatever a collective does, the
+    caller gets {"status", "phase", everything that finished} back and decides the exit code."""
+    import tempfile
+
+    timeout_s = float(os.environ.get("GPMP_BENCH_DIST_TIMEOUT", "420"))
+    with tempfile.TemporaryDirectory(prefix="gpmp_bench_") as tmp:
+        path = os.path.join(tmp, "dist_progress.json")
+        got = spawn_ranks(n_ranks, ["--role", "dist-extra", "--gpus", str(n_ranks), "--progress", path], timeout_s)
+        res = {"status": "started", "phase": "no progress written: the workers did not get as far as setup"}
+        try:
+            with open(path) as f:
+                res = json.load(f)
+        except (OSError, ValueError):
+            pass
+    if got["status"] != "ok":
+        res["status"] = got["status"]                    # "timeout" / "error": what was in flight is in res["phase"]
+    elif res.get("status") != "ok":
+        res["status"] = "error"
+    res.update({"worker_rc": got["rc"], "worker_pids": got["pids"], "wall_s": round(got["seconds"], 2), "timeout_s": timeout_s,
+                "isolation": f"{n_ranks} fresh processes in their own sessions, killed as groups on timeout"})
+    return res
+
+
+def dist_extra_enabled(world):
+    env = os.environ.get("GPMP_BENCH_DIST", "1")
+    return env not in ("0", "") and (world > 1 or env == "force")
+
+
+def finish_with_dist_extra(line, world):
+    """The coordinator's last act (the launcher, or rank 0 of a torch.distributed.run launch after it left its process
+    group): run the distributed extra in its own process group, attach it, print THE line, return the exit code."""
+    rc = 0
+    if dist_extra_enabled(world):
+        res = run_dist_extra_group(world)
+        line.setdefault("extra", {})["dist_potrf"] = res
+        if res["status"] != "ok":
+            rc = EXIT_TIMEOUT if res["status"] == "timeout" else EXIT_ERROR
+            sys.stderr.write(f"[bench] distributed extra: {res['status']} in phase {res.get('phase')!r} {res.get('error', '')}\n")
+    print(json.dumps(line), flush=True)
+    return rc
+
+
+def launcher_main(args, argv):
+    """`python bench.py --gpus N` (N > 1, no RANK in the environment).  Makes no GPU call."""
+    assert "torch" not in sys.modules, "the launcher must not import torch (a GPU-initialised parent may not start GPU children safely)"
+    got = spawn_ranks(args.gpus, ["--role", "headline"] + argv, float(os.environ.get("GPMP_BENCH_HEADLINE_TIMEOUT", "1500")))
+    line = _last_json_line(got["stdout0"])
+    if got["status"] != "ok" or line is None:
+        sys.stderr.write(f"[bench] headline workers: {got['status']}, exit codes {got['rc']}\n")
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "points/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                          "error": f"headline workers {got['status']}: exit codes {got['rc']}", "partial": line}), flush=True)
+        bad = got["first_bad_rc"]
+        return EXIT_TIMEOUT if got["status"] == "timeout" else (bad if bad is not None and 0 < bad < 256 else EXIT_ERROR)
+    line.setdefault("extra", {})["launcher"] = {"pid": os.getpid(), "worker_pids": got["pids"], "wall_s": round(got["seconds"], 2),
+                                                 "note": "GPU-free parent started one fresh process per rank"}
+    return finish_with_dist_extra(line, args.gpus)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: the distributed extra (worker side)
+# ------------------------------------------------------------------------------------------------------------------
 DIST_N = {2: 65536, 4: 90112, 8: 131072}     # about 17 GB of local matrix per GPU; 8 GPUs = BASELINE.json configs[4]
 
 
+class _Progress(dict):
+    """dict that rank 0 mirrors into a JSON file at every assignment (atomic rename): what the launcher reads back."""
+
+    def __init__(self, path):
+        super().__init__()
+        self._path = path
+
+    def _flush(self):
+        if self._path:
+            tmp = self._path + ".tmp"
+            with open(tmp, "w") as f:
+                json.dump(self, f)
+            os.replace(tmp, self._path)
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, v)
+        self._flush()
+
+    def update(self, *a, **kw):
+        super().update(*a, **kw)
+        self._flush()
+
+
 def dist_potrf_extra(world, rank, res):
-    """OUTSIDE the timed region, N > 1 only: the 2-D block-cyclic Cholesky (+ NLL) of BASELINE.json configs[4]
-    (n = 131072 on the 2 x 4 grid of 8 GPUs; n scaled to the same memory per GPU on 2 / 4 GPUs) with RCCL panel
-    broadcasts, once per transport.  Fills ``res`` progressively so that a watchdog can still report what finished."""
+    """The 2-D block-cyclic Cholesky (+ NLL) of BASELINE.json configs[4] (n = 131072 on the 2 x 4 grid of 8 GPUs; n scaled
+    to the same memory per GPU on 2 / 4 GPUs; GPMP_BENCH_DIST_N overrides) with RCCL panel broadcasts, once per transport,
+    preceded by a values check at n = 8192 against the single-GPU path.  Fills ``res`` progressively."""
     import torch
     import torch.distributed as dist
 
@@ -276,10 +485,11 @@ def dist_potrf_extra(world, rank, res):
     from gpmp_amd.kernel import MaternCovariance
 
     pr, pc = ProcessGrid.default_shape(world)
-    n = DIST_N.get(world, max(1024, int(46000 * math.sqrt(world)) // 1024 * 1024))
+    n = int(os.environ.get("GPMP_BENCH_DIST_N", "0")) or DIST_N.get(world, max(1024, int(46000 * math.sqrt(world)) // 1024 * 1024))
     d, nb = 8, 1024
-    res.update({"n": n, "d": d, "grid": f"{pr}x{pc}", "block": nb, "noise_variance": 1e-4,
-                "note": "outside the timed region; flops = n^3/3 over wall time of factor() (max over ranks)"})
+    nccl = dist.get_backend() == "nccl"
+    res.update({"n": n, "d": d, "grid": f"{pr}x{pc}", "block": nb, "noise_variance": 1e-4, "backend": dist.get_backend(),
+                "note": "own process group, outside the timed region; flops = n^3/3 over wall time of factor() (max over ranks)"})
     rng = np.random.default_rng(1234)
     x = rng.random((n, d))
     z = np.sin(2 * np.pi * x[:, 0]) + x[:, 1:].sum(axis=1)
@@ -289,26 +499,29 @@ def dist_potrf_extra(world, rank, res):
     torch.cuda.empty_cache()
 
     def tmax(v):
-        t = torch.tensor([v], dtype=torch.float64, device=gnp._dev())
+        t = torch.tensor([v], dtype=torch.float64, device=gnp._dev() if nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     # ---- values first: a small problem through the same grid / collectives against the single-GPU path on rank 0
-    n_chk = 8192
-    res["phase"] = "check_n8192: build + factor (bcast)"
-    chk = BlockCyclicCholesky(grid, n_chk, nb=nb, transport="bcast")
-    chk.build_local_gram(MaternCovariance(2), xd[:n_chk].contiguous(), theta, 1e-4)
-    info_chk = chk.factor()
-    res["phase"] = "check_n8192: nll (world broadcast + all-reduce per block column)"
-    nll_dist = chk.negative_log_likelihood(z[:n_chk])
-    del chk
-    if rank == 0:
-        import gpmp_amd as gp
+    n_chk = min(8192, n)
+    for transport in ("bcast", "p2p"):
+        res["phase"] = f"check_n{n_chk} ({transport}): build + factor"
+        chk = BlockCyclicCholesky(grid, n_chk, nb=nb, transport=transport)
+        chk.build_local_gram(MaternCovariance(2), xd[:n_chk].contiguous(), theta, 1e-4)
+        info_chk = chk.factor()
+        res["phase"] = f"check_n{n_chk} ({transport}): nll (world broadcast + all-reduce per block column)"
+        nll_dist = chk.negative_log_likelihood(z[:n_chk])
+        del chk
+        if rank == 0:
+            import gpmp_amd as gp
 
-        th2 = np.concatenate(([theta[0], math.log(1e-4)], theta[1:]))
-        ref = float(gp.Model(None, MaternCovariance(2, noise=True), None, th2, "zero").negative_log_likelihood_zero_mean(th2, x[:n_chk], z[:n_chk]))
-        res["check_n8192"] = {"info": info_chk, "nll_block_cyclic": nll_dist, "nll_single_gpu": ref,
-                              "rel_diff": abs(nll_dist - ref) / abs(ref)}
+            th2 = np.concatenate(([theta[0], math.log(1e-4)], theta[1:]))
+            ref = float(gp.Model(None, MaternCovariance(2, noise=True), None, th2, "zero").negative_log_likelihood_zero_mean(th2, x[:n_chk], z[:n_chk]))
+            res[f"check_n{n_chk}_{transport}"] = {"info": info_chk, "nll_block_cyclic": nll_dist, "nll_single_gpu": ref,
+                                                   "rel_diff": abs(nll_dist - ref) / abs(ref)}
+            if not (info_chk == 0 and abs(nll_dist - ref) <= 1e-9 * abs(ref)):
+                raise RuntimeError(f"values check failed ({transport}): info {info_chk}, block-cyclic NLL {nll_dist!r} vs single GPU {ref!r}")
 
     for transport in ("bcast", "p2p"):
         for rep in ("warm", "timed"):
@@ -341,101 +554,134 @@ def dist_potrf_extra(world, rank, res):
     res["phase"] = "done"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size-n", dest="n", type=int, default=32768)
-    ap.add_argument("--size-m", dest="m", type=int, default=50000)
-    ap.add_argument("--dim-d", dest="d", type=int, default=8)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--cpu-m-sample", type=int, default=512, help="prediction points of the CPU baseline's bounded sample")
-    ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] extras")
-    args = ap.parse_args()
+def dist_extra_worker(args):
+    """One rank of the distributed extra's own process group (started by spawn_ranks).  Exit code 0 / 4; a hang is the
+    launcher's business (it kills the group at its time limit)."""
+    world, rank, local_rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
+    if world != args.gpus:
+        sys.stderr.write(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}\n")
+        return 2
+    res = _Progress(args.progress if rank == 0 else None)
+    res.update({"status": "started", "phase": "setup: process group"})
+    try:
+        stub = _stub_module()
+        if stub is not None:
+            import torch.distributed as dist
 
-    import torch
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # GPMP_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one
-    # GPU): the ranks share the GPUs there are.  The measured run is one rank per GPU over nccl (= RCCL).
-    backend = os.environ.get("GPMP_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(torch.cuda.device_count(), 1)
-        os.environ["LOCAL_RANK"] = str(local_rank)       # (gpmp_amd.num picks its device from it)
-    torch.cuda.set_device(local_rank)
-    dist_on = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # launched by torch.distributed.run
-    if dist_on:
-        import torch.distributed as dist
-
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(os.environ.get("GPMP_BENCH_BACKEND", "gloo"))
+            stub.dist_extra(world, rank, res)
         else:
-            dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+            import torch
+            import torch.distributed as dist
 
-    import gpmp_amd as gp
-    import gpmp_amd.num as gnp
-    from gpmp_amd import _lib
-    from gpmp_amd.kernel import MaternCovariance
+            backend = os.environ.get("GPMP_BENCH_BACKEND", "nccl")
+            if backend != "nccl":
+                local_rank %= max(torch.cuda.device_count(), 1)
+                os.environ["LOCAL_RANK"] = str(local_rank)
+            torch.cuda.set_device(local_rank)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+            dist_potrf_extra(world, rank, res)
+        res["status"] = "ok"
+        dist.barrier()
+        dist.destroy_process_group()
+        return 0
+    except BaseException as e:     # noqa: BLE001 -- recorded, then exit code 4 (the peers are ended by the launcher)
+        res["error"] = f"{type(e).__name__}: {e}"[:400]
+        res["status"] = "error"
+        sys.stderr.write(f"[bench dist-extra rank {rank}] {type(e).__name__}: {e}\n")
+        sys.stderr.flush()
+        os._exit(EXIT_ERROR)       # collectives may be wedged: no orderly teardown
 
-    lib = _lib.load()
-    n, m, d = args.n, args.m, args.d
-    xi_h, zi_h, xt_h, theta = synth(n, m, d, rank)
-    xi, zi, xt = gnp.asarray(xi_h), gnp.asarray(zi_h), gnp.asarray(xt_h)   # resident in HBM before timing
-    model = gp.Model(None, MaternCovariance(2), None, theta, "zero")
 
-    def step():
-        zpm, zpv = model.predict(xi, zi, xt, convert_in=False, convert_out=False)
-        nll = model.negative_log_likelihood_zero_mean(theta, xi, zi)
-        return zpm, zpv, nll
+# ------------------------------------------------------------------------------------------------------------------
+# the headline worker (one per GPU)
+# ------------------------------------------------------------------------------------------------------------------
+METRIC = "fp64 predict+NLL throughput (points/s) and potrf TFLOP/s vs roofline, n=32k"
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    import ctypes
+def _stub_module():
+    """GPMP_BENCH_STUB_MODULE=<module>: launcher / process-group tests on machines without a GPU (tests/bench_stub.py).  The
+    module supplies Workload and dist_extra; its line says "data": "stub".  Never set in a measurement."""
+    name = os.environ.get("GPMP_BENCH_STUB_MODULE")
+    if not name:
+        return None
+    import importlib
+
+    return importlib.import_module(name)
+
+
+class HipWorkload:
+    """The measured workload: Model.predict + zero-mean NLL through libgpmp_hip.so, inputs resident in HBM."""
+
+    data = "synthetic"
+
+    def __init__(self, args, rank, world):
+        import torch
+
+        import gpmp_amd as gp
+        import gpmp_amd.num as gnp
+        from gpmp_amd import _lib
+        from gpmp_amd.kernel import MaternCovariance
+
+        self.torch, self.gnp, self.args, self.rank, self.world = torch, gnp, args, rank, world
+        self.lib = _lib.load()
+        n, m, d = args.n, args.m, args.d
+        xi_h, zi_h, xt_h, self.theta = synth(n, m, d, rank)
+        self.xi, self.zi, self.xt = gnp.asarray(xi_h), gnp.asarray(zi_h), gnp.asarray(xt_h)   # resident in HBM before timing
+        self.model = gp.Model(None, MaternCovariance(2), None, self.theta, "zero")
+        self.out = None
+
+    def device(self):
+        return self.gnp._dev()
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def step(self, m=None):
+        xt = self.xt if m is None else self.xt[:m]
+        zpm, zpv = self.model.predict(self.xi, self.zi, xt, convert_in=False, convert_out=False)
+        nll = self.model.negative_log_likelihood_zero_mean(self.theta, self.xi, self.zi)
+        self.out = (zpm, zpv, nll)
+        return self.out
 
     # HIP events on the launch stream around every launch of the DOMINANT kernel only (kind 9: the LDS-direct NN GEMM
     # of the n x m solve, 63 launches per step) inside the timed region; recording every kind (9000 events per step
     # around the small launches of the factorisations) costs 0.8 % of the step, so the other kinds are collected from
-    # one extra, untimed step below.
+    # one extra, untimed step afterwards.
     DOMINANT = 1 << 9
-    if not args.no_kernel_events:
-        lib.gpmp_profile_begin_kinds(DOMINANT)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    table = (ctypes.c_double * 36)()
-    lib.gpmp_profile_end(table)
-    prof_timed = np.array(list(table)).reshape(12, 3)
-    # diagnostics of the other kernels: one untimed step with every kind recorded, scaled to the timed step count
-    lib.gpmp_profile_begin_kinds(0xFFFFFFFF & ~DOMINANT)
-    step()
-    torch.cuda.synchronize()
-    lib.gpmp_profile_end(table)
-    prof = np.array(list(table)).reshape(12, 3) * args.steps
-    prof[9] = prof_timed[9]
 
-    if dist_on:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=gnp._dev())
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed_begin(self):
+        if not self.args.no_kernel_events:
+            self.lib.gpmp_profile_begin_kinds(self.DOMINANT)
 
-    # ---- outside the timed region: the Cholesky alone (BASELINE metric also quotes potrf TFLOP/s)
-    potrf_ms = None
-    if rank == 0:
-        cov = model.covariance
+    def timed_end(self):
+        import ctypes
+
+        table = (ctypes.c_double * 36)()
+        self.lib.gpmp_profile_end(table)
+        prof_timed = np.array(list(table)).reshape(12, 3)
+        # diagnostics of the other kernels: one untimed step with every kind recorded, scaled to the timed step count
+        self.lib.gpmp_profile_begin_kinds(0xFFFFFFFF & ~self.DOMINANT)
+        self.step()
+        self.sync()
+        self.lib.gpmp_profile_end(table)
+        self.prof = np.array(list(table)).reshape(12, 3) * self.args.steps
+        self.prof[9] = prof_timed[9]
+
+    def check(self):
+        zpm, zpv, nll = self.out
+        assert bool(self.torch.isfinite(zpm).all()) and bool((zpv >= 0).all()) and math.isfinite(float(nll))
+
+    def report(self, line):
+        """rank 0: roofline of the dominant kernel + diagnostics, from the events of the timed region"""
+        torch, gnp, args = self.torch, self.gnp, self.args
+        n, m, d, steps = args.n, args.m, args.d, args.steps
+        prof = self.prof
+        # ---- outside the timed region: the Cholesky alone (BASELINE metric also quotes potrf TFLOP/s)
+        cov = self.model.covariance
 
         def _timed(fn, reps=2):
             best = float("inf")
@@ -447,28 +693,20 @@ def main():
                 best = min(best, time.perf_counter() - t_)
             return best
 
-        t_gram = _timed(lambda: cov.gram_lower(xi, theta))
-        t_both = _timed(lambda: gnp.cholesky_factor(cov.gram_lower(xi, theta), overwrite=True))
+        t_gram = _timed(lambda: cov.gram_lower(self.xi, self.theta))
+        t_both = _timed(lambda: gnp.cholesky_factor(cov.gram_lower(self.xi, self.theta), overwrite=True))
         potrf_ms = 1e3 * (t_both - t_gram)
-
-    zpm, zpv, nll = out
-    assert bool(torch.isfinite(zpm).all()) and bool((zpv >= 0).all()) and math.isfinite(float(nll))
-
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = world * m / (elapsed / args.steps)
         # ---- roofline of the dominant kernel: the NN fp64 MFMA GEMM behind the n x m triangular solve.
         # Algorithmic flops routed through it per step: n^2 m for V = L^-1 K(xi, xt)
         # (+ n^2 for the NLL's single right-hand side); launches and time measured with HIP events
         # on the launch stream over the timed region.
-        steps = args.steps
         nn_cnt, nn_ms, nn_exec = prof[9]            # gemm_f64_kernel_v2<AKC=1,BKC=0>: the large trsm updates
         nn1_cnt, nn1_ms, nn1_exec = prof[1]         # register-staged kernel: K < 512 updates, diagonal-block products
         nt_cnt, nt_ms, nt_exec = prof[0] + prof[8]
         alg_solve = (float(n) * n * m + float(n) * n) * steps
         # Every flop of these launches is algorithmic: they are the plain rectangular products B2 -= L21 X1 of the
         # recursive solve (no triangular waste), so executed == algorithmic for THIS kernel.
-        roof = {
+        line["roofline"] = {
             "bound": "mfma", "kernel": "gemm_f64_kernel_v2<true, false, true> (trsm updates B2 -= L21 X1, K >= 512)",
             "achieved": nn_exec / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else None,
             "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -484,7 +722,7 @@ def main():
                             "note": "n^2 m flops of V = L^-1 K(xi,xt) over ALL NN GEMM launches (both kernels)"},
         }
         gram_cnt, gram_ms, gram_bytes = prof[5]
-        extra = {
+        line["extra"].update({
             "potrf": {"n": n, "ms": potrf_ms, "tflops": (float(n) ** 3 / 3.0) / (potrf_ms * 1e-3) / 1e12,
                       "frac_of_fp64_mfma_peak": (float(n) ** 3 / 3.0) / (potrf_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                       "note": "whole factorisation (diagonal blocks + panels + trailing updates), wall time outside the timed region"},
@@ -494,78 +732,172 @@ def main():
             "gram": {"ms_per_step": gram_ms / steps, "GBps_written": gram_bytes / (gram_ms * 1e-3) / 1e9 if gram_ms > 0 else None,
                      "frac_of_hbm_peak": (gram_bytes / (gram_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if gram_ms > 0 else None},
             "coldots": {"ms_per_step": prof[6][1] / steps},
-            "nll": float(nll),
-        }
+            "nll": float(self.out[2]),
+        })
+        threads = _host_threads()
+        if self.world == 1 and not args.no_extras:
+            # configs[1] and configs[3] at their stated sizes, outside the timed region, each beside a same-size CPU figure
+            self.out = None
+            torch.cuda.empty_cache()
+            line["extra"]["config2"] = config2_extra(self.model, d, threads, not args.no_cpu_baseline)
+            line["extra"]["config4"] = config4_extra(threads, not args.no_cpu_baseline)
+        if self.world == 1 and not args.no_cpu_baseline:      # rank 0 at N = 1 only
+            line["cpu_baseline"] = cpu_baseline(n, m, d, threads, m_sample=args.cpu_m_sample)
+            line["extra"]["potrf"]["host_potrf"] = line["cpu_baseline"].pop("host_potrf")
+
+    def release(self):
+        """Drop every device buffer (the distributed extra's processes are about to use this GPU)."""
+        self.out = self.xi = self.zi = self.xt = None
+        self.torch.cuda.empty_cache()
+
+
+def headline_worker(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # never a silent one-rank run that prints "n_gpus": 1 for a --gpus N request
+        sys.stderr.write(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` (self-launching) "
+                         f"or under torch.distributed.run --nproc-per-node {args.gpus}\n")
+        return 2
+    dist_on = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    stub = _stub_module()
+    # GPMP_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one
+    # GPU): the ranks share the GPUs there are.  The measured run is one rank per GPU over nccl (= RCCL).
+    backend = os.environ.get("GPMP_BENCH_BACKEND", "gloo" if stub is not None else "nccl")
+    import torch
+
+    have_gpu = stub is None
+    if have_gpu:
+        if backend != "nccl":
+            local_rank %= max(torch.cuda.device_count(), 1)
+            os.environ["LOCAL_RANK"] = str(local_rank)       # (gpmp_amd.num picks its device from it)
+        torch.cuda.set_device(local_rank)
+    dist = None
+    if dist_on:
+        import torch.distributed as dist
+
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+        assert dist.get_world_size() == world
+
+    wl = (stub.Workload if stub is not None else HipWorkload)(args, rank, world)
+    comm_dev = wl.device() if backend == "nccl" else "cpu"
+
+    def barrier():
+        wl.sync()
+        if dist_on:
+            dist.barrier()
+        wl.sync()
+
+    def max_over_ranks(v):
+        if not dist_on:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    wl.timed_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    wl.timed_end()
+    elapsed = max_over_ranks(elapsed)
+    wl.check()
+
+    # ---- who ran: one PID per rank (evidence that N processes, not one, produced the line)
+    pids = [os.getpid()]
+    if dist_on:
+        pt = torch.zeros(world, dtype=torch.int64, device=comm_dev)
+        pt[rank] = os.getpid()
+        dist.all_reduce(pt, op=dist.ReduceOp.SUM)
+        pids = [int(v) for v in pt.tolist()]
+
+    # ---- strong scaling, outside the timed region: the SAME step with a fixed total of m points split over the ranks
+    #      (K still factored on every rank: 2 potrf + n^2 m / N solve flops per rank)
+    m = args.m
+    strong = None
+    if world > 1:
+        from gpmp_amd.dist.predict import shard_bounds
+
+        lo, hi = shard_bounds(m, world, rank)
+        wl.step(hi - lo)
+        barrier()
+        reps = max(1, min(args.steps, 3))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            wl.step(hi - lo)
+        barrier()
+        t_strong = max_over_ranks(time.perf_counter() - t0) / reps
+        strong = {"m_total": m, "m_per_gpu": [shard_bounds(m, world, r)[1] - shard_bounds(m, world, r)[0] for r in range(world)],
+                  "steps": reps, "ms_per_step": 1e3 * t_strong, "points_per_s": m / t_strong,
+                  "note": "fixed total work: the m points of ONE GPU's headline step split over the ranks, K factored on every rank "
+                          "(Amdahl bound at N = 8: 2 potrf = 372 ms replicated + 763 / N ms of solve)"}
+
+    rc = 0
+    line = None
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * m / (elapsed / args.steps)
+        if strong is None:
+            strong = {"m_total": m, "ms_per_step": ms_per_step, "points_per_s": value, "note": "N = 1: the headline step itself"}
+        n, d = args.n, args.d
         line = {
-            "metric": "fp64 predict+NLL throughput (points/s) and potrf TFLOP/s vs roofline, n=32k",
+            "metric": METRIC,
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": wl.data,
             "config": {"workload": f"d={d} Matern-5/2 anisotropic, n={n} train, m={m} test points per GPU, fp64 "
                                    f"predict (mean+variance) + one zero-mean NLL eval per step",
-                       "n": n, "m_per_gpu": m, "d": d, "parallelism": f"xt-sharded x{world}, K replicated"},
-            "roofline": roof,
-            "extra": extra,
+                       "n": n, "m_per_gpu": m, "d": d,
+                       "parallelism": f"xt-sharded x{world} (m points per rank); K built and factored on EVERY rank (replicated, "
+                                      f"no data-path collective) -- weak scaling is ~N x by construction, see extra.strong_scaling"},
+            "extra": {"worker_pids": pids, "backend": backend if dist_on else None, "strong_scaling": strong},
         }
-        threads = _host_threads()
-        if world == 1 and not args.no_extras:
-            # configs[1] and configs[3] at their stated sizes, outside the timed region, each beside a same-size CPU figure
-            del out, zpm, zpv
-            torch.cuda.empty_cache()
-            extra["config2"] = config2_extra(model, d, threads, not args.no_cpu_baseline)
-            extra["config4"] = config4_extra(threads, not args.no_cpu_baseline)
-            out = zpm = zpv = None
-        if world == 1 and not args.no_cpu_baseline:      # rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(n, m, d, threads, m_sample=args.cpu_m_sample)
-            extra["potrf"]["host_potrf"] = line["cpu_baseline"].pop("host_potrf")
-
-    # ---- N > 1, OPT-IN (GPMP_BENCH_DIST=1; =force also runs it on a 1 x 1 grid): the distributed Cholesky of configs[4]
-    # as an extra after the headline measurement.  Off by default: its RCCL path with more than one rank has not run on
-    # hardware yet (this pool gives one GPU per box), and an unproven collective schedule must not be able to turn the
-    # headline run into a failure.  When it is on, a watchdog bounds it: on a timeout or an error rank 0 still prints
-    # the headline line (with what finished and the phase that was in flight), and then EVERY rank leaves with a
-    # non-zero exit code -- 3 for a timeout, 4 for an error -- so the run is recorded as failed, never as rc 0.
-    dist_env = os.environ.get("GPMP_BENCH_DIST", "0")
-    run_dist = dist_on and dist_env not in ("0", "") and (world > 1 or dist_env == "force")
-    if run_dist:
-        import threading
-
-        res = {"status": "started", "phase": "setup"}
-        done = threading.Lock()
-        EXIT = {"ok": 0, "timeout": 3, "error": 4}
-
-        def finish(status):
-            if not done.acquire(blocking=False):
-                return
-            res["status"] = status
-            if rank == 0:
-                line["extra"]["dist_potrf"] = res
-                print(json.dumps(line), flush=True)
-            if status != "ok":
-                sys.stderr.write(f"[bench rank {rank}] distributed extra: {status} in phase {res.get('phase')!r}"
-                                 f" {res.get('error', '')}\n")
-                sys.stdout.flush()
-                sys.stderr.flush()
-                os._exit(EXIT[status])   # collectives may be wedged: no orderly teardown, and never exit code 0
-
-        wd = threading.Timer(float(os.environ.get("GPMP_BENCH_DIST_TIMEOUT", "240")), finish, args=("timeout",))
-        wd.daemon = True
-        wd.start()
-        out = zpm = zpv = None
-        try:
-            dist_potrf_extra(world, rank, res)
-            wd.cancel()
-            finish("ok")
-        except BaseException as e:     # noqa: BLE001 -- report, then leave with exit code 4 (peers: their own watchdogs, 3)
-            wd.cancel()
-            res["error"] = f"{type(e).__name__}: {e}"[:400]
-            finish("error")
-    elif rank == 0:
-        print(json.dumps(line), flush=True)
+        wl.report(line)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if os.environ.get("GPMP_BENCH_CHILD") == "1":
+            print(json.dumps(line), flush=True)         # under the launcher: it attaches the distributed extra itself
+        else:
+            # N = 1, or started by torch.distributed.run: rank 0 is the coordinator.  It has left its process group and holds no device
+            # buffer any more; the extra runs in N fresh child processes (children are started, nothing is exec'ed).
+            wl.release()
+            rc = finish_with_dist_extra(line, world)
+    return rc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size-n", dest="n", type=int, default=32768)
+    ap.add_argument("--size-m", dest="m", type=int, default=50000)
+    ap.add_argument("--dim-d", dest="d", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--cpu-m-sample", type=int, default=4096, help="prediction points of the CPU baseline's bounded sample")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] extras")
+    ap.add_argument("--role", choices=("auto", "headline", "dist-extra"), default="auto", help="internal: set by the launcher")
+    ap.add_argument("--progress", default=None, help="internal: progress file of the distributed extra")
+    args = ap.parse_args()
+    if args.role == "dist-extra":
+        return dist_extra_worker(args)
+    if args.role == "auto" and args.gpus > 1 and "RANK" not in os.environ:
+        argv = [a for a in sys.argv[1:]]
+        return launcher_main(args, argv)
+    return headline_worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

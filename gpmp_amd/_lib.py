@@ -25,6 +25,7 @@ SIGNATURES = {
     "gpmp_profile_end": (c_int, [_P]),
     "gpmp_stream_create_reserving_cus": (c_int, [c_int, _P]),
     "gpmp_stream_destroy": (c_int, [_P]),
+    "gpmp_stream_release": (c_int, [_P]),
     "gpmp_hint_machine_busy": (c_int, [c_int]),
     "gpmp_matern_gram": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_double, c_int, _P, c_long, _P]),
     "gpmp_matern_pairwise": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P]),

@@ -95,8 +95,11 @@ extern "C" int gpmp_stream_create_reserving_cus(int reserve_cus, gpmp_stream_t* 
   *stream_out = (gpmp_stream_t)st;
   return 0;
 }
+extern "C" int gpmp_stream_release(gpmp_stream_t stream);
 extern "C" int gpmp_stream_destroy(gpmp_stream_t stream) {
-  if (stream != nullptr) GPMP_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  if (stream == nullptr) return 0;
+  if (int rc = gpmp_stream_release(stream)) return rc;      // the per-stream state of the one-launch solve goes with it
+  GPMP_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
   return 0;
 }
 

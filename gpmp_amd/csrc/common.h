@@ -84,7 +84,7 @@ int launch_potf2_inv_batch(double* A, long lda, int jb, double* dinv, int* info_
 // inv(L_kk) of every NB diagonal block of an already factored n x n lower L (one launch).
 int launch_trtri_blocks(const double* L, long ldl, int n, double* dinv, hipStream_t st);
 
-// ---- few right-hand sides (trsv.hip): in-place op(L)^-1 B, m <= 4
+// ---- few right-hand sides (trsv.hip): in-place op(L)^-1 B, m <= TRSV_FEW_MAX (in passes of at most 8 columns)
 constexpr int TRSV_FEW_MAX = 16;      // right-hand sides the HBM-bound sweep takes in one pass
 int trsv_few(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int trans,
              hipStream_t st);

@@ -464,8 +464,25 @@ int solve_status(hipStream_t st, int* status_host) {
   return (int)v;
 }
 
+// Forget `st`: wait for what is queued on it, free its state block, erase its map entries.  Without it the block (16.4 KB)
+// lives until the process ends and a later stream that happens to get the same handle value inherits it (harmless: the
+// state words are zeroed before every solve; only the give-up counter would carry over).  No HIP call when the stream
+// never ran a single-vector solve.
+int stream_release(hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_state_mu);
+  for (auto it = g_states.begin(); it != g_states.end();) {
+    if (it->first.second != st) { ++it; continue; }
+    GPMP_HIP_TRY(hipStreamSynchronize(st));       // a solve of this stream may still be polling the block
+    GPMP_HIP_TRY(hipFree(it->second.words));
+    it = g_states.erase(it);
+  }
+  return 0;
+}
+
 }  // namespace gpmp
 
 extern "C" int gpmp_solve_status(gpmp_stream_t stream, int* status_host) {
   return gpmp::solve_status(gpmp::as_stream(stream), status_host);
 }
+
+extern "C" int gpmp_stream_release(gpmp_stream_t stream) { return gpmp::stream_release(gpmp::as_stream(stream)); }

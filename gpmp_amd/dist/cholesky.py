@@ -188,7 +188,19 @@ class _Streams:
         return torch.cuda.stream(self.main) if self.on else contextlib.nullcontext()
 
     def close(self):
-        """Join the masked stream into the caller's stream and release it."""
+        """Join the masked stream into the caller's stream and release it; hand back what the library keeps for the two
+        side streams (they are created per factorisation: the flag block of the one-launch solve must not pile up)."""
+        lib = self._lib if self._masked is not None else None
+        if self.on:
+            try:
+                from .. import _lib as _l
+
+                lib = _l.load()
+                for s in (self.side, self.diag):
+                    s.synchronize()
+                    lib.gpmp_stream_release(s.cuda_stream)
+            except ImportError:
+                pass
         if self._masked is not None:
             self.caller.wait_stream(self.main)
             self.main.synchronize()          # the stream object goes away: nothing of ours may still be queued on it

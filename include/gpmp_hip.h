@@ -17,7 +17,14 @@
  *  - Callers (the torch allocator) own every matrix, vector and workspace; workspace sizes come from the
  *    gpmp_*_ws_* / gpmp_dinv_elems queries.  The library itself allocates only the 16.4 KB flag block of the one-launch
  *    triangular solve, once per (device, stream) that uses it (see gpmp_solve_status), plus host-side helper streams /
- *    events.  One device per process and one calling thread at a time per stream.
+ *    events.  Lifetime of that block: from the stream's first single-vector solve until gpmp_stream_release(stream)
+ *    (or gpmp_stream_destroy for the library's own streams) -- a caller that creates and destroys streams calls
+ *    gpmp_stream_release before destroying one; otherwise the block stays allocated until the process ends (16.4 KB per
+ *    stream ever used) and a later stream with the same handle value reuses it (harmless: it is zeroed before every solve).
+ *  - ONE DEVICE PER PROCESS (the launch model is one process per GPU): the helper streams and events of the look-ahead
+ *    factorisation are created on the device of the first call, and a call made with another current device returns -1
+ *    with a message.  A host that drives several GPUs from one process starts one worker process per GPU, each loading
+ *    the library.  One calling thread at a time per stream.
  *  - covparam layout (gpmp/kernel/matern.py:78-79,88-89): theta = [log sigma^2, log(1/rho_1..d)];
  *    with `noise` != 0 the layout is [log sigma^2, log sigma_noise^2, log(1/rho_1..d)]
  *    (examples/gpmp_example07_nd_regression.py:95-131).
@@ -136,6 +143,11 @@ int gpmp_trsm_lower(const double* L, int n, long ldl, const double* dinv, double
  * returns it (0 = every solve on this stream completed; < 0: HIP error).  The flag block (16.4 KB) is the one piece of
  * device memory the library allocates itself: one per (device, stream) that has run such a solve, on first use. */
 int gpmp_solve_status(gpmp_stream_t stream, int* status_host);
+/* Releases what the library holds for `stream` (today: that flag block): waits for the work queued on the stream -- the
+ * one entry point besides gpmp_solve_status / gpmp_profile_end that synchronises -- frees the block and forgets the
+ * stream.  0 when the stream holds nothing (no HIP call is made then).  Call it before destroying a stream that ran
+ * single-vector solves; a later solve on the same handle simply allocates a fresh block. */
+int gpmp_stream_release(gpmp_stream_t stream);
 
 /* B <- B L^-T for an M x k row-major B and a k x k lower-triangular L (right-side solve: the panel step
  * A21 <- A21 inv(L11)^T of a blocked / distributed Cholesky).  dinv as produced by gpmp_potrf_lower_async

@@ -75,6 +75,10 @@ assert lib.gpmp_profile_begin() == 0
 tab = (ctypes.c_double * 36)()
 assert lib.gpmp_profile_end(tab) == 0 and sum(tab) == 0.0
 assert lib.gpmp_hint_machine_busy(1) == 0 and lib.gpmp_hint_machine_busy(0) == 1
+# stream bookkeeping: releasing / destroying a stream the library holds nothing for is a no-op that makes no HIP call
+for h in (None, ctypes.c_void_p(0x1000), ctypes.c_void_p(0x1000)):
+    assert lib.gpmp_stream_release(h) == 0
+assert lib.gpmp_stream_destroy(None) == 0
 print("ASAN-CHILD-OK")
 '''
 

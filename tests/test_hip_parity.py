@@ -454,6 +454,41 @@ def test_single_vector_solves_eight_streams_in_flight(gnp):
         assert torch.equal(got, refs[s % 4][1 if s >= 4 else 0]), s
 
 
+def test_stream_release_frees_the_solve_state_and_a_later_solve_starts_afresh(gnp):
+    """gpmp_stream_release: the per-stream flag block of the one-launch solve is freed, releasing twice / releasing a stream
+    that never solved is a no-op, and a solve issued on the same stream afterwards allocates a fresh block and returns the
+    same bits (a use-after-free of the block would show as a fault or a given-up solve)"""
+    import ctypes
+    import torch
+    from gpmp_amd import _lib
+    from oracle import gp_oracle as orc
+
+    lib = _lib.load()
+    rng = np.random.default_rng(18)
+    n = 1700
+    x = rng.random((n, 3))
+    K = orc.maternp_covariance(x, None, 2, np.array([0.0, 1.0, 0.7, 1.3])) + 1e-5 * np.eye(n)
+    F = gnp.cholesky_factor(gnp.asarray(K))
+    z = gnp.asarray(rng.standard_normal((n, 2)))
+    ref = F.solve_lower(z).clone()
+    torch.cuda.synchronize()
+    st, idle = torch.cuda.Stream(), torch.cuda.Stream()
+    h = ctypes.c_void_p(st.cuda_stream)
+    assert lib.gpmp_stream_release(ctypes.c_void_p(idle.cuda_stream)) == 0       # holds nothing
+    with torch.cuda.stream(st):
+        st.wait_stream(torch.cuda.current_stream())
+        a = F.solve_lower(z)
+        # released while the solve may still be running: the call waits for the stream before it frees the block
+        assert lib.gpmp_stream_release(h) == 0 and lib.gpmp_stream_release(h) == 0
+        b = F.solve_lower(z, trans=False)
+        for _ in range(3):                                                         # release / re-create a few times in a row
+            assert lib.gpmp_stream_release(h) == 0
+            c = F.solve_lower(z)
+    st.synchronize()
+    assert torch.equal(a, ref) and torch.equal(b, ref) and torch.equal(c, ref)
+    assert lib.gpmp_solve_status(h, None) == 0 and lib.gpmp_stream_release(h) == 0
+
+
 @pytest.mark.parametrize("strip", [16, 32, 64, 128])
 @pytest.mark.parametrize("n,m", [(1536, 700), (2048, 1024), (1280, 514), (1500, 900)])
 def test_forward_solve_many_rhs_fused_leaves(gnp, n, m, strip, monkeypatch):
