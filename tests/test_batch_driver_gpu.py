@@ -95,6 +95,42 @@ def test_batch_driver_ragged_sizes_shared_parameters(env, sizes, q):
         assert rel_err(grads[b], g) < tol_g, (b, grads[b], g)
 
 
+def _cond_scale(K):
+    """max(1, cond(K) / 1e6): the factor by which the SURVEY 8(c) tolerances grow with the conditioning (measured, host eigenvalues)"""
+    ev = np.linalg.eigvalsh(K)
+    return max(1.0, float(ev[-1] / max(ev[0], 1e-300)) / 1e6)
+
+
+@pytest.mark.parametrize("noise", [0, 1])
+@pytest.mark.parametrize("q", [0, 1, 3])
+@pytest.mark.parametrize("sizes", [(2048, 1300, 1537), (300, 128, 77, 257)])
+def test_batch_driver_against_the_oracle_at_its_edges(env, sizes, q, noise):
+    """the batched kernel against the CPU ORACLE (not against another HIP driver): ragged slots up to the 2048-point limit,
+    q = 0 (ML: likelihood.py:18-52) and q = 1, 3 (REML: likelihood.py:92-129), values and analytic gradients, with the
+    SURVEY 8(c) tolerances (value rel 1e-12, gradient rel 1e-8) scaled by the MEASURED cond(K) / 1e6 of each problem;
+    noise = 1 adds a 1e-4 noise variance (cond ~ 5e6), noise = 0 is the bare kernel (cond up to 5e8 at n = 2048)"""
+    from oracle import gp_oracle as orc
+
+    d = 3
+    th = np.concatenate(([0.2], -np.log(0.3 + 0.2 * np.arange(d))))
+    if noise:
+        th = np.concatenate(([th[0], math.log(1e-4)], th[1:]))
+    data = [_data(n, d, 100 + n + k) for k, n in enumerate(sizes)]
+    xs, zs = [a for a, _ in data], [b for _, b in data]
+    Ps = None if q == 0 else [np.hstack((np.ones((len(x), 1)), x))[:, :q] for x in xs]
+    vals, grads, info = _batch(env, xs, zs, Ps, th, shared=True, noise=noise)
+    assert np.all(info == 0)
+    cov = orc.noisy_maternp_covariance if noise else orc.maternp_covariance
+    for b, n in enumerate(sizes):
+        cs = _cond_scale(cov(xs[b], None, 2, th))
+        if q == 0:
+            v, g = orc.nll_zero_mean_value_and_grad(xs[b], zs[b], 2, th, noise_index=1 if noise else None)
+        else:
+            v, g = orc.reml_value_and_grad(xs[b], zs[b], Ps[b], 2, th, noise_index=1 if noise else None)
+        assert abs(vals[b] - v) <= 1e-12 * cs * max(abs(v), n), (b, n, cs, vals[b], v)
+        assert rel_err(grads[b], g) <= 1e-8 * cs, (b, n, cs, grads[b], g)
+
+
 def test_batch_driver_many_parameter_vectors_one_data_set(env):
     """the sampler pattern: stride 0 on the data, one parameter row per problem; noisy kernel"""
     torch, gnp, _lib, lib = env

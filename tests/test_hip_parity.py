@@ -322,7 +322,12 @@ def test_factor_and_solve_in_one_call(gnp, n, m):
         assert rel_err(L1 @ gnp.to_np(V1), B) < 1e-9
     # the factor object returned by the fused call serves further solves
     z = rng.standard_normal(n)
-    assert rel_err(gnp.to_np(F1.solve(gnp.asarray(z))), gnp.to_np(F0.solve(gnp.asarray(z)))) < 1e-10     # (cond(K) ~ 1e6)
+    # two routes to K^-1 z whose factors differ in the last bits (n <= 2048): the solutions may differ by O(cond(K) eps) --
+    # a MEASURED bound (host eigenvalues), not a fixed one: 5 eps cond(K) (cond ~ 1e6 here, i.e. about 1e-9)
+    ev = np.linalg.eigvalsh(K)
+    cond = float(ev[-1] / ev[0])
+    assert 1e4 < cond < 1e8, cond
+    assert rel_err(gnp.to_np(F1.solve(gnp.asarray(z))), gnp.to_np(F0.solve(gnp.asarray(z)))) < 5.0 * np.finfo(np.float64).eps * cond, cond
 
 
 @pytest.mark.parametrize("n", [100, 129, 300, 1000, 1500, 2049, 3333, 5000])
