@@ -284,6 +284,11 @@ class BlockCyclicCholesky:
         self.info = 0
         self.diag_cache = {}     # k -> (L_kk, dinv) on the ranks of the owning process column
         self.bytes_received = 0
+        # issue log (tests, tools/dist_issue_order.py): when a list, every collective this rank enqueues is appended as
+        # (communicator tag, operation, root rank, doubles, step label, stream role) in HOST ISSUE ORDER -- the order RCCL
+        # sees.  RCCL needs the per-communicator sequences to be identical on all members of a communicator.
+        self.oplog = None
+        self._step_label = None
 
     # ---- index helpers
     def bs(self, I: int) -> int:
@@ -341,12 +346,37 @@ class BlockCyclicCholesky:
         self.A = A_local
 
     # ---- communication helpers
+    def _comm_tag(self, group) -> str:
+        g = self.grid
+        if group is g.row_group:
+            return f"row{g.r}"
+        if group is g.col_group:
+            return f"col{g.c}"
+        if group is g.diag_col_group:
+            return f"diag{g.c}"
+        return "world"
+
+    def _stream_role(self) -> str:
+        st = self._st
+        if st is None or not st.on:
+            return "host"
+        cur = torch.cuda.current_stream()
+        return "diag" if cur == st.diag else "side" if cur == st.side else "main" if cur == st.main else "caller"
+
+    def _log(self, group, op: str, root: int, numel: int):
+        if self.oplog is not None:
+            self.oplog.append((self._comm_tag(group), op, int(root), int(numel), self._step_label, self._stream_role()))
+
     def _bcast(self, t: torch.Tensor, src_rank: int, group, members: List[int]) -> torch.Tensor:
         """Root ``src_rank`` -> every rank of ``members`` (``t`` allocated with the same shape everywhere).  Enqueued on
-        the current stream with RCCL; blocking with gloo."""
+        the current stream with RCCL; blocking with gloo.  ONE message = ONE call = (p2p transport) ONE send/recv group: the
+        root's group holds exactly the sends of this message to its peers, a peer's group exactly its one receive, so the
+        k-th group a peer issues on a communicator always pairs with the k-th group of that communicator's root of the
+        moment -- messages of different steps can never be matched with each other."""
         ct = _comm_tensor(t, self.backend)
         me = self.grid.rank
         if self.transport == "p2p":
+            self._log(group, "p2p_bcast", src_rank, ct.numel())
             if me == src_rank:
                 reqs = [dist.P2POp(dist.isend, ct, peer, group) for peer in members if peer != src_rank]
             else:
@@ -354,11 +384,17 @@ class BlockCyclicCholesky:
             for w in (dist.batch_isend_irecv(reqs) if reqs else []):
                 w.wait()
         else:
+            self._log(group, "broadcast", src_rank, ct.numel())
             dist.broadcast(ct, src=src_rank, group=group)
         if me != src_rank:
             self.bytes_received += ct.numel() * 8
         if ct.data_ptr() != t.data_ptr():
             t.copy_(ct)
+        return t
+
+    def _all_reduce(self, t: torch.Tensor, op, group, what: str):
+        self._log(group, f"all_reduce:{what}", -1, t.numel())
+        dist.all_reduce(t, op=op, group=group)
         return t
 
     # ---- factorisation
@@ -394,6 +430,7 @@ class BlockCyclicCholesky:
         rd, cd = g.owner_row(k), g.owner_col(k)
         bk = self.bs(k)
         in_col = g.c == cd
+        self._step_label = f"panel{k}"
         i0, j0 = self._first_row_after(k), self._first_col_after(k)
         Mr = self.roff[-1] - self.roff[i0]
         Nc = self.coff[-1] - self.coff[j0]
@@ -410,6 +447,7 @@ class BlockCyclicCholesky:
                 Lkk, dinv = self._diagonal_block(k, rd, cd, bk, col_members)
 
         # 3. panel solve on the owning process column, 4. broadcast along the process row
+        self._step_label = f"panel{k}"
         panel = self._panel_buf[k % 2][:Mr, :bk]
         if in_col and Mr > 0:
             lj = k // g.pc
@@ -454,6 +492,7 @@ class BlockCyclicCholesky:
 
     def _diagonal_block(self, k, rd, cd, bk, col_members):
         g, ops, A = self.grid, self.ops, self.A
+        self._step_label = f"diag{k}"
         ldk = (bk + 15) // 16 * 16
         ndinv = ((bk + 127) // 128) * 128 * 128
         dbuf = self._flat(bk * ldk + ndinv + 1)
@@ -628,7 +667,8 @@ class BlockCyclicCholesky:
                 break
         it = torch.tensor([mine], dtype=torch.float64)
         it = it.to("cuda") if self.backend == "nccl" else it
-        dist.all_reduce(it, op=dist.ReduceOp.MIN, group=g.world_group)
+        self._step_label = "info"
+        self._all_reduce(it, dist.ReduceOp.MIN, g.world_group, "info")
         self.info = 0 if math.isinf(float(it.item())) else int(it.item())
         return self.info
 
@@ -642,7 +682,8 @@ class BlockCyclicCholesky:
                 s += ops.sum_log_diag(self.diag_cache[k][0])
         t = torch.tensor([2.0 * s], dtype=torch.float64)
         t = t.to("cuda") if self.backend == "nccl" else t
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=g.world_group)
+        self._step_label = "logdet"
+        self._all_reduce(t, dist.ReduceOp.SUM, g.world_group, "logdet")
         return float(t.item())
 
     def solve_lower_vector(self, z):
@@ -661,6 +702,8 @@ class BlockCyclicCholesky:
                 Lkk, dinv = self.diag_cache[k]
                 wk = ops.solve_lower_vec(Lkk, dinv, ops.asarray(w[k0:k0 + bk])).to(dev)
             wk = wk.contiguous()
+            self._step_label = f"vec{k}"
+            self._log(g.world_group, "broadcast", g.rank_of(rd, cd), wk.numel())
             dist.broadcast(wk, src=g.rank_of(rd, cd), group=g.world_group)
             w[k0:k0 + bk] = wk
             rest = self.n - (k0 + bk)
@@ -674,58 +717,133 @@ class BlockCyclicCholesky:
                     P = self.A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]]
                     upd = ops.matvec(P, ops.asarray(wk)).to(dev)
                     delta[gri[self.roff[i0]:] - (k0 + bk)] = upd
-            dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=g.world_group)
+            self._all_reduce(delta, dist.ReduceOp.SUM, g.world_group, "vec_update")
             w[k0 + bk:] -= delta
         return w
 
     # ---- many right-hand sides on the distributed factor (prediction beyond one GPU's HBM)
-    def solve_lower_many(self, Bloc: torch.Tensor) -> torch.Tensor:
+    def solve_lower_many(self, Bloc: torch.Tensor, overlap: Optional[bool] = None, profile: Optional[bool] = None) -> torch.Tensor:
         """V = L^-1 B in place for a right-hand side laid out like the factor's rows: ``Bloc`` holds the block rows this
         process row owns (self.local_rows() x m_c) of THIS process column's shard of the columns of B (the columns of B are
         split over the process columns, gpmp_amd.dist.shard_bounds(m, Pc, c)).  Per block column k:
-          1. L_kk (+ its diagonal-block inverses) travels along process row k mod Pr      [one broadcast, nb^2]
-          2. the ranks of that process row solve X_k = L_kk^-1 B_k for their column shard   [local]
-          3. X_k travels down every process column                                          [nb x m_c per column]
-          4. the panel L_{I>k, k} travels along every process row; B_I -= L_Ik X_k          [panel broadcast + local GEMM]
-        n^2 m flops spread evenly over the grid; the panel broadcasts are the ones of the factorisation again."""
+          P(k)  prefetch: L_kk (+ its diagonal-block inverses) travels along process row k mod Pr, then the panel
+                L_{I>k, k} along every process row                                     [row communicators; factor data only]
+          C(k)  chain:    on process row k mod Pr: B_k -= L_{k,k-1} X_{k-1} (the ONE block row the next solve needs),
+                X_k = L_kk^-1 B_k; X_k travels down every process column                 [column communicators]
+          U(k)  update:   B_I -= L_Ik X_k for the block rows I > k+1 this rank owns       [local GEMM, n^2 m flops in total]
+        Schedule (the factorisation's look-ahead pattern on the same three streams): while U(k) runs on the caller's
+        stream, P(k+1) runs on the prefetch stream and C(k+1) on the side stream -- the broadcasts of step k+1 and the small
+        products on the critical path are hidden behind the bulk GEMM of step k; two buffers per message kind.  Every
+        communicator is used from ONE stream (row communicators: prefetch stream, column communicators: side stream) and in
+        the same order on all of its members.  ``overlap=False`` (GPMP_DIST_SOLVE_OVERLAP=0) issues the same operations in
+        the same order on the caller's stream alone."""
         g, ops, nb = self.grid, self.ops, self.nb
+        if overlap is None:
+            overlap = os.environ.get("GPMP_DIST_SOLVE_OVERLAP", "1") != "0"
+        if profile is not None:
+            self.profile = profile
         mloc = Bloc.shape[1]
+        nblk = self.nblocks
         row_members = [g.rank_of(g.r, cc) for cc in range(g.pc)]
         col_members = [g.rank_of(rr, g.c) for rr in range(g.pr)]
-        for k in range(self.nblocks):
-            rd, cd = g.owner_row(k), g.owner_col(k)
+        nbk = self.bs(0)
+        ld0 = (nbk + 15) // 16 * 16
+        nd0 = ((nbk + 127) // 128) * 128 * 128
+        Lbuf = [self._flat(nbk * ld0 + nd0) for _ in range(2)]
+        Pbuf = [ops.empty(self.local_rows(), nb) for _ in range(2)]
+        Xbuf = [ops.empty(nb, mloc) for _ in range(2)]
+        self._marks = []
+        st = self._st = _Streams(getattr(ops, "device", None) if overlap else None, 0, getattr(ops, "lib", None))
+        pre_ctx, side_ctx = st.diag_ctx, st.side_ctx          # the "diagonal" stream of the factorisation carries the prefetch here
+        start = st.record(False)
+        l_ready, p_ready, x_ready, u_done = {}, {}, {}, {}
+
+        def views(k):
             bk = self.bs(k)
             ldk = (bk + 15) // 16 * 16
             ndinv = ((bk + 127) // 128) * 128 * 128
-            xk = ops.empty(bk, mloc)
-            if g.r == rd:
-                dbuf = self._flat(bk * ldk + ndinv)
-                Lkk = dbuf[: bk * ldk].view(bk, ldk)[:, :bk]
-                dinv = dbuf[bk * ldk:]
-                if g.c == cd:
-                    L0, d0 = self.diag_cache[k]
-                    Lkk.copy_(L0)
-                    dinv.copy_(d0[:ndinv])
-                if g.pc > 1:
-                    self._bcast(dbuf, g.rank_of(rd, cd), g.row_group, row_members)
-                li = k // g.pr
-                Bk = Bloc[self.roff[li]:self.roff[li + 1]]
-                if mloc:
-                    ops.trsm_left(Lkk, dinv, Bk)
-                    xk.copy_(Bk)
-            if g.pr > 1 and mloc:
-                self._bcast(xk, g.rank_of(rd, g.c), g.col_group, col_members)
+            buf = Lbuf[k % 2][: bk * ldk + ndinv]
+            return bk, buf, buf[: bk * ldk].view(bk, ldk)[:, :bk], buf[bk * ldk:]
+
+        def prefetch(k):
+            rd, cd = g.owner_row(k), g.owner_col(k)
+            bk, buf, Lkk, dinv = views(k)
+            self._step_label = f"solve_pre{k}"
+            with pre_ctx():
+                st.wait_diag(start)
+                st.wait_diag(x_ready.get(k - 1))     # C(k-1) has read L buffer (k-2) and panel k-2
+                st.wait_diag(u_done.get(k - 2))      # U(k-2) has read panel k-2
+                with self._phase("solve_prefetch"):
+                    if g.r == rd:
+                        if g.c == cd:
+                            L0, d0 = self.diag_cache[k]
+                            Lkk.copy_(L0)
+                            dinv.copy_(d0[: dinv.numel()])
+                        if g.pc > 1:
+                            self._bcast(buf, g.rank_of(rd, cd), g.row_group, row_members)
+                    l_ready[k] = st.record_diag()
+                    i0 = self._first_row_after(k)
+                    Mr = self.roff[-1] - self.roff[i0]
+                    if Mr > 0:
+                        panel = Pbuf[k % 2][:Mr, :bk]
+                        if g.c == cd:
+                            lj = k // g.pc
+                            panel.copy_(self.A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]])
+                        if g.pc > 1:
+                            self._bcast(panel, g.rank_of(g.r, cd), g.row_group, row_members)
+                    p_ready[k] = st.record_diag()
+
+        def chain(k):
+            rd = g.owner_row(k)
+            bk, buf, Lkk, dinv = views(k)
+            xk = Xbuf[k % 2][:bk]
+            self._step_label = f"solve_chain{k}"
+            with side_ctx():
+                st.wait(True, start)
+                st.wait(True, l_ready.get(k))
+                st.wait(True, p_ready.get(k - 1))
+                st.wait(True, u_done.get(k - 2))     # block row k has received the updates 0 ... k-2, X buffer (k-2) is free
+                with self._phase("solve_chain"):
+                    if g.r == rd and mloc:
+                        li = k // g.pr
+                        Bk = Bloc[self.roff[li]:self.roff[li + 1]]
+                        if k > 0:
+                            # update k-1 of this ONE block row (the bulk update k-1 skips it): first row of panel k-1
+                            bp = self.bs(k - 1)
+                            ip = self._first_row_after(k - 1)
+                            off = self.roff[li] - self.roff[ip]
+                            ops.gemm_nn_sub(Bk, Pbuf[(k - 1) % 2][off: off + bk, :bp], Xbuf[(k - 1) % 2][:bp])
+                        ops.trsm_left(Lkk, dinv, Bk)
+                        xk.copy_(Bk)
+                    if g.pr > 1 and mloc:
+                        self._bcast(xk, g.rank_of(rd, g.c), g.col_group, col_members)
+                x_ready[k] = st.record(True)
+
+        def update(k):
+            bk = self.bs(k)
             i0 = self._first_row_after(k)
-            Mr = self.roff[-1] - self.roff[i0]
-            if Mr > 0:
-                panel = ops.empty(Mr, bk)
-                if g.c == cd:
-                    lj = k // g.pc
-                    panel.copy_(self.A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]])
-                if g.pc > 1:
-                    self._bcast(panel, g.rank_of(g.r, cd), g.row_group, row_members)
-                if mloc:
-                    ops.gemm_nn_sub(Bloc[self.roff[i0]:], panel, xk)
+            i1 = self._first_row_after(k + 1)           # block row k+1 (if owned) is updated by C(k+1)
+            self._step_label = f"solve_update{k}"
+            st.wait(False, x_ready.get(k))
+            st.wait(False, p_ready.get(k))
+            with st.main_ctx(), self._phase("solve_update"):
+                if mloc and self.roff[-1] - self.roff[i1] > 0:
+                    off = self.roff[i1] - self.roff[i0]
+                    ops.gemm_nn_sub(Bloc[self.roff[i1]:], Pbuf[k % 2][off: self.roff[-1] - self.roff[i0], :bk], Xbuf[k % 2][:bk])
+            u_done[k] = st.record(False)
+
+        prefetch(0)
+        chain(0)
+        for k in range(nblk):
+            if k + 1 < nblk:
+                prefetch(k + 1)
+                chain(k + 1)
+            update(k)
+            for evs in (l_ready, p_ready, x_ready, u_done):      # keep three steps of events
+                evs.pop(k - 3, None)
+        st.wait(False, x_ready.get(nblk - 1))
+        st.wait(False, p_ready.get(nblk - 1))
+        st.close()
         return Bloc
 
     def predict_zero_mean(self, cov, x, z, xt, covparam):
@@ -758,7 +876,8 @@ class BlockCyclicCholesky:
             mean_p, ssq_p = ops.coldots(V, wloc)
             part[0], part[1] = mean_p.to(dev), ssq_p.to(dev)
         if g.pr > 1:
-            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=g.col_group)
+            self._step_label = "predict_reduce"
+            self._all_reduce(part, dist.ReduceOp.SUM, g.col_group, "mean_var")
         prior = ops.pairwise_variance(cov, xtc, covparam).to(dev) if j1 > j0 else part[1]
         return part[0].cpu().numpy(), (prior - part[1]).cpu().numpy(), (j0, j1)
 

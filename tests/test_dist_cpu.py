@@ -248,3 +248,67 @@ def test_grid_shapes():
     assert ProcessGrid.default_shape(4) == (2, 2)
     assert ProcessGrid.default_shape(2) == (1, 2)
     assert ProcessGrid.default_shape(1) == (1, 1)
+
+
+def _oplog_worker(rank, world, port, pr, pc, n, m, nb, out, transport, lookahead):
+    _init(rank, world, port)
+    try:
+        from gpmp_amd.dist import BlockCyclicCholesky, ProcessGrid
+        from tests.cpu_local_ops import CpuLocalOps
+
+        x, z = make_xz(n, 3, 7)
+        xt, _ = make_xz(m, 3, 8)
+        th = theta_aniso(3, scale=0.4)
+        grid = ProcessGrid(pr, pc)
+        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=CpuLocalOps(), transport=transport, lookahead=lookahead)
+        ch.oplog = []
+        ch.build_local_gram(_cov, x, th, 1e-6)
+        assert ch.factor() == 0
+        ch.negative_log_likelihood(z)
+        ch.predict_zero_mean(_cov_full, x, z, xt, th)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (grid.r, grid.c, ch.oplog))
+        if rank == 0:
+            import pickle
+
+            with open(out, "wb") as f:
+                pickle.dump(gathered, f)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("transport", ["bcast", "p2p"])
+@pytest.mark.parametrize("lookahead", [True, False])
+def test_issue_order_is_identical_on_all_members_of_every_communicator(tmp_path, transport, lookahead):
+    """What RCCL needs when several communicators are live on one device: every member of a communicator issues the SAME
+    sequence of operations on it (same kind, root, size, step).  The schedule logs (communicator, operation, root, doubles,
+    step) in host issue order on every rank of the 2 x 4 grid of BASELINE config 5 -- factorisation, NLL and the
+    many-right-hand-side solve, look-ahead on and off, both transports -- and the per-communicator sequences are compared
+    across the members.  Also: the four kinds of communicator are all exercised, a p2p "broadcast" is one message per
+    send/recv group, and ranks that own nothing in a step still take part in the collectives of their communicators."""
+    import pickle
+
+    pr, pc, n, m, nb = 2, 4, 1900, 403, 128
+    out = str(tmp_path / "log.pkl")
+    mp.spawn(_oplog_worker, args=(pr * pc, _free_port(), pr, pc, n, m, nb, out, transport, lookahead), nprocs=pr * pc, join=True)
+    with open(out, "rb") as f:
+        gathered = pickle.load(f)
+    per_comm = {}
+    for (r, c, log) in gathered:
+        assert log, "every rank communicates"
+        for tag in {e[0] for e in log}:
+            per_comm.setdefault(tag, []).append(((r, c), [e[:5] for e in log if e[0] == tag]))
+    expect_members = {**{f"row{r}": pc for r in range(pr)}, **{f"col{c}": pr for c in range(pc)},
+                      **{f"diag{c}": pr for c in range(pc)}, "world": pr * pc}
+    assert set(per_comm) == set(expect_members)
+    for tag, seqs in per_comm.items():
+        assert len(seqs) == expect_members[tag], (tag, [who for who, _ in seqs])      # every member issued on it
+        first = seqs[0][1]
+        assert len(first) > 0
+        for who, seq in seqs[1:]:
+            assert seq == first, (tag, who, next((a, b) for a, b in zip(seq, first) if a != b) if len(seq) == len(first) else (len(seq), len(first)))
+    kinds = {e[1] for _, _, log in gathered for e in log}
+    assert ("p2p_bcast" in kinds) == (transport == "p2p") and ("broadcast" in kinds)     # (the NLL's vector solve always broadcasts)
+    # the roots rotate as the block-cyclic layout says: row communicator r sees every process column as a root
+    roots = {e[2] for e in per_comm["row0"][0][1]}
+    assert roots == set(range(pc))

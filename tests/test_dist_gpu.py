@@ -103,7 +103,7 @@ def _run_and_check(tmp_path, pr, pc, n, nb, transport, lookahead, backend):
     assert abs(nll - ref) < 1e-8 * abs(ref)
 
 
-def _predict_worker(rank, world, port, pr, pc, n, m, nb, out, transport):
+def _predict_worker(rank, world, port, pr, pc, n, m, nb, out, transport, overlap=True):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
@@ -120,9 +120,21 @@ def _predict_worker(rank, world, port, pr, pc, n, m, nb, out, transport):
         cov = MaternCovariance(2)
         grid = ProcessGrid(pr, pc)
         ch = BlockCyclicCholesky(grid, n, nb=nb, ops=HipLocalOps(), transport=transport)
+        ch.oplog = []
         ch.build_local_gram(cov, x, th, 10.0 * math.exp(th[0]) * gnp.eps)
         assert ch.factor() == 0
+        os.environ["GPMP_DIST_SOLVE_OVERLAP"] = "1" if overlap else "0"
         mean, var, (j0, j1) = ch.predict_zero_mean(cov, x, z, xt, th)
+        # every communicator is driven from ONE stream per phase (what keeps RCCL's per-communicator streams independent):
+        # factorisation: row / column communicators from the side stream, the diagonal-block communicator from the diagonal
+        # stream; many-right-hand-side solve: row communicators from the prefetch (= diagonal) stream, column from the side
+        for (tag, op, root, numel, step, role) in ch.oplog:
+            if step.startswith(("panel", "diag")):
+                assert role == ("diag" if tag.startswith("diag") else "side"), (tag, step, role)
+            elif step.startswith("solve_pre"):
+                assert tag.startswith("row") and role == ("diag" if overlap else "caller"), (tag, step, role)
+            elif step.startswith("solve_chain"):
+                assert tag.startswith("col") and role == ("side" if overlap else "caller"), (tag, step, role)
         gathered = [None] * world
         dist.all_gather_object(gathered, (grid.r, j0, j1, mean, var))
         if rank == 0:
@@ -135,17 +147,20 @@ def _predict_worker(rank, world, port, pr, pc, n, m, nb, out, transport):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("pr,pc,n,m,nb,transport", [(1, 1, 1500, 700, 512, "bcast"), (2, 2, 2000, 901, 256, "bcast"), (1, 2, 1500, 333, 256, "p2p")])
-def test_block_cyclic_predict_hip(tmp_path, pr, pc, n, m, nb, transport):
+@pytest.mark.parametrize("pr,pc,n,m,nb,transport,overlap", [(1, 1, 1500, 700, 512, "bcast", True), (2, 2, 2000, 901, 256, "bcast", True),
+                                                            (1, 2, 1500, 333, 256, "p2p", True), (2, 2, 2000, 901, 256, "p2p", False),
+                                                            (2, 2, 3100, 1201, 256, "bcast", True), (2, 1, 2304, 513, 256, "bcast", True)])
+def test_block_cyclic_predict_hip(tmp_path, pr, pc, n, m, nb, transport, overlap):
     """many-right-hand-side solve on the block-cyclic factor with the real kernels (ranks share the test GPU over gloo):
-    posterior mean / variance against the oracle's predict"""
+    posterior mean / variance against the oracle's predict; with the prefetch / chain / update streams overlapped (default)
+    and in program order on one stream"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
 
     world = pr * pc
     out = str(tmp_path / "p.npy")
-    mp.spawn(_predict_worker, args=(world, _free_port(), pr, pc, n, m, nb, out, transport), nprocs=world, join=True)
+    mp.spawn(_predict_worker, args=(world, _free_port(), pr, pc, n, m, nb, out, transport, overlap), nprocs=world, join=True)
     got = np.load(out)
     x, z = make_xz(n, 4, 11)
     xt, _ = make_xz(m, 4, 12)
