@@ -132,9 +132,9 @@ def _predict_worker(rank, world, port, pr, pc, n, m, nb, out, transport, overlap
             if step.startswith(("panel", "diag")):
                 assert role == ("diag" if tag.startswith("diag") else "side"), (tag, step, role)
             elif step.startswith("solve_pre"):
-                assert tag.startswith("row") and role == ("diag" if overlap else "caller"), (tag, step, role)
+                assert tag.startswith("row") and role == ("diag" if overlap else "host"), (tag, step, role)
             elif step.startswith("solve_chain"):
-                assert tag.startswith("col") and role == ("side" if overlap else "caller"), (tag, step, role)
+                assert tag.startswith("col") and role == ("side" if overlap else "host"), (tag, step, role)
         gathered = [None] * world
         dist.all_gather_object(gathered, (grid.r, j0, j1, mean, var))
         if rank == 0:

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--coords", default="0,0")
     ap.add_argument("--no-lookahead", action="store_true")
     ap.add_argument("--reserve-cus", type=int, default=None)
+    ap.add_argument("--solve-m", type=int, default=0, help="also time the many-right-hand-side solve for this many prediction points "
+                    "(split over the process columns), with and without the prefetch / chain / update overlap")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -43,7 +45,7 @@ def main():
     r, c = (int(v) for v in a.coords.split(","))
     grid = ProcessGrid.__new__(ProcessGrid)
     grid.world, grid.rank, grid.pr, grid.pc, grid.r, grid.c = pr * pc, r * pc + c, pr, pc, r, c
-    grid.row_groups, grid.col_groups, grid.world_group = [None] * pr, [None] * pc, None
+    grid.row_groups, grid.col_groups, grid.diag_col_groups, grid.world_group = [None] * pr, [None] * pc, [None] * pc, None
 
     class Emulated(BlockCyclicCholesky):
         def _bcast(self, t, src_rank, group, members):      # noqa: D401 -- no communication: shapes only
@@ -65,13 +67,32 @@ def main():
     ch.factor()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
+    factor_phases = {k: round(v, 2) for k, v in ch.phase_times().items()}
     share = (n ** 3 / 3.0) / (pr * pc)
+    solve = None
+    if a.solve_m > 0:
+        from gpmp_amd.dist import shard_bounds
+
+        j0, j1 = shard_bounds(a.solve_m, pc, c)
+        mc = j1 - j0
+        solve = {"m": a.solve_m, "m_local": mc, "rank_share_flops": float(n) * n * a.solve_m / (pr * pc)}
+        for overlap in (True, False, True):
+            B = gnp.alloc_matrix(ch.local_rows(), mc)
+            B.copy_(torch.randn(ch.local_rows(), mc, dtype=torch.float64, device=B.device) * 1e-3)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            ch.solve_lower_many(B, overlap=overlap, profile=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t3
+            solve["overlap" if overlap else "in_order"] = {"s": dt, "rank_share_tflops": solve["rank_share_flops"] / dt / 1e12,
+                                                           "phases_ms": {k: round(v, 2) for k, v in ch.phase_times().items()}}
+            del B
     print(json.dumps({"tool": "dist_rank_emulation", "n": n, "grid": a.grid, "coords": a.coords, "block": a.block,
                       "local_shape": [ch.local_rows(), ch.local_cols()], "lookahead": not a.no_lookahead, "reserve_cus": ch.reserve_cus,
                       "gram_s": t1 - t0, "factor_s": t2 - t1, "rank_share_tflops": share / (t2 - t1) / 1e12,
                       "frac_of_fp64_mfma_peak": share / (t2 - t1) / 1e12 / 78.6,
                       "bytes_received_GB": ch.bytes_received / 1e9,
-                      "phases_ms": {k: round(v, 2) for k, v in ch.phase_times().items()},
+                      "phases_ms": factor_phases, "solve": solve,
                       "note": "collectives stubbed: timing and fault check only, values are not a factorisation"}))
     dist.destroy_process_group()
 
