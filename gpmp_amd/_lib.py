@@ -63,6 +63,17 @@ SIGNATURES = {
     "gpmp_nll_grad_batch": (c_int, [_P, c_long, _P, c_long, _P, c_long, c_long, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int,
                                     _P, _P, _P, _P, _P]),
     "gpmp_loo_ws_elems": (c_size_t, [c_int, c_int]),
+    "gpmp_dist_diag_msg_elems": (c_size_t, [c_int]),
+    "gpmp_dist_diag_factor": (c_int, [_P, c_int, c_long, _P, _P]),
+    "gpmp_dist_panel_ws_elems": (c_size_t, [c_int]),
+    "gpmp_dist_panel_solve": (c_int, [_P, c_int, _P, c_int, c_long, _P, c_long, _P, _P]),
+    "gpmp_dist_local_shape": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "gpmp_dist_step_shape": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "gpmp_dist_exchange_rows": (c_long, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "gpmp_dist_exchange_pack": (c_int, [_P, c_long, _P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "gpmp_dist_exchange_unpack": (c_int, [_P, c_long, _P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "gpmp_dist_trailing_update": (c_int, [_P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_long, _P, c_long, c_int, c_int,
+                                          c_int, _P]),
     "gpmp_loo": (c_int, [_P, _P, _P, c_long, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]),
 }
 

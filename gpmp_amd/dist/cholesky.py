@@ -150,6 +150,46 @@ class HipLocalOps:
     def pairwise_variance(self, cov, xt, covparam):
         return self.gnp.asarray(cov(xt, None, covparam, pairwise=True)).reshape(-1)
 
+    # ---- one block-column step through gpmp_dist_* (include/gpmp_hip.h): what a C++ / RCCL host calls between its
+    # collectives (examples/dist_potrf_rccl.cpp).  ``lay`` = (n, nb, Pr, Pc, r, c).  The schedule uses these when the
+    # local-ops object has them; the generic tensor-level code they replace stays for the CPU stand-in of the tests.
+    step_abi = True
+
+    def diag_factor_msg(self, D, msg):
+        g = self.gnp
+        self._lib.check(self.lib.gpmp_dist_diag_factor(g._ptr(D), D.shape[0], g._ld(D), g._ptr(msg), g._stream()), "gpmp_dist_diag_factor")
+
+    def panel_solve_msg(self, Lkk, P, panel):
+        """panel <- P L_kk^-T (and P in place); ``Lkk`` is the view at the start of the diagonal-block message"""
+        g = self.gnp
+        bk = Lkk.shape[0]
+        ws = torch.empty(int(self.lib.gpmp_dist_panel_ws_elems(bk)), dtype=torch.float64, device=self.device) if bk % 128 == 0 else None
+        self._lib.check(self.lib.gpmp_dist_panel_solve(g._ptr(Lkk), bk, g._ptr(P), P.shape[0], g._ld(P), g._ptr(panel), g._ld(panel),
+                                                       g._ptr(ws), g._stream()), "gpmp_dist_panel_solve")
+
+    def exchange_rows(self, lay, rp, k):
+        n, nb, pr, pc, r, c = lay
+        return int(self.lib.gpmp_dist_exchange_rows(n, nb, pr, pc, rp, c, k))
+
+    def exchange_pack(self, panel, piece, lay, k, bk):
+        g = self.gnp
+        n, nb, pr, pc, r, c = lay
+        self._lib.check(self.lib.gpmp_dist_exchange_pack(g._ptr(panel), g._ld(panel), g._ptr(piece), g._ld(piece), n, nb, pr, pc, r, c, k, bk,
+                                                         g._stream()), "gpmp_dist_exchange_pack")
+
+    def exchange_unpack(self, piece, colop, lay, rp, k, bk):
+        g = self.gnp
+        n, nb, pr, pc, r, c = lay
+        self._lib.check(self.lib.gpmp_dist_exchange_unpack(g._ptr(piece), g._ld(piece), g._ptr(colop), g._ld(colop), n, nb, pr, pc, rp, c, k,
+                                                           bk, g._stream()), "gpmp_dist_exchange_unpack")
+
+    def trailing_update(self, A, lay, k, panel, colop, jlo, jhi, rows_after):
+        g = self.gnp
+        n, nb, pr, pc, r, c = lay
+        self._lib.check(self.lib.gpmp_dist_trailing_update(g._ptr(A), g._ld(A), n, nb, pr, pc, r, c, k, g._ptr(panel), g._ld(panel),
+                                                           g._ptr(colop), g._ld(colop), jlo, jhi, -1 if rows_after is None else rows_after,
+                                                           g._stream()), "gpmp_dist_trailing_update")
+
 
 # ------------------------------------------------------------------------------------------------
 def _comm_tensor(t: torch.Tensor, backend: str) -> torch.Tensor:
@@ -289,6 +329,9 @@ class BlockCyclicCholesky:
         # sees.  RCCL needs the per-communicator sequences to be identical on all members of a communicator.
         self.oplog = None
         self._step_label = None
+        self._lay = (n, nb, grid.pr, grid.pc, grid.r, grid.c)
+        # local arithmetic of a step through the C ABI's gpmp_dist_* (HipLocalOps) or through the tensor-level code below
+        self._abi = bool(getattr(self.ops, "step_abi", False)) and nb <= 1024 and os.environ.get("GPMP_DIST_STEP_ABI", "1") != "0"
 
     # ---- index helpers
     def bs(self, I: int) -> int:
@@ -453,7 +496,9 @@ class BlockCyclicCholesky:
             lj = k // g.pc
             P = A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]]
             with self._phase("trsm"):
-                if self.panel_via_inverse and hasattr(ops, "trsm_right_via_inverse") and bk % 128 == 0:
+                if self._abi and self.panel_via_inverse:
+                    ops.panel_solve_msg(Lkk, P, panel)
+                elif self.panel_via_inverse and hasattr(ops, "trsm_right_via_inverse") and bk % 128 == 0:
                     ops.trsm_right_via_inverse(Lkk, dinv, P, panel)
                     P.copy_(panel)
                 else:
@@ -502,10 +547,13 @@ class BlockCyclicCholesky:
         if g.r == rd:
             li, lj = k // g.pr, k // g.pc
             D = A[self.roff[li]:self.roff[li + 1], self.coff[lj]:self.coff[lj + 1]]
-            dv, info = ops.potrf(D)
-            dinv.copy_(dv[:ndinv])
-            Lkk.copy_(D)
-            inf.copy_(info.to(torch.float64))
+            if self._abi:
+                ops.diag_factor_msg(D, dbuf)
+            else:
+                dv, info = ops.potrf(D)
+                dinv.copy_(dv[:ndinv])
+                Lkk.copy_(D)
+                inf.copy_(info.to(torch.float64))
         if g.pr > 1:
             # its own communicator (grid.diag_col_group): issued from the diagonal stream with look-ahead, from the side
             # stream without -- never interleaved with the column exchange's collectives on g.col_group
@@ -532,6 +580,21 @@ class BlockCyclicCholesky:
         """colop rows of block J (J > k, J mod Pc == c) = panel rows of block J held by process row J mod Pr: one gather on
         the holder, one broadcast inside the process column, one scatter on the receivers per process row."""
         g, nb = self.grid, self.nb
+        if self._abi:
+            ops = self.ops
+            for rp in range(g.pr):
+                rows = ops.exchange_rows(self._lay, rp, k)
+                if rows <= 0:
+                    continue
+                if g.pr == 1:          # the holder is this rank and the piece IS the column operand (consecutive blocks)
+                    ops.exchange_pack(panel, colop, self._lay, k, bk)
+                    continue
+                piece = self._piece_buf[:rows, :bk]
+                if g.r == rp:
+                    ops.exchange_pack(panel, piece, self._lay, k, bk)
+                self._bcast(piece, g.rank_of(rp, g.c), g.col_group, col_members)
+                ops.exchange_unpack(piece, colop, self._lay, rp, k, bk)
+            return
         for rp, (blocks, src_idx, dst_idx) in enumerate(self._xmaps):
             first = bisect.bisect_right(blocks, k)            # blocks[first:] are the J > k
             if first >= len(blocks):
@@ -560,6 +623,10 @@ class BlockCyclicCholesky:
         if jhi <= jlo:
             return
         ops, A = self.ops, self.A
+        if self._abi:
+            if A.shape[0] and A.shape[1]:
+                ops.trailing_update(A, self._lay, k, panel, colop, jlo, jhi, rows_after)
+            return
         i0, j0 = self._first_row_after(k), self._first_col_after(k)
         nrb = len(self.row_blocks)
         G = 4

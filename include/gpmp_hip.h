@@ -303,6 +303,47 @@ int gpmp_nll_grad_batch(const double* x, long stride_x, const double* z, long st
                         const double* theta_host, int theta_stride, int noise, double* ws, double* values_dev,
                         double* grads_dev, int* info_dev, gpmp_stream_t stream);
 
+/* ---- distributed (2-D block-cyclic) Cholesky: the LOCAL half of one block-column step --------------------------
+ * SURVEY 8(b) `gpmp_dist_*`; the reference has no counterpart (README.md:39-40).  The library links no communication
+ * library and takes no communicator: the HOST owns every collective (gpmp_amd/dist over torch.distributed = RCCL; a
+ * C++ / RCCL host: examples/dist_potrf_rccl.cpp) and calls these between them.  Layout: global
+ * block (I, J) of size nb (a multiple of 128, <= 1024) of the n x n matrix lives on rank (I mod Pr, J mod Pc) at local
+ * block (I div Pr, J div Pc) of ONE dense row-major local matrix (gpmp_dist_local_shape); only the last block is short.
+ * Step k:  owner of (k, k): gpmp_dist_diag_factor -> msg;  [broadcast msg down process column k mod Pc];
+ *          ranks of that column: gpmp_dist_panel_solve -> panel (their block rows I > k);  [broadcast along process rows];
+ *          per process row rp: gpmp_dist_exchange_pack on the holder, [broadcast inside the process column],
+ *          gpmp_dist_exchange_unpack everywhere -> colop (block rows J > k of the owned block COLUMNS);
+ *          every rank: gpmp_dist_trailing_update.  Everything only enqueues on `stream`. */
+/* doubles of the diagonal-block message [L_kk (bk x ld16(bk)) | inverses of its 128-blocks | info as a double] */
+size_t gpmp_dist_diag_msg_elems(int bk);
+/* factor the bk x bk diagonal block D in place (numpy_backend.py:466 on one block) and fill msg; msg's last double is the
+ * LAPACK-style info of the block (0, or the 1-based failing pivot inside it) */
+int gpmp_dist_diag_factor(double* D, int bk, long ldd, double* msg, gpmp_stream_t stream);
+size_t gpmp_dist_panel_ws_elems(int bk);
+/* panel = P L_kk^-T for the `rows` local rows below the diagonal block (P: rows x bk view into the local matrix, also
+ * overwritten with the result); ws: gpmp_dist_panel_ws_elems(bk) doubles (NULL or a ragged bk: substitution in place) */
+int gpmp_dist_panel_solve(const double* msg, int bk, double* P, int rows, long ldp, double* panel, long ldo, double* ws,
+                          gpmp_stream_t stream);
+/* rows x cols of the local matrix of rank (r, c) */
+int gpmp_dist_local_shape(int n, int nb, int pr, int pc, int r, int c, long* rows_out, long* cols_out);
+/* step k on rank (r, c): rows of the panel buffer (owned block rows I > k), rows of the column operand (owned block
+ * columns J > k), and the local row / column where they start */
+int gpmp_dist_step_shape(int n, int nb, int pr, int pc, int r, int c, int k, long* panel_rows_out, long* colop_rows_out,
+                         long* panel_row0_out, long* colop_col0_out);
+/* rows of the piece that process row rp contributes to the column operand of process column c at step k
+ * (the blocks J > k with J mod Pc == c and J mod Pr == rp); 0: nothing to exchange, < 0: bad arguments */
+long gpmp_dist_exchange_rows(int n, int nb, int pr, int pc, int rp, int c, int k);
+/* holder (r == rp): gather those blocks from its panel buffer into `piece` (consecutive rows) */
+int gpmp_dist_exchange_pack(const double* panel, long ldp, double* piece, long ldq, int n, int nb, int pr, int pc, int r, int c,
+                            int k, int bk, gpmp_stream_t stream);
+/* every rank of the process column: scatter process row rp's piece into its column operand */
+int gpmp_dist_exchange_unpack(const double* piece, long ldq, double* colop, long ldc, int n, int nb, int pr, int pc, int rp, int c,
+                              int k, int bk, gpmp_stream_t stream);
+/* A_IJ -= panel_I colop_J^T for the local blocks I >= J with local block-column index in [jlo, jhi) (jhi < 0: to the end)
+ * and, when rows_after >= 0, global block row I > rows_after: a staircase of fp64 MFMA GEMMs over groups of 4 block rows */
+int gpmp_dist_trailing_update(double* A, long lda, int n, int nb, int pr, int pc, int r, int c, int k, const double* panel,
+                              long ldp, const double* colop, long ldc, int jlo, int jhi, int rows_after, gpmp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

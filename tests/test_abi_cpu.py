@@ -90,3 +90,37 @@ def test_backend_namespace_covers_the_reference_contract():
                "numpy_backend", "os", "shared", "warnings"}
     missing = [n for n in names if n not in not_api and not hasattr(gnp, n)]
     assert len(names) > 100 and missing == []
+
+
+def test_dist_layout_queries_match_the_block_cyclic_definition():
+    """gpmp_dist_local_shape / gpmp_dist_step_shape / gpmp_dist_exchange_rows are host arithmetic (no HIP call): checked here
+    against the definition -- global block (I, J) on rank (I mod Pr, J mod Pc) -- over ragged sizes and non-square grids"""
+    import ctypes
+
+    from gpmp_amd import _lib
+
+    lib = _lib.load()
+    L = ctypes.c_long
+    for n, nb in ((1900, 128), (2000, 256), (1024, 1024), (131072, 1024), (700, 128), (200, 128)):
+        nblk = (n + nb - 1) // nb
+        bs = lambda I: min(nb, n - I * nb)  # noqa: E731
+        for pr, pc in ((1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (3, 2), (2, 3)):
+            for r in range(pr):
+                for c in range(pc):
+                    rows, cols = L(-1), L(-1)
+                    assert lib.gpmp_dist_local_shape(n, nb, pr, pc, r, c, ctypes.byref(rows), ctypes.byref(cols)) == 0
+                    rb, cb = list(range(r, nblk, pr)), list(range(c, nblk, pc))
+                    assert rows.value == sum(bs(I) for I in rb) and cols.value == sum(bs(J) for J in cb)
+                    for k in sorted({0, 1, nblk // 2, nblk - 2, nblk - 1} & set(range(nblk))):
+                        pr_rows, co_rows, r0, c0 = L(-1), L(-1), L(-1), L(-1)
+                        assert lib.gpmp_dist_step_shape(n, nb, pr, pc, r, c, k, ctypes.byref(pr_rows), ctypes.byref(co_rows), ctypes.byref(r0),
+                                                        ctypes.byref(c0)) == 0
+                        assert pr_rows.value == sum(bs(I) for I in rb if I > k) and co_rows.value == sum(bs(J) for J in cb if J > k)
+                        assert r0.value == sum(bs(I) for I in rb if I <= k) and c0.value == sum(bs(J) for J in cb if J <= k)
+                        for rp in range(pr):
+                            want = sum(bs(J) for J in cb if J > k and J % pr == rp)
+                            assert lib.gpmp_dist_exchange_rows(n, nb, pr, pc, rp, c, k) == want, (n, nb, pr, pc, rp, c, k)
+    # argument checks come back negative with a message, without touching a device
+    assert lib.gpmp_dist_local_shape(100, 100, 1, 1, 0, 0, None, None) < 0 and lib.gpmp_last_error()
+    assert lib.gpmp_dist_exchange_rows(1000, 128, 2, 2, 0, 5, 0) < 0
+    assert lib.gpmp_dist_diag_msg_elems(1024) == 1024 * 1024 + 8 * 128 * 128 + 1 and lib.gpmp_dist_diag_msg_elems(200) == 200 * 208 + 2 * 128 * 128 + 1

@@ -61,6 +61,14 @@ calls = [
     lambda: lib.gpmp_nll_grad(N, N, N, 1, 10, 2, 0, 2, th, 0, N, N, N, N, N),
     lambda: lib.gpmp_loo(N, N, N, 1, 10, 2, 0, 2, th, 0, N, N, N, N, N, N),
     lambda: lib.gpmp_nll_grad_batch(N, 0, N, 0, N, 1, 0, 0, N, 10, 2, 4, 2, th, 0, 0, N, N, N, N, N),
+    lambda: lib.gpmp_dist_diag_factor(N, 256, 256, N, N),
+    lambda: lib.gpmp_dist_diag_factor(ctypes.c_void_p(8), 2048, 2048, ctypes.c_void_p(8), N),
+    lambda: lib.gpmp_dist_panel_solve(N, 256, N, 10, 256, N, 256, N, N),
+    lambda: lib.gpmp_dist_exchange_pack(N, 256, N, 256, 4096, 256, 2, 2, 0, 0, 0, 256, N),
+    lambda: lib.gpmp_dist_exchange_unpack(N, 256, N, 256, 4096, 256, 2, 2, 0, 0, 0, 256, N),
+    lambda: lib.gpmp_dist_trailing_update(N, 4096, 4096, 256, 2, 2, 0, 0, 0, N, 256, N, 256, 0, -1, -1, N),
+    lambda: lib.gpmp_dist_trailing_update(N, 4096, 4096, 100, 2, 2, 0, 0, 0, N, 256, N, 256, 0, -1, -1, N),
+    lambda: lib.gpmp_dist_step_shape(4096, 256, 2, 2, 0, 0, 99, N, N, N, N),
     lambda: lib.gpmp_profile_end(N),
     lambda: lib.gpmp_stream_create_reserving_cus(0, N),
 ]
@@ -75,6 +83,22 @@ assert lib.gpmp_profile_begin() == 0
 tab = (ctypes.c_double * 36)()
 assert lib.gpmp_profile_end(tab) == 0 and sum(tab) == 0.0
 assert lib.gpmp_hint_machine_busy(1) == 0 and lib.gpmp_hint_machine_busy(0) == 1
+# the distributed step's layout arithmetic over a sweep (host only)
+L_ = ctypes.c_long
+for n in (1, 127, 1000, 4097, 131072):
+    for nb in (128, 256, 1024):
+        for (pr, pc) in ((1, 1), (2, 4), (3, 2)):
+            for r in range(pr):
+                for c in range(pc):
+                    a, b = L_(0), L_(0)
+                    assert lib.gpmp_dist_local_shape(n, nb, pr, pc, r, c, ctypes.byref(a), ctypes.byref(b)) == 0
+                    for k in range(0, (n + nb - 1) // nb, 7):
+                        assert lib.gpmp_dist_step_shape(n, nb, pr, pc, r, c, k, ctypes.byref(a), ctypes.byref(b), None, None) == 0
+                        for rp in range(pr):
+                            assert lib.gpmp_dist_exchange_rows(n, nb, pr, pc, rp, c, k) >= 0
+# nothing to exchange / update: returns before any pointer or device is touched
+assert lib.gpmp_dist_exchange_pack(N, 256, N, 256, 256, 256, 1, 1, 0, 0, 0, 256, N) == 0
+assert lib.gpmp_dist_trailing_update(N, 256, 256, 256, 1, 1, 0, 0, 0, N, 256, N, 256, 0, -1, -1, N) == 0
 # stream bookkeeping: releasing / destroying a stream the library holds nothing for is a no-op that makes no HIP call
 for h in (None, ctypes.c_void_p(0x1000), ctypes.c_void_p(0x1000)):
     assert lib.gpmp_stream_release(h) == 0

@@ -21,8 +21,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, pr, pc, n, nb, out, transport, lookahead, backend="gloo"):
+def _worker(rank, world, port, pr, pc, n, nb, out, transport, lookahead, backend="gloo", step_abi="1"):
     import torch.distributed as dist
+
+    os.environ["GPMP_DIST_STEP_ABI"] = step_abi
 
     # gloo: every rank on the one test GPU; nccl (= RCCL): one GPU per rank
     local = str(rank) if backend == "nccl" else "0"
@@ -80,6 +82,28 @@ def test_block_cyclic_cholesky_rccl(tmp_path, pr, pc, n, nb, transport, lookahea
     if torch.cuda.device_count() < pr * pc:
         pytest.skip(f"needs {pr * pc} GPUs, have {torch.cuda.device_count()}")
     _run_and_check(tmp_path, pr, pc, n, nb, transport, lookahead, "nccl")
+
+
+@pytest.mark.parametrize("pr,pc,n,nb,lookahead", [(2, 2, 2000, 256, True), (1, 2, 1500, 256, True), (2, 1, 1500, 256, False), (1, 1, 2304, 1024, True),
+                                                   (2, 2, 3100, 256, True)])
+def test_step_abi_equals_the_tensor_level_schedule(tmp_path, pr, pc, n, nb, lookahead):
+    """gpmp_dist_* (diag_factor / panel_solve / exchange_pack + unpack / trailing_update: what a C++ RCCL host calls) against
+    the tensor-level code of gpmp_amd/dist for the same schedule: the same kernels on the same operands in the same order,
+    so the assembled factor must be IDENTICAL bit for bit (ragged last block: n = 2000 / 256 leaves 208 rows, whose panel
+    solve takes the substitution route; n = 3100: two block columns per rank and a ragged last block)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+
+    world = pr * pc
+    outs = []
+    for abi in ("1", "0"):
+        out = str(tmp_path / f"L{abi}.npy")
+        mp.spawn(_worker, args=(world, _free_port(), pr, pc, n, nb, out, "bcast", lookahead, "gloo", abi), nprocs=world, join=True)
+        outs.append((np.load(out), np.load(out + ".meta.npy")))
+    (L1, m1), (L0, m0) = outs
+    assert m1[0] == 0 and m0[0] == 0
+    assert np.array_equal(L1, L0) and m1[1] == m0[1]
 
 
 def _run_and_check(tmp_path, pr, pc, n, nb, transport, lookahead, backend):
@@ -169,3 +193,23 @@ def test_block_cyclic_predict_hip(tmp_path, pr, pc, n, m, nb, transport, overlap
     rm, rv = orc.predict(om, x, z, xt, zero_neg_variances=False)
     assert np.max(np.abs(got[0] - rm)) < 1e-8 * np.max(np.abs(z))
     assert np.max(np.abs(got[1] - rv)) < 1e-8
+
+
+@pytest.mark.parametrize("n,nb", [(4096, 512), (3000, 256), (2048, 1024)])
+def test_cpp_rccl_host_on_the_step_abi(tmp_path, n, nb):
+    """examples/dist_potrf_rccl.cpp: a C++ host that owns the RCCL communicators and drives gpmp_dist_* (no torch, no
+    Python) -- here on the 1 x 1 grid a one-GPU box allows (RCCL initialised with one rank, every broadcast a no-op): info 0
+    and log|K| equal to the single-GPU factorisation of the same matrix.  With N GPUs the same binary runs as N processes."""
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "dist_potrf_rccl.bin")
+    if not torch.cuda.is_available() or not os.path.exists(exe):
+        pytest.skip("no GPU or example not built (run __graft_entry__.build())")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([exe, "0", "1", "1", "1", str(n), str(nb), str(tmp_path / "nccl_id")], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, (p.returncode, p.stdout[-1000:], p.stderr[-2000:])
+    assert re.search(r"info=0 ", p.stdout)
+    rel = float(re.search(r"rel_diff=([-+0-9.eE]+)", p.stdout).group(1))
+    assert rel < 1e-12, p.stdout
