@@ -104,6 +104,28 @@ BATCH_MAX_N = 2048      # GPMP_BATCH_MAX_N
 BATCH_MAX_Q = 3
 
 
+def batch_qualifies(model, use_mean=False):
+    """Model-level part of the batched route's conditions, decidable BEFORE any batch is moved to the device: a declared
+    Matern covariance (the fused Gram / gradient kernels)."""
+    return isinstance(model.covariance, MaternCovariance)
+
+
+def batch_piece_limit(nmax, d, q, want_grad, device=None):
+    """Largest number of problems of up to ``nmax`` points whose workspace fits the budget of ONE library call (a quarter
+    of the free device memory, at most 32 GiB; GPMP_BATCH_WS_BUDGET_MB overrides): two nmax x nmax matrices per problem
+    with gradients, 70 MB at 2048 points.  0: the shape is outside the batched kernel's limits."""
+    lib = _lib.load()
+    per_problem = 8 * int(lib.gpmp_batch_ws_elems(int(nmax), int(d), int(q), 1, 1 if want_grad else 0))
+    if per_problem == 0:
+        return 0
+    budget = 1 << 30
+    if device is not None and torch.device(device).type == "cuda":
+        budget = min(int(torch.cuda.mem_get_info(device)[0]) // 4, 32 << 30)
+    if os.environ.get("GPMP_BATCH_WS_BUDGET_MB"):            # (tests: force the piecewise route)
+        budget = int(float(os.environ["GPMP_BATCH_WS_BUDGET_MB"]) * (1 << 20))
+    return max(1, budget // per_problem)
+
+
 def batch_values_and_gradients(model, covparams, batches, want_grad=True, use_mean=False, mean_offset=None):
     """Criterion values (and gradients) of B small problems through ONE library call (gpmp_nll_grad_batch: every
     kernel batched over the problems) -- the throughput path behind ``gnp.BatchDifferentiableSelectionCriterion``
@@ -138,13 +160,7 @@ def batch_values_and_gradients(model, covparams, batches, want_grad=True, use_me
     dev = xs[0].device
     # the workspace grows with B (two nmax x nmax matrices per problem with gradients: 70 MB at 2048 points): a call is cut into
     # pieces whose workspace fits a quarter of the free device memory (at most 32 GiB)
-    per_problem = 8 * int(lib.gpmp_batch_ws_elems(nmax, d, q, 1, 1 if want_grad else 0))
-    budget = 1 << 30
-    if dev.type == "cuda":
-        budget = min(int(torch.cuda.mem_get_info(dev)[0]) // 4, 32 << 30)
-    if os.environ.get("GPMP_BATCH_WS_BUDGET_MB"):            # (tests: force the piecewise route)
-        budget = int(float(os.environ["GPMP_BATCH_WS_BUDGET_MB"]) * (1 << 20))
-    b_piece = max(1, budget // max(per_problem, 1))
+    b_piece = max(1, batch_piece_limit(nmax, d, q, want_grad, dev))
     if B > b_piece:
         th_all = numpy.asarray(covparams, dtype=numpy.float64)
         vals, grads = [], []
@@ -205,6 +221,10 @@ def _reml_batch(self, covparam, batches, want_grad=True):
 
 MLZeroMeanAnalytic.batch_values_and_gradients = _ml_batch
 REMLAnalytic.batch_values_and_gradients = _reml_batch
+MLZeroMeanAnalytic.batch_qualifies = lambda self: batch_qualifies(self.model)
+REMLAnalytic.batch_qualifies = lambda self: batch_qualifies(self.model, use_mean=True)
+MLZeroMeanAnalytic.batch_max_points = REMLAnalytic.batch_max_points = BATCH_MAX_N
+MLZeroMeanAnalytic.batch_piece_limit = REMLAnalytic.batch_piece_limit = staticmethod(batch_piece_limit)
 
 
 def _many(self, P, xi, zi, want_grad=False):

@@ -206,6 +206,17 @@ class _RemapAnalytic:
         reml_state, covparam = state
         return self.reml.gradient_from_state(reml_state) + self.gnlp(covparam)
 
+    # (qualification and piece size of the batched route are the REML part's)
+    def batch_qualifies(self):
+        return self.reml.batch_qualifies()
+
+    @property
+    def batch_max_points(self):
+        return self.reml.batch_max_points
+
+    def batch_piece_limit(self, *a, **kw):
+        return self.reml.batch_piece_limit(*a, **kw)
+
     def batch_values_and_gradients(self, covparam, batches, want_grad=True):
         """every batch's REML through the batched library call; the prior (O(d), host) is added to each batch as
         the one-at-a-time route does"""

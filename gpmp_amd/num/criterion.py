@@ -153,30 +153,69 @@ class BatchDifferentiableSelectionCriterion:
             raise ValueError("Loader is empty.")
         return total / n if self.reduction == "mean" else total
 
-    def _batched(self, p_arr, batches, want_grad):
-        """All batches in ONE library call (gpmp_nll_grad_batch: every kernel batched over the problems) when the
-        analytic object offers it and the batches qualify (declared Matern covariance, <= 2048 points per batch,
-        <= 3 mean columns); None otherwise -> the batches are evaluated one after the other."""
-        fn = getattr(self._analytic, "batch_values_and_gradients", None)
-        if fn is None or not self.use_batched_kernel:
-            return None
-        return fn(p_arr, batches, want_grad)
-
     use_batched_kernel = True      # set False to force the one-batch-at-a-time route (tests compare both)
 
-    def evaluate(self, p):
-        batches = [self._prepare(xb, zb) for xb, zb in self._batches()]
-        sizes = [int(xb.shape[0]) for xb, _ in batches]
-        p_arr = numpy.array(numpy.asarray(p, dtype=numpy.float64), copy=True)
-        fast = self._batched(p_arr, batches, False) if batches else None
-        if fast is not None:
-            total = float(numpy.dot(fast[0], sizes))
-            return self._reduce(total, sum(sizes))
+    def _accumulate(self, p_arr, want_grad):
+        """Sum of (batch value x batch size), points seen and -- with ``want_grad`` -- the sum of (batch gradient x batch size)
+        over the batches of this evaluation, STREAMING the loader: whether the batched kernel applies is decided first (a
+        declared Matern covariance: model level, no data touched) and per batch from its size on the host (<= 2048 points);
+        qualifying batches are collected into pieces of at most one library call's workspace budget
+        (``batch_piece_limit``) and go through gpmp_nll_grad_batch piece by piece, every other batch is evaluated on its own
+        and dropped -- at no time more than one piece of the loader is resident on the device."""
+        an = self._analytic
+        fn = getattr(an, "batch_values_and_gradients", None)
+        can_batch = fn is not None and self.use_batched_kernel and (getattr(an, "batch_qualifies", None) is None or an.batch_qualifies())
+        max_pts = getattr(an, "batch_max_points", 0) if can_batch else 0
+        limit_fn = getattr(an, "batch_piece_limit", None)
         total, n = 0.0, 0
-        for xb, zb in batches:
+        grad = numpy.zeros_like(p_arr) if want_grad else None
+        pending, nmax = [], 0
+
+        def one(xb, zb):
+            nonlocal total, n, grad
             bs = xb.shape[0]
-            total += float(self.crit(p, xb, zb)) * bs
+            if want_grad:
+                value, state = an.value_and_state(p_arr, xb, zb)
+                grad += bs * numpy.asarray(an.gradient_from_state(state), dtype=numpy.float64)
+            else:
+                value = self.crit(p_arr, xb, zb)
+            total += float(value) * bs
             n += bs
+
+        def flush():
+            nonlocal total, n, grad, pending, nmax
+            if not pending:
+                return
+            out = fn(p_arr, pending, want_grad)
+            if out is None:                      # (e.g. more mean columns than the batched kernel carries): one by one
+                for xb, zb in pending:
+                    one(xb, zb)
+            else:
+                sizes = numpy.array([int(xb.shape[0]) for xb, _ in pending], dtype=numpy.float64)
+                total += float(numpy.dot(out[0], sizes))
+                n += int(sizes.sum())
+                if want_grad:
+                    grad += sizes @ out[1]
+            pending, nmax = [], 0
+
+        for xb_h, zb_h in self._batches():
+            bs = int(xb_h.shape[0])
+            if can_batch and 0 < bs <= max_pts:
+                xb, zb = self._prepare(xb_h, zb_h)
+                pending.append((xb, zb))
+                nmax = max(nmax, bs)
+                # q is not known here (the mean is a user callable): size the piece for the widest design the kernel takes
+                lim = limit_fn(nmax, int(xb.shape[1]), 3, want_grad, xb.device) if limit_fn is not None else 64
+                if len(pending) >= max(1, lim):
+                    flush()
+            else:
+                one(*self._prepare(xb_h, zb_h))
+        flush()
+        return total, n, grad
+
+    def evaluate(self, p):
+        p_arr = numpy.array(numpy.asarray(p, dtype=numpy.float64), copy=True)
+        total, n, _ = self._accumulate(p_arr, False)
         return self._reduce(total, n)
 
     def evaluate_no_grad(self, p):
@@ -191,21 +230,8 @@ class BatchDifferentiableSelectionCriterion:
         p_arr = numpy.array(numpy.asarray(p, dtype=numpy.float64), copy=True)
         if self._analytic is None:
             return self.evaluate_no_grad(p_arr)
-        total, n, grad = 0.0, 0, numpy.zeros_like(p_arr)
         try:
-            batches = [self._prepare(xb, zb) for xb, zb in self._batches()]
-            fast = self._batched(p_arr, batches, True) if batches else None
-            if fast is not None:
-                sizes = numpy.array([int(xb.shape[0]) for xb, _ in batches], dtype=numpy.float64)
-                total, n = float(numpy.dot(fast[0], sizes)), int(sizes.sum())
-                grad = sizes @ fast[1]
-            else:
-                for xb, zb in batches:
-                    bs = xb.shape[0]
-                    value, state = self._analytic.value_and_state(p_arr, xb, zb)
-                    grad += bs * numpy.asarray(self._analytic.gradient_from_state(state), dtype=numpy.float64)
-                    total += float(value) * bs
-                    n += bs
+            total, n, grad = self._accumulate(p_arr, True)
         except Exception as exc:
             if _is_linalg_exception(exc):
                 self._gradient = numpy.zeros_like(p_arr)
