@@ -81,6 +81,60 @@ def pmc_traffic_per_launch(kernel_substr):
     return tot if n_disp else None
 
 
+def pmc_traffic_live(kernel_substr, args, timeout_s=300.0):
+    """HBM-side bytes per launch of a kernel measured IN THIS RUN: two child processes of this same benchmark (one step, no
+    extras) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, counters only (no tracing domain
+    beside them), the program itself after `--`, as MI355X_MICROARCH.md's HBM / rocprofv3 section prescribes; FETCH_SIZE and
+    WRITE_SIZE count KB, and on gfx950 FETCH_SIZE reports half of a wide streaming read (x2).  Children are STARTED (nothing is
+    exec'ed from this GPU-initialised process), each in its own session under a time limit.  Returns (bytes per launch,
+    note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    tot = 0.0
+    launches = None
+    for counter, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        out = tempfile.mkdtemp(prefix="gpmp_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--role", "headline",
+               "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--no-kernel-events", "--no-live-pmc",
+               "--size-n", str(args.n), "--size-m", str(args.m), "--dim-d", str(args.d)]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GPMP_BENCH_CHILD")}
+        env["TMPDIR"] = "/tmp"
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                return None, f"{counter} pass exceeded {timeout_s:.0f} s and was killed"
+            if rc != 0:
+                return None, f"{counter} pass ended with code {rc}"
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"{counter} pass wrote no counter_collection.csv"
+            val, disp = 0.0, set()
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") == counter and kernel_substr in row.get("Kernel_Name", ""):
+                    val += float(row["Counter_Value"])
+                    disp.add(row["Dispatch_Id"])
+            if not disp:
+                return None, f"{counter} pass: no dispatch of the kernel"
+            launches = len(disp)
+            tot += factor * 1024.0 * val / launches
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return tot, (f"measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE; KB -> bytes) over one step of "
+                 f"this command each, {launches} launches of the kernel per pass; bytes at the fabric side of L2, Infinity-Cache hits included")
+
+
 def _host_threads():
     try:
         from threadpoolctl import threadpool_info
@@ -735,6 +789,17 @@ class HipWorkload:
             "nll": float(self.out[2]),
         })
         threads = _host_threads()
+        if self.world == 1 and (n, m) == (32768, 50000) and not args.no_live_pmc and os.environ.get("GPMP_BENCH_LIVE_PMC", "1") != "0":
+            # `traffic` measured in THIS run (two counter passes of one step each, ~1 min); on any failure the figure of the
+            # latest committed passes stays, and the note says which it is
+            self.out = None
+            torch.cuda.empty_cache()
+            live, note = pmc_traffic_live("gemm_f64_kernel_v2<true, false, true>", args)
+            if live is not None:
+                line["roofline"]["traffic_committed_passes"] = line["roofline"]["traffic"]
+                line["roofline"]["traffic"], line["roofline"]["traffic_note"] = live, note
+            else:
+                line["roofline"]["traffic_note"] = f"live PMC passes failed ({note}); " + line["roofline"]["traffic_note"]
         if self.world == 1 and not args.no_extras:
             # configs[1] and configs[3] at their stated sizes, outside the timed region, each beside a same-size CPU figure
             self.out = None
@@ -888,6 +953,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not record per-kernel HIP events in the timed region")
     ap.add_argument("--cpu-m-sample", type=int, default=4096, help="prediction points of the CPU baseline's bounded sample")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] extras")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--role", choices=("auto", "headline", "dist-extra"), default="auto", help="internal: set by the launcher")
     ap.add_argument("--progress", default=None, help="internal: progress file of the distributed extra")
     args = ap.parse_args()
