@@ -144,21 +144,20 @@ def _host_threads():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(n, m, d, threads, m_sample=4096, n_sample=8192):
+def cpu_baseline(n, m, d, threads, m_sample=2048, n_sample=8192):
     """The oracle (NumPy / SciPy restatement of the reference's NumPy backend: cdist -> Matern ufuncs -> cholesky ->
-    2 x solve_triangular -> einsum) on the host cores, on a BOUNDED sample of the headline workload.  The reference's Gram
-    build is single-threaded (SciPy cdist + ~7 full-size NumPy temporaries: 1.6 s at n = 4096, i.e. ~100 s at n = 32768,
-    twice per step), so the full step cannot be run inside a benchmark; what is run, ~30-60 s of CPU work:
-      * Cholesky at the FULL n (LAPACK dpotrf through numpy.linalg.cholesky, all BLAS threads) -- also the host potrf figure;
-      * Gram(xi, xi), Gram(xi, xt_s), the two triangular solves + reductions for m_sample points and the NLL solves at
-        n_sample = min(n, 8192) observations of the same synthetic set.  m_sample = 4096 columns (round 2: 512, a skinny
-        trsm at 0.15 TFLOP/s that made the CPU look several times slower than a BLAS-3 run): the solves are timed on their
-        own and their measured TFLOP/s is printed.
-    `value` is NOT a measured step: the step time at the full size is ASSEMBLED from these measured pieces with their exact
-    complexities -- Gram(xi,xi) ~ n^2, Gram(xi,xt) ~ n m, solves ~ n^2 m, NLL solves ~ n^2:
-        T = 2 (Gram_ii (n/n_s)^2 + Cholesky(n)) + NLL_tail (n/n_s)^2 + m/m_s (Gram_it (n/n_s) + Solve (n/n_s)^2)
-    and value = m / T; `assembled` says so, `measured_s` holds every measured piece, `extrapolated_s` the scaled terms.
-    (One full-size CPU run of the same step is recorded in DESIGN section 5 beside this model figure.)"""
+    2 x solve_triangular -> einsum) on the host cores, on a BOUNDED sample of the headline workload (~45-60 s of CPU work).
+    The full step takes 3.5 minutes on this host (ONE full-size run: tools/cpu_fullsize_step.py, profiles/r3/cpu_fullsize_step.log:
+    209.7 s = 238 points/s on 64 threads), so `value` is ASSEMBLED, and round 3 changed what is sampled after that run showed
+    the previous model 2.9x too slow: LAPACK / BLAS-3 rates depend on n, so everything that goes through BLAS is now timed at
+    the FULL n and only the number of prediction points is sampled:
+      * Cholesky at the full n (numpy.linalg.cholesky on a stand-in SPD matrix: dpotrf's time does not depend on the entries);
+      * with that full-size factor: the two triangular solves (their TFLOP/s is printed), the reductions and the NLL's
+        single-vector solves, for m_sample = 2048 of the m prediction points (x m / m_sample: linear in m at fixed n);
+      * Gram(xi, xt_s) at the full n x m_sample (x m / m_sample) and Gram(xi, xi) at n_sample = 8192 observations
+        (x (n / n_sample)^2): SciPy cdist + the Matern ufuncs are single-threaded elementwise passes, linear in the entries.
+        T = 2 (Gram_ii (n/n_s)^2 + Cholesky(n)) + NLL_tail(n) + m/m_s (Gram_it(n) + Solve(n) + Reductions(n))
+    `assembled` says that value = m / T is a model figure; `measured_s` holds every measured piece, `extrapolated_s` the terms."""
     from scipy.linalg import solve_triangular
 
     from oracle import gp_oracle as orc
@@ -166,7 +165,7 @@ def cpu_baseline(n, m, d, threads, m_sample=4096, n_sample=8192):
     ns = min(n, n_sample)
     ms = min(m, m_sample)
     xi, zi, xt, theta = synth(n, m, d, 0)
-    xi_s, zi_s, xs = xi[:ns], zi[:ns], xt[:ms]
+    xs = xt[:ms]
     t = {}
     np.linalg.cholesky(orc.maternp_covariance(xi[:512], None, 2, theta))    # BLAS thread pool / page-in warm-up, untimed
 
@@ -176,10 +175,16 @@ def cpu_baseline(n, m, d, threads, m_sample=4096, n_sample=8192):
         t[name] = time.perf_counter() - t0
         return out
 
-    K = tick("gram_ii", lambda: orc.maternp_covariance(xi_s, None, 2, theta))               # kriging.py:59, likelihood.py:43
-    L = tick("cholesky_ns", lambda: np.linalg.cholesky(K))                                   # numpy_backend.py:466
+    K = tick("gram_ii_ns", lambda: orc.maternp_covariance(xi[:ns], None, 2, theta))          # kriging.py:59, likelihood.py:43
+    if ns < n:
+        del K
+        # dpotrf at the full n: its time does not depend on the entries, so a cheap SPD matrix stands in for K (8n^2 bytes);
+        # its factor is a well-conditioned lower-triangular matrix of the right size for timing the solves
+        K = np.full((n, n), 0.5)
+        K[np.diag_indices(n)] = float(n)
+    L = tick("cholesky", lambda: np.linalg.cholesky(K))                                      # numpy_backend.py:466
     del K
-    Kit = tick("gram_it", lambda: orc.maternp_covariance(xi_s, xs, 2, theta))               # kriging.py:60
+    Kit = tick("gram_it", lambda: orc.maternp_covariance(xi, xs, 2, theta))                 # kriging.py:60
 
     def trsm_pair():                                                                         # numpy_backend.py:467-468
         y = solve_triangular(L, Kit, lower=True)
@@ -189,38 +194,28 @@ def cpu_baseline(n, m, d, threads, m_sample=4096, n_sample=8192):
 
     def reductions():                                                                        # kriging.py:193-194, model.py:298
         var = orc.maternp_covariance(xs, None, 2, theta, True) - np.einsum("i..., i...", lam, Kit)
-        return np.einsum("i..., i...", lam, zi_s), var
+        return np.einsum("i..., i...", lam, zi), var
 
     tick("reductions", reductions)
     del lam
 
     def nll_tail():                                                                          # likelihood.py:46-51
-        a = solve_triangular(L.T, solve_triangular(L, zi_s, lower=True), lower=False)
-        return 0.5 * (ns * math.log(2 * math.pi) + 2.0 * np.sum(np.log(np.diag(L))) + zi_s @ a)
+        a = solve_triangular(L.T, solve_triangular(L, zi, lower=True), lower=False)
+        return 0.5 * (n * math.log(2 * math.pi) + 2.0 * np.sum(np.log(np.diag(L))) + zi @ a)
 
     tick("nll_tail", nll_tail)
     del L, Kit
-    if ns < n:
-        # dpotrf at the full n: its time does not depend on the entries, so a cheap SPD matrix stands in for K (8n^2 bytes)
-        S = np.full((n, n), 0.5)
-        S[np.diag_indices(n)] = float(n)
-        tick("cholesky", lambda: np.linalg.cholesky(S))
-        del S
-    else:
-        t["cholesky"] = t["cholesky_ns"]
     r = n / ns
-    trsm_tflops = 2.0 * ns * ns * ms / t["trsm_pair"] / 1e12
-    ext = {"gram_ii_x2": 2.0 * t["gram_ii"] * r * r, "cholesky_x2 (measured at the full n)": 2.0 * t["cholesky"],
-           "nll_tail": t["nll_tail"] * r * r, "gram_it": t["gram_it"] * r * m / ms,
-           "trsm_pair": t["trsm_pair"] * r * r * m / ms, "reductions": t["reductions"] * r * m / ms}
+    trsm_tflops = 2.0 * n * n * ms / t["trsm_pair"] / 1e12
+    ext = {"gram_ii_x2": 2.0 * t["gram_ii_ns"] * r * r, "cholesky_x2": 2.0 * t["cholesky"], "nll_tail": t["nll_tail"],
+           "gram_it": t["gram_it"] * m / ms, "trsm_pair": t["trsm_pair"] * m / ms, "reductions": t["reductions"] * m / ms}
     step = sum(ext.values())
     return {"value": m / step, "unit": "points/s", "cores": threads, "kind": "port", "assembled": True,
-            "sample": f"oracle (SciPy cdist + Matern ufuncs + LAPACK), d={d}: Cholesky at the full n={n} ({t['cholesky']:.1f} s); Gram(xi,xi) "
-                      f"({t['gram_ii']:.1f} s), Gram(xi,xt), 2 triangular solves ({trsm_tflops:.2f} TFLOP/s measured) + reductions for "
-                      f"{ms} of the {m} points and the NLL solves at n_s={ns}; NOT a measured step: step time ASSEMBLED with the exact "
-                      f"complexities (Gram_ii, solves, NLL ~ (n/n_s)^2; Gram_it, reductions ~ n/n_s; per-point parts x m/{ms}): "
-                      f"{step:.0f} s per predict+NLL step; CPU work done {sum(t.values()):.0f} s; "
-                      f"BLAS threads={threads} (cdist and the ufuncs are single-threaded)",
+            "sample": f"oracle (SciPy cdist + Matern ufuncs + LAPACK), d={d}, everything that goes through BLAS at the FULL n={n}: Cholesky "
+                      f"({t['cholesky']:.1f} s), 2 triangular solves ({trsm_tflops:.2f} TFLOP/s measured) + reductions + Gram(xi,xt) for {ms} of the "
+                      f"{m} points (x m/{ms}), NLL solves; Gram(xi,xi) at n_s={ns} (x (n/n_s)^2: single-threaded elementwise passes); NOT a "
+                      f"measured step: {step:.0f} s per predict+NLL step ASSEMBLED from these; CPU work done {sum(t.values()):.0f} s; BLAS threads={threads}. "
+                      f"One full-size run of the same step (tools/cpu_fullsize_step.py, 64 threads): 209.7 s",
             "cpu_trsm_tflops": trsm_tflops,
             "host_potrf": {"n": n, "s": t["cholesky"], "tflops": n ** 3 / 3.0 / t["cholesky"] / 1e12},
             "measured_s": {k_: round(v_, 3) for k_, v_ in t.items()},
@@ -951,7 +946,7 @@ def main():
     ap.add_argument("--dim-d", dest="d", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--cpu-m-sample", type=int, default=4096, help="prediction points of the CPU baseline's bounded sample")
+    ap.add_argument("--cpu-m-sample", type=int, default=2048, help="prediction points of the CPU baseline's bounded sample")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] extras")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--role", choices=("auto", "headline", "dist-extra"), default="auto", help="internal: set by the launcher")
