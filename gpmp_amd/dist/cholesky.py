@@ -147,6 +147,23 @@ class HipLocalOps:
         out = self.gnp.coldots(V, w.reshape(-1, 1))
         return out[0], out[1]
 
+    def coldots_many(self, V, W):
+        """(W^T V as an (r, m) array, column sums of squares of V) in one pass over V (W: rows x r, r <= 72)."""
+        out = self.gnp.coldots(V, self.gnp.as_matrix(W))
+        return out[:-1], out[-1]
+
+    def matmul(self, A, B):
+        """A B through the library GEMM (A: M x K view, B: K x r)."""
+        g = self.gnp
+        M, K = A.shape
+        out = g.alloc_matrix(M, B.shape[1])
+        if M == 0:
+            return out
+        Bm = g.as_matrix(B, copy=True)
+        self._lib.check(self.lib.gpmp_dgemm(0, 0, M, B.shape[1], K, 1.0, g._ptr(A), g._ld(A), g._ptr(Bm), g._ld(Bm), 0.0, g._ptr(out),
+                                            g._ld(out), 0, g._stream()), "gpmp_dgemm")
+        return out
+
     def pairwise_variance(self, cov, xt, covparam):
         return self.gnp.asarray(cov(xt, None, covparam, pairwise=True)).reshape(-1)
 
@@ -754,11 +771,19 @@ class BlockCyclicCholesky:
         return float(t.item())
 
     def solve_lower_vector(self, z):
-        """w = L^-1 z for a replicated vector z (n,): block forward substitution with one broadcast and
-        one all-reduce of the update per block column."""
+        """w = L^-1 z for a replicated vector z (n,): see solve_lower_few."""
+        return self.solve_lower_few(np.asarray(z, dtype=np.float64).reshape(-1, 1))[:, 0]
+
+    def solve_lower_few(self, Z):
+        """W = L^-1 Z for a REPLICATED n x r matrix with a few columns ([z, P] of REML / LOO: r = 1 + q): block forward
+        substitution with one broadcast and one all-reduce of the update per block column.  Returns the replicated W
+        (device tensor with RCCL, CPU tensor with gloo)."""
         g, ops, nb = self.grid, self.ops, self.nb
         dev = "cuda" if self.backend == "nccl" else "cpu"
-        w = torch.as_tensor(np.asarray(z, dtype=np.float64)).to(dev).clone()
+        w = torch.as_tensor(np.asarray(Z, dtype=np.float64)).to(dev).clone()
+        if w.dim() != 2 or w.shape[0] != self.n:
+            raise ValueError("expected an n x r matrix")
+        r = w.shape[1]
         gri = torch.as_tensor(self.global_row_index(), dtype=torch.int64, device=dev)    # global row of every local row
         for k in range(self.nblocks):
             rd, cd = g.owner_row(k), g.owner_col(k)
@@ -767,7 +792,13 @@ class BlockCyclicCholesky:
             wk = w[k0:k0 + bk].clone()
             if g.r == rd and g.c == cd:
                 Lkk, dinv = self.diag_cache[k]
-                wk = ops.solve_lower_vec(Lkk, dinv, ops.asarray(w[k0:k0 + bk])).to(dev)
+                if r == 1:
+                    wk = ops.solve_lower_vec(Lkk, dinv, ops.asarray(wk[:, 0])).to(dev).reshape(-1, 1)
+                else:
+                    blk = ops.empty(bk, r)
+                    blk.copy_(ops.asarray(wk))
+                    ops.trsm_left(Lkk, dinv, blk)
+                    wk = blk.to(dev)
             wk = wk.contiguous()
             self._step_label = f"vec{k}"
             self._log(g.world_group, "broadcast", g.rank_of(rd, cd), wk.numel())
@@ -776,13 +807,16 @@ class BlockCyclicCholesky:
             rest = self.n - (k0 + bk)
             if rest <= 0:
                 continue
-            delta = torch.zeros(rest, dtype=torch.float64, device=dev)
+            delta = torch.zeros((rest, r), dtype=torch.float64, device=dev)
             if g.c == cd:
                 i0 = self._first_row_after(k)
                 if i0 < len(self.row_blocks):
                     lj = k // g.pc
                     P = self.A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]]
-                    upd = ops.matvec(P, ops.asarray(wk)).to(dev)
+                    if r == 1:
+                        upd = ops.matvec(P, ops.asarray(wk[:, 0])).to(dev).reshape(-1, 1)
+                    else:
+                        upd = ops.matmul(P, ops.asarray(wk)).to(dev)
                     delta[gri[self.roff[i0]:] - (k0 + bk)] = upd
             self._all_reduce(delta, dist.ReduceOp.SUM, g.world_group, "vec_update")
             w[k0 + bk:] -= delta
@@ -954,3 +988,82 @@ class BlockCyclicCholesky:
             return math.inf
         w = self.solve_lower_vector(z)
         return 0.5 * (self.n * math.log(2.0 * math.pi) + self.logdet() + float((w * w).sum().item()))
+
+    def negative_log_restricted_likelihood(self, z, P) -> float:
+        """REML criterion (gpmp/core/likelihood.py:92-129) on the distributed factor, with the exact restatement the
+        single-GPU path uses: for W an orthonormal basis of Null(P^T),
+            ln|W^T K W| = ln|K| + ln|P^T K^-1 P| - ln|P^T P|,   (W^T z)^T (W^T K W)^-1 (W^T z) = z^T K^-1 z - b^T S^-1 b,
+        S = P^T K^-1 P = Wp^T Wp, b = Wp^T wz with [wz, Wp] = L^-1 [z, P]: ONE forward solve with 1 + q replicated columns,
+        then q x q algebra on the host.  P: the n x q mean design (replicated)."""
+        if self.info:
+            return math.inf
+        z = np.asarray(z, dtype=np.float64).reshape(-1)
+        P = np.asarray(P, dtype=np.float64).reshape(self.n, -1)
+        q = P.shape[1]
+        W = self.solve_lower_few(np.hstack((z.reshape(-1, 1), P))).cpu().numpy()
+        wz, Wp = W[:, 0], W[:, 1:]
+        S = Wp.T @ Wp
+        b = Wp.T @ wz
+        try:
+            cS = np.linalg.cholesky(S)
+            cP = np.linalg.cholesky(P.T @ P)
+        except np.linalg.LinAlgError:
+            return math.inf                       # rank-deficient mean design: the reference's safe_inf() convention
+        y = np.linalg.solve(cS, b)
+        logdet = self.logdet() + 2.0 * np.sum(np.log(np.diag(cS))) - 2.0 * np.sum(np.log(np.diag(cP)))
+        return 0.5 * ((self.n - q) * math.log(2.0 * math.pi) + logdet + float(wz @ wz - y @ y))
+
+    def loo(self, z, P=None):
+        """Leave-one-out predictions by virtual cross-validation (gpmp/core/loo.py:65-83 zero mean; :103-130 with a linear
+        predictor, in the form Qinv = K^-1 - U S^-1 U^T, U = K^-1 P of gpmp_amd/core/loo.py) on the distributed factor.
+        T = L^-1 comes from the many-right-hand-side solve on the identity (its columns split over the process columns like
+        prediction points); diag(K^-1) = column sums of squares of T and K^-1 [z, P] = T^T (L^-1 [z, P]) are ONE pass over
+        the local part of T + one all-reduce inside the process column.  Returns (zloo, sigma2loo, eloo, (j0, j1)): this
+        process column's shard of the n leave-one-out results (identical on the ranks of a process column), NumPy arrays."""
+        from .predict import shard_bounds
+
+        if self.info:
+            raise np.linalg.LinAlgError("the distributed factorisation failed (not positive definite): no leave-one-out")
+        g, ops = self.grid, self.ops
+        z = np.asarray(z, dtype=np.float64).reshape(-1)
+        Y = z.reshape(-1, 1) if P is None else np.hstack((z.reshape(-1, 1), np.asarray(P, dtype=np.float64).reshape(self.n, -1)))
+        r = Y.shape[1]
+        j0, j1 = shard_bounds(self.n, g.pc, g.c)
+        ri = self.global_row_index()
+        eye = ops.empty(len(ri), j1 - j0)
+        eye.zero_()
+        hit = np.nonzero((ri >= j0) & (ri < j1))[0]
+        if len(hit):
+            eye[torch.as_tensor(hit, device=eye.device), torch.as_tensor(ri[hit] - j0, device=eye.device)] = 1.0
+        T = self.solve_lower_many(eye)                                   # local rows x column shard of L^-1
+        W = self.solve_lower_few(Y)                                      # replicated L^-1 [z, P]
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        part = torch.zeros((r + 1, j1 - j0), dtype=torch.float64, device=dev)
+        if len(ri) and j1 > j0:
+            Wloc = ops.asarray(W[torch.as_tensor(ri, device=W.device)])
+            dots, ssq = ops.coldots_many(T, Wloc)                        # (r, m_c): T^T W;  (m_c,): column sums of squares
+            part[:r], part[r] = dots.to(dev), ssq.to(dev)
+        if g.pr > 1:
+            self._step_label = "loo_reduce"
+            self._all_reduce(part, dist.ReduceOp.SUM, g.col_group, "loo")
+        part = part.cpu().numpy()
+        X, dK = part[:r].T, part[r]                                      # K^-1 [z, P] (shard rows), diag(K^-1)
+        zs = z[j0:j1]
+        if P is None:
+            eloo = X[:, 0] / dK
+            return zs - eloo, 1.0 / dK, eloo, (j0, j1)
+        # S = P^T K^-1 P and z^T K^-1 P need every shard: one small all-reduce over the process ROW (each column shard once)
+        Pn = np.asarray(P, dtype=np.float64).reshape(self.n, -1)
+        U = X[:, 1:]
+        G = torch.as_tensor(np.vstack((z[j0:j1] @ U, Pn[j0:j1].T @ U)))
+        G = G.to("cuda") if self.backend == "nccl" else G
+        if g.pc > 1:
+            self._all_reduce(G, dist.ReduceOp.SUM, g.row_group, "loo_meanspace")
+        G = G.cpu().numpy()
+        S = 0.5 * (G[1:] + G[1:].T)
+        US = U @ np.linalg.inv(S)
+        Qz = X[:, 0] - US @ G[0]
+        Qd = dK - np.sum(US * U, axis=1)
+        eloo = Qz / Qd
+        return zs - eloo, 1.0 / Qd, eloo, (j0, j1)
+

@@ -54,5 +54,11 @@ class CpuLocalOps:
     def coldots(self, V, w):
         return V.T @ w, (V * V).sum(dim=0)
 
+    def coldots_many(self, V, W):
+        return W.T @ V, (V * V).sum(dim=0)
+
+    def matmul(self, A, B):
+        return A @ B
+
     def pairwise_variance(self, cov, xt, covparam):
         return torch.as_tensor(np.ascontiguousarray(cov(xt.numpy(), None, covparam, True)))

@@ -312,3 +312,58 @@ def test_issue_order_is_identical_on_all_members_of_every_communicator(tmp_path,
     # the roots rotate as the block-cyclic layout says: row communicator r sees every process column as a root
     roots = {e[2] for e in per_comm["row0"][0][1]}
     assert roots == set(range(pc))
+
+
+def _reml_loo_worker(rank, world, port, pr, pc, n, nb, q, out):
+    _init(rank, world, port)
+    try:
+        from gpmp_amd.dist import BlockCyclicCholesky, ProcessGrid
+        from tests.cpu_local_ops import CpuLocalOps
+
+        x, z = make_xz(n, 3, 7)
+        th = theta_aniso(3, scale=0.4)
+        P = None if q == 0 else np.hstack((np.ones((n, 1)), x))[:, :q]
+        grid = ProcessGrid(pr, pc)
+        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=CpuLocalOps())
+        ch.build_local_gram(_cov, x, th, 1e-6)
+        assert ch.factor() == 0
+        reml = ch.negative_log_restricted_likelihood(z, P) if q else ch.negative_log_likelihood(z)
+        zloo, s2, eloo, (j0, j1) = ch.loo(z, P)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (grid.r, j0, j1, zloo, s2, eloo, reml))
+        if rank == 0:
+            full = np.full((3, n), np.nan)
+            for (r, a, b, zl, s, e, v) in gathered:
+                assert v == reml                                  # the criterion is replicated
+                if r == 0:
+                    full[0, a:b], full[1, a:b], full[2, a:b] = zl, s, e
+            np.save(out, np.vstack((full, np.full((1, n), reml))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pr,pc,n,nb,q", [(2, 2, 700, 128, 0), (2, 2, 700, 128, 1), (1, 2, 500, 128, 3), (2, 1, 500, 128, 1), (2, 4, 1100, 128, 2)])
+def test_block_cyclic_reml_and_leave_one_out(tmp_path, pr, pc, n, nb, q):
+    """REML (likelihood.py:92-129) and leave-one-out (loo.py:65-83,103-130) from the 2-D block-cyclic factor against the
+    oracle's complete-QR / explicit-inverse routes; q = 0 is the zero-mean pair (NLL, zero-mean LOO)"""
+    world = pr * pc
+    out = str(tmp_path / "r.npy")
+    mp.spawn(_reml_loo_worker, args=(world, _free_port(), pr, pc, n, nb, q, out), nprocs=world, join=True)
+    got = np.load(out)
+    x, z = make_xz(n, 3, 7)
+    th = theta_aniso(3, scale=0.4)
+    # K(x, x) + 1e-6 I on the ii path (identity dispatch as gpmp/kernel/matern.py:124-141: `y is x or y is None`)
+    cov = lambda a, b, t, pairwise=False: (orc.maternp_covariance_it(a, a if b is None else b, 2, t, pairwise)            # noqa: E731
+                                           + (1e-6 * np.eye(len(a)) if ((b is None or b is a) and not pairwise) else 0.0))
+    if q == 0:
+        om = orc.OracleModel(None, cov, None, th, "zero")
+        ref_v = float(orc.negative_log_likelihood_zero_mean(om, th, x, z))
+    else:
+        mean = lambda a, p: np.hstack((np.ones((len(a), 1)), a))[:, :q]      # noqa: E731
+        om = orc.OracleModel(mean, cov, None, th, "linear_predictor")
+        ref_v = float(orc.negative_log_restricted_likelihood(om, th, x, z))
+    rz, rs, re_ = orc.loo(om, x, z)
+    assert abs(got[3, 0] - ref_v) < 1e-9 * abs(ref_v)
+    assert np.max(np.abs(got[0] - rz)) < 1e-7 * np.max(np.abs(z))
+    assert np.max(np.abs(got[1] - rs) / rs) < 1e-7
+    assert np.max(np.abs(got[2] - re_)) < 1e-7 * np.max(np.abs(z))

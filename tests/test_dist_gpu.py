@@ -213,3 +213,65 @@ def test_cpp_rccl_host_on_the_step_abi(tmp_path, n, nb):
     assert re.search(r"info=0 ", p.stdout)
     rel = float(re.search(r"rel_diff=([-+0-9.eE]+)", p.stdout).group(1))
     assert rel < 1e-12, p.stdout
+
+
+def _reml_loo_worker(rank, world, port, pr, pc, n, nb, q, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gpmp_amd.num as gnp
+        from gpmp_amd.dist import BlockCyclicCholesky, HipLocalOps, ProcessGrid
+        from gpmp_amd.kernel import MaternCovariance
+
+        x, z = make_xz(n, 4, 11)
+        th = theta_aniso(4, scale=0.5)
+        P = None if q == 0 else np.hstack((np.ones((n, 1)), x))[:, :q]
+        grid = ProcessGrid(pr, pc)
+        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=HipLocalOps())
+        ch.build_local_gram(MaternCovariance(2), x, th, 10.0 * math.exp(th[0]) * gnp.eps)
+        assert ch.factor() == 0
+        v = ch.negative_log_restricted_likelihood(z, P) if q else ch.negative_log_likelihood(z)
+        zloo, s2, eloo, (j0, j1) = ch.loo(z, P)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (grid.r, j0, j1, zloo, s2, eloo))
+        if rank == 0:
+            full = np.full((3, n), np.nan)
+            for (r, a, b, zl, s, e) in gathered:
+                if r == 0:
+                    full[0, a:b], full[1, a:b], full[2, a:b] = zl, s, e
+            np.save(out, np.vstack((full, np.full((1, n), v))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pr,pc,n,nb,q", [(2, 2, 2000, 256, 1), (1, 2, 1500, 256, 0), (2, 1, 1800, 512, 3)])
+def test_block_cyclic_reml_and_loo_hip(tmp_path, pr, pc, n, nb, q):
+    """REML and leave-one-out from the block-cyclic factor with the real kernels (ranks share the test GPU over gloo) against the
+    oracle (complete-QR REML, explicit-inverse LOO); LOO's T = L^-1 goes through the overlapped many-right-hand-side solve"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+
+    world = pr * pc
+    out = str(tmp_path / "r.npy")
+    mp.spawn(_reml_loo_worker, args=(world, _free_port(), pr, pc, n, nb, q, out), nprocs=world, join=True)
+    got = np.load(out)
+    x, z = make_xz(n, 4, 11)
+    th = theta_aniso(4, scale=0.5)
+    cov = lambda a, b, t, pairwise=False: orc.maternp_covariance(a, b, 2, t, pairwise)       # noqa: E731
+    if q == 0:
+        om = orc.OracleModel(None, cov, None, th, "zero")
+        ref_v = float(orc.negative_log_likelihood_zero_mean(om, th, x, z))
+    else:
+        om = orc.OracleModel(lambda a, p: np.hstack((np.ones((len(a), 1)), a))[:, :q], cov, None, th, "linear_predictor")
+        ref_v = float(orc.negative_log_restricted_likelihood(om, th, x, z))
+    rz, rs, re_ = orc.loo(om, x, z)
+    ev = np.linalg.eigvalsh(orc.maternp_covariance(x, None, 2, th))
+    cs = max(1.0, float(ev[-1] / ev[0]) / 1e6)
+    assert abs(got[3, 0] - ref_v) < 1e-11 * cs * abs(ref_v)
+    assert np.max(np.abs(got[0] - rz)) < 1e-8 * cs * np.max(np.abs(z))
+    assert np.max(np.abs(got[1] - rs) / rs) < 1e-8 * cs
+    assert np.max(np.abs(got[2] - re_)) < 1e-8 * cs * np.max(np.abs(z))
