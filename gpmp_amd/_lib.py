@@ -48,6 +48,7 @@ SIGNATURES = {
     "gpmp_coldots_ws_rows": (c_int, [c_int]),
     "gpmp_logdet_chol": (c_int, [_P, c_int, c_long, _P, _P]),
     "gpmp_matern_grad_trace": (c_int, [_P, c_long, _P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, c_long, _P, _P, _P]),
+    "gpmp_matern_grad_trace_cross": (c_int, [_P, c_long, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, c_long, _P, _P, _P]),
     "gpmp_grad_ws_elems": (c_size_t, [c_int, c_int]),
     "gpmp_nll_ws_elems": (c_size_t, [c_int]),
     "gpmp_nll_zero_mean": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),

@@ -358,6 +358,10 @@ struct GradParams {
   long stride_kinv, stride_x, stride_f, stride_partial;
   const int* ns;
   const double* pp;              // per-problem parameter blocks (see GramParams), or nullptr
+  // cross mode (grad_trace_kernel<DT, false, true>): M is a RECTANGULAR n x m block of a larger matrix, its rows belong to the
+  // points x and its columns to the points y; every entry weighs 1 (no symmetric doubling), no trace term
+  const double* y;
+  int m, ntiles_c;
   double invrho[GPMP_MAX_DIM];   // 2 c / rho_j: the tile accumulates t^2 = (2 c h)^2 and the weights are per (2 c delta_j)^2
   MaternSpec ms;
   FastExp fe;
@@ -377,7 +381,7 @@ __device__ __forceinline__ double matern_dk_over_h(const MaternSpec& ms, double 
 
 // PP: length scales from the problem's parameter block in device memory instead of the kernel arguments (a run-time choice
 // between the two sources made the compiler copy the argument block to scratch memory: compile-time instead)
-template <int DT, bool PP = false>
+template <int DT, bool PP = false, bool CROSS = false>
 __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* xs = sm;                    // [DT][GT]
@@ -394,6 +398,9 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
   // (locals, never a store into the parameter block: see gram_kernel_v3)
   const double* __restrict__ pKinv = p.Kinv;
   const double* __restrict__ px = p.x;
+  const double* __restrict__ py = CROSS ? p.y : p.x;
+  const int pm = CROSS ? p.m : 0;
+  (void)pm;
   const double* __restrict__ pF = p.F;
   const double* __restrict__ pG = p.G;
   double* __restrict__ ppartial = p.partial;
@@ -415,11 +422,18 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
   }
 
   for (int tile = blockIdx.x; tile < pntiles; tile += gridDim.x) {
-    int ti = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
-    while (ti * (ti + 1) / 2 > tile) --ti;
-    const int tj = tile - ti * (ti + 1) / 2;
+    int ti, tj;
+    if constexpr (CROSS) {
+      ti = tile / p.ntiles_c;
+      tj = tile - ti * p.ntiles_c;
+    } else {
+      ti = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+      while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+      while (ti * (ti + 1) / 2 > tile) --ti;
+      tj = tile - ti * (ti + 1) / 2;
+    }
     const int row0 = ti * GT, col0 = tj * GT;
+    const int ncols = CROSS ? pm : pn;            // valid columns
     __syncthreads();
     for (int idx = t; idx < DT * GT; idx += 256) {
       const int r = idx / DT, k = idx % DT;
@@ -428,7 +442,7 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
         double ir;
         if constexpr (PP) ir = ppb[k]; else ir = p.invrho[k];
         if (row0 + r < pn) vx = ir * px[(long)(row0 + r) * p.d + k];
-        if (col0 + r < pn) vy = ir * px[(long)(col0 + r) * p.d + k];
+        if (col0 + r < ncols) vy = ir * py[(long)(col0 + r) * p.d + k];
       }
       xs[k * GT + r] = vx;
       ys[k * GT + r] = vy;
@@ -436,7 +450,7 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
     for (int idx = t; idx < p.r * GT; idx += 256) {
       const int r = idx / p.r, a = idx % p.r;
       fs[a * GT + r] = (row0 + r < pn) ? pF[(long)(row0 + r) * p.ldf + a] : 0.0;
-      gs[a * GT + r] = (col0 + r < pn) ? pG[(long)(col0 + r) * p.ldf + a] : 0.0;
+      gs[a * GT + r] = (col0 + r < ncols) ? pG[(long)(col0 + r) * p.ldf + a] : 0.0;
     }
     __syncthreads();
 
@@ -475,7 +489,11 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
       for (int b = 0; b < 4; ++b) {
         const int col = col0 + tx * 4 + b;
         double wt = 0.0;
-        if (row < pn && col < pn) wt = col < row ? 2.0 : (col == row ? 1.0 : 0.0);
+        if constexpr (CROSS) {
+          if (row < pn && col < ncols) wt = 1.0;
+        } else {
+          if (row < pn && col < pn) wt = col < row ? 2.0 : (col == row ? 1.0 : 0.0);
+        }
         double mval = 0.0;
         if (wt != 0.0) mval = wt * (pKinv[(long)row * p.ldk + col] - w[a][b]);
         // K(h) = e^{-t/2} sum q_k t^k and (K'(h)/h) / (2c)^2 = e^{-t/2} sum_{k>=1} s_k t^{k-1} (p >= 1), t = 2 c h
@@ -493,7 +511,7 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
           dk = e * sp;
         }
         g0 = fma(mval, kval, g0);
-        if (row == col) gtr += mval;
+        if (!CROSS && row == col) gtr += mval;
         w[a][b] = mval * dk;  // weight of (delta_j)^2 for every dimension j
       }
     }
@@ -800,6 +818,7 @@ int launch_grad_trace_batch(const double* Kinv, long ldk, long stride_kinv, cons
                             long stride_f, double* g_dev, double* ws, int nprob, hipStream_t st, const double* pp_dev) {
   GradParams gp;
   gp.pp = nullptr;
+  gp.y = nullptr; gp.m = 0; gp.ntiles_c = 0;
   gp.Kinv = Kinv; gp.ldk = ldk; gp.x = x; gp.F = F; gp.G = G; gp.ldf = ldf;
   gp.n = nmax; gp.d = d; gp.r = r;
   gp.ntiles_side = (nmax + GT - 1) / GT;
@@ -872,6 +891,7 @@ extern "C" int gpmp_matern_grad_trace(const double* Kinv, long ldk, const double
   GradParams gp;
   gp.pp = nullptr;
   gp.nprob = 1; gp.stride_kinv = gp.stride_x = gp.stride_f = gp.stride_partial = 0; gp.ns = nullptr;
+  gp.y = nullptr; gp.m = 0; gp.ntiles_c = 0;
   gp.Kinv = Kinv; gp.ldk = ldk; gp.x = x; gp.F = F; gp.G = G; gp.ldf = ldf;
   gp.n = n; gp.d = d; gp.r = r;
   gp.ntiles_side = (n + GT - 1) / GT;
@@ -899,6 +919,68 @@ extern "C" int gpmp_matern_grad_trace(const double* Kinv, long ldk, const double
   const double noise_var = noise ? std::exp(theta_host[1]) : 0.0;
   hipLaunchKernelGGL(grad_finalize_kernel, dim3(1), dim3(128), 0, st, ws, nblocks, dt + 2, d, noise,
                      gp.sigma2, nugget_scale, noise_var, g_dev);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// cross traces: g[0] = sigma2 sum M Kc, g[1 + j] = sigma2 sum M (K'/h) delta_j^2  (no nugget / noise terms: the caller owns tr(M))
+__global__ void grad_cross_finalize_kernel(const double* __restrict__ partial, int nblocks, int width, int d, double sigma2,
+                                           double* __restrict__ g) {
+  const int k = threadIdx.x;
+  if (k > d) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * width + k];
+  g[k] = sigma2 * s;
+}
+
+extern "C" int gpmp_matern_grad_trace_cross(const double* M, long ldm, const double* x, int n, const double* y, int m, int d, int p,
+                                            const double* theta_host, int noise, const double* F, const double* G, int r, long ldf,
+                                            double* g_dev, double* ws, gpmp_stream_t stream) {
+  GPMP_ARG(M != nullptr, 1, "M is NULL");
+  GPMP_ARG(x != nullptr && y != nullptr, 3, "x or y is NULL");
+  GPMP_ARG(n >= 1 && m >= 1 && ldm >= m, 4, "n < 1, m < 1 or ldm < m");
+  GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 7, "d outside [1, GPMP_MAX_DIM]");
+  GPMP_ARG(p >= 0 && p <= GPMP_MAX_P, 8, "p outside [0, GPMP_MAX_P]");
+  GPMP_ARG(theta_host != nullptr, 9, "theta is NULL");
+  GPMP_ARG(r >= 0 && r <= GPMP_MAX_RANK, 13, "r outside [0, GPMP_MAX_RANK]");
+  GPMP_ARG(r == 0 || (F != nullptr && G != nullptr), 11, "F/G NULL with r > 0");
+  GPMP_ARG(g_dev != nullptr && ws != nullptr, 15, "g or ws is NULL");
+  GradParams gp;
+  gp.pp = nullptr;
+  gp.nprob = 1; gp.stride_kinv = gp.stride_x = gp.stride_f = gp.stride_partial = 0; gp.ns = nullptr;
+  gp.Kinv = M; gp.ldk = ldm; gp.x = x; gp.y = y; gp.F = F; gp.G = G; gp.ldf = ldf;
+  gp.n = n; gp.m = m; gp.d = d; gp.r = r;
+  gp.ntiles_side = (n + GT - 1) / GT;
+  gp.ntiles_c = (m + GT - 1) / GT;
+  const long nt = (long)gp.ntiles_side * gp.ntiles_c;
+  GPMP_ARG(nt < 0x7FFFFFFFL, 4, "too many tiles");
+  gp.ntiles = (int)nt;
+  gp.sigma2 = std::exp(theta_host[0]);
+  gp.partial = ws;
+  const int off = noise ? 2 : 1;
+  fill_matern(gp.ms, p);
+  for (int k = 0; k < d; ++k) gp.invrho[k] = 2.0 * gp.ms.c * std::exp(theta_host[off + k]);
+  fill_fast_exp(gp.fe);
+  const int nblocks = gp.ntiles < GRAD_BLOCKS ? gp.ntiles : GRAD_BLOCKS;
+  const int dt = grad_tier(d);
+  hipStream_t st = as_stream(stream);
+  const size_t lds = sizeof(double) * (2 * (size_t)dt * GT + 2 * (size_t)r * GT);
+  auto go = [&](auto kern) -> int {
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, gp);
+    GPMP_HIP_TRY(hipGetLastError());
+    return 0;
+  };
+  int rc = 0;
+  switch (dt) {
+    case 4: rc = go(grad_trace_kernel<4, false, true>); break;
+    case 8: rc = go(grad_trace_kernel<8, false, true>); break;
+    case 16: rc = go(grad_trace_kernel<16, false, true>); break;
+    case 32: rc = go(grad_trace_kernel<32, false, true>); break;
+    default: rc = go(grad_trace_kernel<64, false, true>); break;
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(grad_cross_finalize_kernel, dim3(1), dim3(128), 0, st, ws, nblocks, dt + 2, d, gp.sigma2, g_dev);
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }

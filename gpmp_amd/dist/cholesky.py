@@ -167,6 +167,42 @@ class HipLocalOps:
     def pairwise_variance(self, cov, xt, covparam):
         return self.gnp.asarray(cov(xt, None, covparam, pairwise=True)).reshape(-1)
 
+    def gemm_tn(self, A, B):
+        """A^T B through the library GEMM (A: K x M, B: K x N views) -> M x N."""
+        g = self.gnp
+        K, M = A.shape
+        N = B.shape[1]
+        out = g.alloc_matrix(M, N, zero=(K == 0))
+        if K == 0 or M == 0 or N == 0:
+            return out
+        self._lib.check(self.lib.gpmp_dgemm(1, 0, M, N, K, 1.0, g._ptr(A), g._ld(A), g._ptr(B), g._ld(B), 0.0, g._ptr(out), g._ld(out), 0,
+                                            g._stream()), "gpmp_dgemm")
+        return out
+
+    def grad_trace_cross(self, M, xr, xc, p, covparam, noise, F, G):
+        """[sum M sigma^2 Kc, sum M dK/dlog(1/rho_j) ...] over the rectangular block M (rows: points xr, columns: points xc),
+        M <- M - F G^T in registers: gpmp_matern_grad_trace_cross.  Returns a (1 + d,) device vector."""
+        g = self.gnp
+        n, m = M.shape
+        d = xr.shape[1]
+        out = torch.zeros(1 + d, dtype=torch.float64, device=self.device)
+        if n == 0 or m == 0:
+            return out
+        r = 0 if F is None else F.shape[1]
+        Fm = Gm = None
+        if r:
+            # (same leading dimension for both: the kernel takes one ldf)
+            Fm, Gm = g.alloc_matrix(n, r), g.alloc_matrix(m, r)
+            Fm.copy_(g.asarray(F))
+            Gm.copy_(g.asarray(G))
+        xr, xc = g.asarray(xr).contiguous(), g.asarray(xc).contiguous()
+        ws = torch.empty(int(self.lib.gpmp_grad_ws_elems(n, d)), dtype=torch.float64, device=self.device)
+        self._lib.check(self.lib.gpmp_matern_grad_trace_cross(g._ptr(M), g._ld(M), g._ptr(xr), n, g._ptr(xc), m, d, int(p),
+                                                              self._lib.host_vec(covparam), 1 if noise else 0, g._ptr(Fm), g._ptr(Gm), r,
+                                                              g._ld(Fm) if r else 1, g._ptr(out), g._ptr(ws), g._stream()),
+                        "gpmp_matern_grad_trace_cross")
+        return out
+
     # ---- one block-column step through gpmp_dist_* (include/gpmp_hip.h): what a C++ / RCCL host calls between its
     # collectives (examples/dist_potrf_rccl.cpp).  ``lay`` = (n, nb, Pr, Pc, r, c).  The schedule uses these when the
     # local-ops object has them; the generic tensor-level code they replace stays for the CPU stand-in of the tests.
@@ -451,6 +487,24 @@ class BlockCyclicCholesky:
         if ct.data_ptr() != t.data_ptr():
             t.copy_(ct)
         return t
+
+    def _ring_shift(self, t: torch.Tensor, shift: int) -> torch.Tensor:
+        """Inside the process row: send ``t`` to the rank ``shift`` process columns to the left, receive the tensor of the rank
+        ``shift`` columns to the right (same shape on every rank of the row up to the column count, which is passed along)."""
+        g = self.grid
+        dst, src = g.rank_of(g.r, (g.c - shift) % g.pc), g.rank_of(g.r, (g.c + shift) % g.pc)
+        ct = _comm_tensor(t, self.backend)
+        # shapes differ by at most one column between shards: agree on the incoming column count first (host integers)
+        from .predict import shard_bounds
+
+        j0, j1 = shard_bounds(self.n, g.pc, (g.c + shift) % g.pc)
+        buf = torch.empty((ct.shape[0], j1 - j0), dtype=ct.dtype, device=ct.device)
+        self._log(g.row_group, f"ring_shift{shift}", -1, ct.shape[0])     # (rows: the same on every member; the column counts differ by <= 1)
+        reqs = [dist.P2POp(dist.isend, ct, dst, g.row_group), dist.P2POp(dist.irecv, buf, src, g.row_group)]
+        for w in dist.batch_isend_irecv(reqs):
+            w.wait()
+        self.bytes_received += buf.numel() * 8
+        return buf if buf.device == t.device else buf.to(t.device)
 
     def _all_reduce(self, t: torch.Tensor, op, group, what: str):
         self._log(group, f"all_reduce:{what}", -1, t.numel())
@@ -1066,4 +1120,109 @@ class BlockCyclicCholesky:
         Qd = dK - np.sum(US * U, axis=1)
         eloo = Qz / Qd
         return zs - eloo, 1.0 / Qd, eloo, (j0, j1)
+
+
+    # ---- analytic gradient of the ML / REML criteria on the distributed factor
+    def value_and_grad(self, x, z, covparam, p, noise=False, P=None):
+        """Value and gradient of the zero-mean NLL (P None; gpmp/core/likelihood.py:18-52) or of the REML criterion with mean
+        design P (likelihood.py:92-129) with respect to the covariance parameters, from the block-cyclic factor of
+        K(x, x; covparam) -- the criterion a parameter fit at n beyond one GPU's HBM evaluates
+        (gpmp/kernel/parameter_selection.py:35-124; the reference has no analytic form: finite differences / autograd).
+            g_j = 1/2 sum_ik (Qinv_ik - beta_i beta_k) dK_ik/dtheta_j,  Qinv = K^-1 - U S^-1 U^T, U = K^-1 P, beta = Qinv z
+        as gpmp_amd/core/gradients.py, with K^-1 = T^T T never assembled in one place: T = L^-1 is the many-right-hand-side
+        solve on the identity (rows over the process rows, columns over the process columns); process column c forms the blocks
+        (shard c, shard c') of T^T T from its own rows -- T travels around the process row (a ring of Pc / 2 shifts, blocks
+        c != c' count twice) -- and traces each block against the matching block of dK in one fused pass
+        (gpmp_matern_grad_trace_cross: dK is recomputed on the fly, the low-rank part is subtracted in registers).  Partial
+        sums over the process rows need no matrix reduction: the trace is linear, so ONE all-reduce of d + 3 doubles ends it.
+        Flops: n^3 / P for T and n^3 / P for the blocks (T's triangle is not exploited: 3x the 2n^3/3 of a blocked potri)."""
+        from .predict import shard_bounds
+
+        g, ops = self.grid, self.ops
+        if self.info:
+            return math.inf, np.zeros(len(covparam))
+        x = np.asarray(x, dtype=np.float64)
+        z = np.asarray(z, dtype=np.float64).reshape(-1)
+        n, d = x.shape
+        q = 0 if P is None else np.asarray(P).reshape(n, -1).shape[1]
+        Pn = None if P is None else np.asarray(P, dtype=np.float64).reshape(n, q)
+        off = 2 if noise else 1
+        th = np.asarray(covparam, dtype=np.float64)
+        sigma2 = math.exp(th[0])
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        # ---- T = L^-1 (local rows x column shard), W = L^-1 [z, P] replicated, X = K^-1 [z, P] = T^T W for my shard
+        j0, j1 = shard_bounds(n, g.pc, g.c)
+        ri = self.global_row_index()
+        eye = ops.empty(len(ri), j1 - j0)
+        eye.zero_()
+        hit = np.nonzero((ri >= j0) & (ri < j1))[0]
+        if len(hit):
+            eye[torch.as_tensor(hit, device=eye.device), torch.as_tensor(ri[hit] - j0, device=eye.device)] = 1.0
+        T = self.solve_lower_many(eye)
+        Y = z.reshape(-1, 1) if Pn is None else np.hstack((z.reshape(-1, 1), Pn))
+        W = self.solve_lower_few(Y)
+        r1 = Y.shape[1]
+        part = torch.zeros((r1 + 1, j1 - j0), dtype=torch.float64, device=dev)
+        if len(ri) and j1 > j0:
+            dots, ssq = ops.coldots_many(T, ops.asarray(W[torch.as_tensor(ri, device=W.device)]))
+            part[:r1], part[r1] = dots.to(dev), ssq.to(dev)
+        if g.pr > 1:
+            self._step_label = "grad_reduce"
+            self._all_reduce(part, dist.ReduceOp.SUM, g.col_group, "kinv_rows")
+        # every rank needs K^-1 [z, P] for ALL rows (the low-rank factors of other shards' columns): one small all-gather
+        # along the process row, assembled as an all-reduce of a zero-padded n x (1 + q) array
+        Xfull = torch.zeros((n, r1), dtype=torch.float64, device=dev)
+        Xfull[j0:j1] = part[:r1].T
+        trKinv = torch.zeros(1, dtype=torch.float64, device=dev)
+        trKinv[0] = part[r1].sum()
+        if g.pc > 1:
+            self._all_reduce(Xfull, dist.ReduceOp.SUM, g.row_group, "kinv_zp")
+            self._all_reduce(trKinv, dist.ReduceOp.SUM, g.row_group, "trace_kinv")
+        Xh = Xfull.cpu().numpy()
+        alpha = Xh[:, 0]
+        logdet = self.logdet()
+        if q == 0:
+            value = 0.5 * (n * math.log(2.0 * math.pi) + logdet + float(z @ alpha))
+            Fh = Gh = alpha.reshape(-1, 1)
+        else:
+            U = Xh[:, 1:]
+            S = Pn.T @ U
+            S = 0.5 * (S + S.T)
+            b = Pn.T @ alpha
+            try:
+                cS, cP = np.linalg.cholesky(S), np.linalg.cholesky(Pn.T @ Pn)
+            except np.linalg.LinAlgError:
+                return math.inf, np.zeros(len(th))
+            Sinv = np.linalg.inv(S)
+            US = U @ Sinv
+            beta = alpha - US @ b
+            value = 0.5 * ((n - q) * math.log(2.0 * math.pi) + logdet + 2.0 * np.sum(np.log(np.diag(cS))) - 2.0 * np.sum(np.log(np.diag(cP)))
+                           + float(z @ alpha - b @ (Sinv @ b)))
+            Fh, Gh = np.hstack((US, beta.reshape(-1, 1))), np.hstack((U, beta.reshape(-1, 1)))
+        # ---- blocks (shard c, shard c') of T^T T against dK: ring over the process row, half of it by symmetry
+        xs_c = x[j0:j1]
+        tot = torch.zeros(1 + d, dtype=torch.float64, device=dev)
+        half = g.pc // 2
+        for sft in range(half + 1):
+            c2 = (g.c + sft) % g.pc
+            T2 = T if sft == 0 else self._ring_shift(T, sft)
+            weight = 1.0 if (sft == 0 or (g.pc % 2 == 0 and sft == half)) else 2.0
+            k0, k1 = shard_bounds(n, g.pc, c2)
+            if j1 > j0 and k1 > k0:
+                Mblk = ops.gemm_tn(T, ops.asarray(T2))                      # (shard c) x (shard c2), partial over my rows
+                # the low-rank part must enter exactly once per block: on process row 0
+                lowF = Fh[j0:j1] if g.r == 0 else None
+                lowG = Gh[k0:k1] if g.r == 0 else None
+                tot += weight * ops.grad_trace_cross(Mblk, xs_c, x[k0:k1], p, th, noise, lowF, lowG).to(dev)
+                del Mblk
+        self._step_label = "grad_total"
+        self._all_reduce(tot, dist.ReduceOp.SUM, g.world_group, "grad_traces")
+        tot = tot.cpu().numpy()
+        trM = float(trKinv.item()) - float(np.sum(Fh * Gh))
+        grad = np.zeros(len(th))
+        grad[0] = tot[0] + (0.0 if noise else 10.0 * sigma2 * float(np.finfo(np.float64).eps) * trM)
+        if noise:
+            grad[1] = math.exp(th[1]) * trM
+        grad[off:] = tot[1:]
+        return value, 0.5 * grad
 

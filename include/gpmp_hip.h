@@ -232,6 +232,16 @@ int gpmp_predict_zero_mean(const double* xi, const double* zi, const double* xt,
 
 /* ---- fused drivers with a linear-predictor mean (REML, gradients, leave-one-out) ------------------------------- */
 
+/* The same traces over a RECTANGULAR block: M is n x m (ldm), its rows belong to the points x (n x d), its columns to the
+ * points y (m x d); every entry counts once.  g_dev[0] = sum M[i,k] sigma^2 Kc(x_i, y_k), g_dev[1 + j] = sum M[i,k]
+ * dK(x_i, y_k)/dlog(1/rho_j), j < d, with M[i,k] = Minv[i,k] - sum_a F[i,a] G[k,a] (F: n x r, G: m x r, same ldf) -- no nugget /
+ * noise term: those need tr(M), which only the caller of a blocked trace knows.  This is the building block of the gradient
+ * on a DISTRIBUTED inverse (gpmp_amd/dist: the blocks (shard c, shard c') of K^-1 = T^T T meet the matching blocks of dK).
+ * ws: gpmp_grad_ws_elems(n, d) doubles.  Enqueue only. */
+int gpmp_matern_grad_trace_cross(const double* M, long ldm, const double* x, int n, const double* y, int m, int d, int p,
+                                 const double* theta_host, int noise, const double* F, const double* G, int r, long ldf,
+                                 double* g_dev, double* ws, gpmp_stream_t stream);
+
 /* The three drivers below take the mean DESIGN matrix P = mean(xi, meanparam) (n x q row-major, leading dimension ldp, on
  * the device; q = 0 / P = NULL: zero-mean model) -- mean functions are user callables in the reference
  * (gpmp/core/model.py:30-52).  0 <= q <= GPMP_MAX_RANK - 1, q < n.  Each call only enqueues: Gram build, Cholesky, the

@@ -62,3 +62,31 @@ class CpuLocalOps:
 
     def pairwise_variance(self, cov, xt, covparam):
         return torch.as_tensor(np.ascontiguousarray(cov(xt.numpy(), None, covparam, True)))
+
+    def gemm_tn(self, A, B):
+        return A.T @ B
+
+    def grad_trace_cross(self, M, xr, xc, p, covparam, noise, F, G):
+        """NumPy restatement of gpmp_matern_grad_trace_cross (oracle formulas: oracle/gp_oracle.py covariance_gradient_traces)"""
+        import math
+
+        from scipy.spatial.distance import cdist
+
+        from oracle import gp_oracle as orc
+
+        Mn = M.numpy().copy()
+        if F is not None:
+            Mn -= np.asarray(F) @ np.asarray(G).T
+        th = np.asarray(covparam, dtype=np.float64)
+        off = 2 if noise else 1
+        inv = np.exp(th[off:])
+        xs, ys = np.asarray(xr) * inv, np.asarray(xc) * inv
+        H = cdist(xs, ys)
+        s2 = math.exp(th[0])
+        out = np.zeros(1 + xs.shape[1])
+        out[0] = s2 * np.sum(Mn * orc.maternp_kernel(p, H))
+        R = s2 * orc.maternp_dkernel_over_h(p, H) * Mn
+        for j in range(xs.shape[1]):
+            out[1 + j] = np.sum(R * (xs[:, j][:, None] - ys[:, j][None, :]) ** 2)
+        return torch.as_tensor(out)
+

@@ -266,6 +266,7 @@ def _oplog_worker(rank, world, port, pr, pc, n, m, nb, out, transport, lookahead
         assert ch.factor() == 0
         ch.negative_log_likelihood(z)
         ch.predict_zero_mean(_cov_full, x, z, xt, th)
+        ch.value_and_grad(x, z, th, 2, P=np.ones((n, 1)))           # REML gradient: ring shifts inside the process rows
         gathered = [None] * world
         dist.all_gather_object(gathered, (grid.r, grid.c, ch.oplog))
         if rank == 0:
@@ -310,8 +311,10 @@ def test_issue_order_is_identical_on_all_members_of_every_communicator(tmp_path,
     kinds = {e[1] for _, _, log in gathered for e in log}
     assert ("p2p_bcast" in kinds) == (transport == "p2p") and ("broadcast" in kinds)     # (the NLL's vector solve always broadcasts)
     # the roots rotate as the block-cyclic layout says: row communicator r sees every process column as a root
-    roots = {e[2] for e in per_comm["row0"][0][1]}
+    roots = {e[2] for e in per_comm["row0"][0][1] if e[1] in ("broadcast", "p2p_bcast")}
     assert roots == set(range(pc))
+    # the gradient's ring inside the process rows: Pc / 2 shifts, logged identically by every member
+    assert [e[1] for e in per_comm["row0"][0][1] if e[1].startswith("ring_shift")] == [f"ring_shift{s}" for s in range(1, pc // 2 + 1)]
 
 
 def _reml_loo_worker(rank, world, port, pr, pc, n, nb, q, out):
@@ -367,3 +370,55 @@ def test_block_cyclic_reml_and_leave_one_out(tmp_path, pr, pc, n, nb, q):
     assert np.max(np.abs(got[0] - rz)) < 1e-7 * np.max(np.abs(z))
     assert np.max(np.abs(got[1] - rs) / rs) < 1e-7
     assert np.max(np.abs(got[2] - re_)) < 1e-7 * np.max(np.abs(z))
+
+
+def _grad_worker(rank, world, port, pr, pc, n, nb, q, noise, out):
+    _init(rank, world, port)
+    try:
+        from gpmp_amd.dist import BlockCyclicCholesky, ProcessGrid
+        from tests.cpu_local_ops import CpuLocalOps
+
+        x, z = make_xz(n, 3, 7)
+        th = theta_aniso(3, scale=0.4)
+        if noise:
+            th = np.concatenate(([th[0], math.log(1e-3)], th[1:]))
+        P = None if q == 0 else np.hstack((np.ones((n, 1)), x))[:, :q]
+        diag = math.exp(th[1]) if noise else 10.0 * math.exp(th[0]) * np.finfo(float).eps
+        cov_it = (lambda a, b, t, pairwise=False: orc.maternp_covariance_it(np.asarray(a), np.asarray(b), 2, np.concatenate(([t[0]], t[2:])) if noise else t, pairwise))
+        grid = ProcessGrid(pr, pc)
+        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=CpuLocalOps())
+        ch.build_local_gram(cov_it, x, th, diag)
+        assert ch.factor() == 0
+        v, gvec = ch.value_and_grad(x, z, th, 2, noise=noise, P=P)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (v, gvec))
+        if rank == 0:
+            for (v2, g2) in gathered:
+                assert v2 == v and np.array_equal(g2, gvec)          # replicated
+            np.save(out, np.concatenate(([v], gvec)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pr,pc,n,nb,q,noise", [(2, 2, 600, 128, 0, False), (2, 2, 600, 128, 1, False), (1, 3, 500, 128, 2, True),
+                                                (2, 1, 400, 128, 1, True), (2, 4, 1100, 128, 0, False), (2, 4, 1100, 128, 3, False)])
+def test_block_cyclic_value_and_gradient(tmp_path, pr, pc, n, nb, q, noise):
+    """ML (q = 0) and REML value + analytic gradient from the block-cyclic factor (T = L^-1 by the many-RHS solve, the blocks
+    of T^T T formed around the process row and traced against dK block by block) against the oracle's analytic gradient
+    (itself pinned to the reference's autograd: ref_gradients.npz); odd and even process-column counts, with / without a noise
+    parameter"""
+    world = pr * pc
+    out = str(tmp_path / "g.npy")
+    mp.spawn(_grad_worker, args=(world, _free_port(), pr, pc, n, nb, q, noise, out), nprocs=world, join=True)
+    got = np.load(out)
+    x, z = make_xz(n, 3, 7)
+    th = theta_aniso(3, scale=0.4)
+    if noise:
+        th = np.concatenate(([th[0], math.log(1e-3)], th[1:]))
+    ni = 1 if noise else None
+    if q == 0:
+        v, g = orc.nll_zero_mean_value_and_grad(x, z, 2, th, noise_index=ni)
+    else:
+        v, g = orc.reml_value_and_grad(x, z, np.hstack((np.ones((n, 1)), x))[:, :q], 2, th, noise_index=ni)
+    assert abs(got[0] - v) < 1e-8 * abs(v)
+    assert np.max(np.abs(got[1:] - g)) < 1e-6 * np.max(np.abs(g)), (got[1:], g)

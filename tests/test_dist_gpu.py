@@ -275,3 +275,58 @@ def test_block_cyclic_reml_and_loo_hip(tmp_path, pr, pc, n, nb, q):
     assert np.max(np.abs(got[0] - rz)) < 1e-8 * cs * np.max(np.abs(z))
     assert np.max(np.abs(got[1] - rs) / rs) < 1e-8 * cs
     assert np.max(np.abs(got[2] - re_)) < 1e-8 * cs * np.max(np.abs(z))
+
+
+def _grad_worker(rank, world, port, pr, pc, n, nb, q, noise, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gpmp_amd.num as gnp
+        from gpmp_amd.dist import BlockCyclicCholesky, HipLocalOps, ProcessGrid
+        from gpmp_amd.kernel import MaternCovariance
+
+        x, z = make_xz(n, 4, 11)
+        th = theta_aniso(4, scale=0.5)
+        if noise:
+            th = np.concatenate(([th[0], math.log(1e-3)], th[1:]))
+        P = None if q == 0 else np.hstack((np.ones((n, 1)), x))[:, :q]
+        diag = math.exp(th[1]) if noise else 10.0 * math.exp(th[0]) * gnp.eps
+        ch = BlockCyclicCholesky(ProcessGrid(pr, pc), n, nb=nb, ops=HipLocalOps())
+        ch.build_local_gram(MaternCovariance(2, noise=noise), x, th, diag)
+        assert ch.factor() == 0
+        v, gvec = ch.value_and_grad(x, z, th, 2, noise=noise, P=P)
+        if rank == 0:
+            np.save(out, np.concatenate(([v], gvec)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pr,pc,n,nb,q,noise", [(2, 2, 2000, 256, 1, False), (1, 2, 1500, 256, 0, True), (1, 3, 1700, 256, 2, False), (1, 1, 1300, 512, 1, False)])
+def test_block_cyclic_value_and_gradient_hip(tmp_path, pr, pc, n, nb, q, noise):
+    """ML / REML value + analytic gradient from the block-cyclic factor with the real kernels (gpmp_matern_grad_trace_cross on
+    the blocks of T^T T; ranks share the test GPU over gloo) against the oracle's analytic gradient"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+
+    world = pr * pc
+    out = str(tmp_path / "g.npy")
+    mp.spawn(_grad_worker, args=(world, _free_port(), pr, pc, n, nb, q, noise, out), nprocs=world, join=True)
+    got = np.load(out)
+    x, z = make_xz(n, 4, 11)
+    th = theta_aniso(4, scale=0.5)
+    if noise:
+        th = np.concatenate(([th[0], math.log(1e-3)], th[1:]))
+    ni = 1 if noise else None
+    if q == 0:
+        v, g = orc.nll_zero_mean_value_and_grad(x, z, 2, th, noise_index=ni)
+    else:
+        v, g = orc.reml_value_and_grad(x, z, np.hstack((np.ones((n, 1)), x))[:, :q], 2, th, noise_index=ni)
+    cov = orc.noisy_maternp_covariance if noise else orc.maternp_covariance
+    ev = np.linalg.eigvalsh(cov(x, None, 2, th))
+    cs = max(1.0, float(ev[-1] / ev[0]) / 1e6)
+    assert abs(got[0] - v) < 1e-11 * cs * abs(v)
+    assert np.max(np.abs(got[1:] - g)) < 1e-8 * cs * np.max(np.abs(g)), (got[1:], g, cs)

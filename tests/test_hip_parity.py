@@ -1377,3 +1377,47 @@ def test_predict_many_shapes_vs_oracle(gp, gnp):
             scale = max(1.0, np.max(np.abs(zi)))
             assert np.max(np.abs(zpm - ozpm)) < 1e-7 * scale, (n, m, d, p, meantype)
             assert np.max(np.abs(zpv - ozpv)) < 1e-7 * math.exp(th[0]), (n, m, d, p, meantype)
+
+
+@pytest.mark.parametrize("n,m,d,p,r", [(300, 171, 3, 2, 0), (129, 400, 8, 2, 2), (64, 64, 20, 3, 1), (257, 130, 5, 0, 0), (90, 333, 2, 1, 4)])
+def test_grad_trace_cross_rectangular_block(gnp, n, m, d, p, r):
+    """gpmp_matern_grad_trace_cross: the traces of a RECTANGULAR block M (rows: points x, columns: points y; low-rank part
+    subtracted in registers) against NumPy with the oracle's K and K'/h -- the building block of the distributed gradient"""
+    import torch
+    from scipy.spatial.distance import cdist
+    from gpmp_amd import _lib
+    from oracle import gp_oracle as orc
+
+    lib = _lib.load()
+    rng = np.random.default_rng(n + m + d)
+    x, y = rng.random((n, d)), rng.random((m, d))
+    if n == m:
+        y[:10] = x[:10]                                   # coincident points: h = 0 exactly (K'/h regular for p >= 1)
+    th = np.concatenate(([0.3], -np.log(0.4 + 0.6 * rng.random(d))))
+    M = rng.standard_normal((n, m))
+    F, G = (rng.standard_normal((n, r)), rng.standard_normal((m, r))) if r else (None, None)
+    Md, xd, yd = gnp.as_matrix(gnp.asarray(M)), gnp.asarray(x), gnp.asarray(y)
+    Fd = Gd = None
+    if r:
+        Fd, Gd = gnp.alloc_matrix(n, r), gnp.alloc_matrix(m, r)
+        Fd.copy_(gnp.asarray(F)); Gd.copy_(gnp.asarray(G))
+    out = torch.zeros(1 + d, dtype=torch.float64, device=Md.device)
+    ws = torch.empty(int(lib.gpmp_grad_ws_elems(n, d)), dtype=torch.float64, device=Md.device)
+    _lib.check(lib.gpmp_matern_grad_trace_cross(gnp._ptr(Md), gnp._ld(Md), gnp._ptr(xd), n, gnp._ptr(yd), m, d, p, _lib.host_vec(th), 0,
+                                                gnp._ptr(Fd), gnp._ptr(Gd), r, gnp._ld(Fd) if r else 1, gnp._ptr(out), gnp._ptr(ws),
+                                                gnp._stream()), "gpmp_matern_grad_trace_cross")
+    got = out.cpu().numpy()
+    Mn = M - (F @ G.T if r else 0.0)
+    inv = np.exp(th[1:])
+    xs, ys = x * inv, y * inv
+    H = cdist(xs, ys)
+    s2 = math.exp(th[0])
+    want = np.zeros(1 + d)
+    want[0] = s2 * np.sum(Mn * orc.maternp_kernel(p, H))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        R = s2 * np.where(H > 0, orc.maternp_dkernel_over_h(p, np.where(H > 0, H, 1.0)), 0.0 if p == 0 else orc.maternp_dkernel_over_h(p, np.zeros_like(H))) * Mn
+    for j in range(d):
+        want[1 + j] = np.sum(R * (xs[:, j][:, None] - ys[:, j][None, :]) ** 2)
+    scale = s2 * np.sum(np.abs(Mn))
+    assert np.max(np.abs(got - want)) < 1e-12 * scale, (got, want)
+
