@@ -490,15 +490,13 @@ class BlockCyclicCholesky:
 
     def _ring_shift(self, t: torch.Tensor, shift: int) -> torch.Tensor:
         """Inside the process row: send ``t`` to the rank ``shift`` process columns to the left, receive the tensor of the rank
-        ``shift`` columns to the right (same shape on every rank of the row up to the column count, which is passed along)."""
+        ``shift`` columns to the right: its local columns are the block columns THAT process column owns (their count is known
+        from the layout, nothing is negotiated)."""
         g = self.grid
         dst, src = g.rank_of(g.r, (g.c - shift) % g.pc), g.rank_of(g.r, (g.c + shift) % g.pc)
         ct = _comm_tensor(t, self.backend)
-        # shapes differ by at most one column between shards: agree on the incoming column count first (host integers)
-        from .predict import shard_bounds
-
-        j0, j1 = shard_bounds(self.n, g.pc, (g.c + shift) % g.pc)
-        buf = torch.empty((ct.shape[0], j1 - j0), dtype=ct.dtype, device=ct.device)
+        ncols2 = sum(self.bs(J) for J in g.local_col_blocks(self.nblocks, (g.c + shift) % g.pc))
+        buf = torch.empty((ct.shape[0], ncols2), dtype=ct.dtype, device=ct.device)
         self._log(g.row_group, f"ring_shift{shift}", -1, ct.shape[0])     # (rows: the same on every member; the column counts differ by <= 1)
         reqs = [dist.P2POp(dist.isend, ct, dst, g.row_group), dist.P2POp(dist.irecv, buf, src, g.row_group)]
         for w in dist.batch_isend_irecv(reqs):
@@ -877,7 +875,7 @@ class BlockCyclicCholesky:
         return w
 
     # ---- many right-hand sides on the distributed factor (prediction beyond one GPU's HBM)
-    def solve_lower_many(self, Bloc: torch.Tensor, overlap: Optional[bool] = None, profile: Optional[bool] = None) -> torch.Tensor:
+    def solve_lower_many(self, Bloc: torch.Tensor, overlap: Optional[bool] = None, profile: Optional[bool] = None, active_cols=None) -> torch.Tensor:
         """V = L^-1 B in place for a right-hand side laid out like the factor's rows: ``Bloc`` holds the block rows this
         process row owns (self.local_rows() x m_c) of THIS process column's shard of the columns of B (the columns of B are
         split over the process columns, gpmp_amd.dist.shard_bounds(m, Pc, c)).  Per block column k:
@@ -891,7 +889,11 @@ class BlockCyclicCholesky:
         products on the critical path are hidden behind the bulk GEMM of step k; two buffers per message kind.  Every
         communicator is used from ONE stream (row communicators: prefetch stream, column communicators: side stream) and in
         the same order on all of its members.  ``overlap=False`` (GPMP_DIST_SOLVE_OVERLAP=0) issues the same operations in
-        the same order on the caller's stream alone."""
+        the same order on the caller's stream alone.
+        ``active_cols``: optional k -> number of LEADING local columns of ``Bloc`` that can be non-zero in block row k of the
+        solution (a function of k and of the process column only).  For a right-hand side with that structure -- the identity
+        in the factor's own block-cyclic column layout, whose solution L^-1 is lower triangular -- C(k) and U(k) then touch
+        only those columns: n^3 / 3 flops instead of n^3, evenly spread over the process columns."""
         g, ops, nb = self.grid, self.ops, self.nb
         if overlap is None:
             overlap = os.environ.get("GPMP_DIST_SOLVE_OVERLAP", "1") != "0"
@@ -948,10 +950,14 @@ class BlockCyclicCholesky:
                             self._bcast(panel, g.rank_of(g.r, cd), g.row_group, row_members)
                     p_ready[k] = st.record_diag()
 
+        def ncols(k):
+            return mloc if active_cols is None else max(0, min(mloc, int(active_cols(k))))
+
         def chain(k):
             rd = g.owner_row(k)
             bk, buf, Lkk, dinv = views(k)
-            xk = Xbuf[k % 2][:bk]
+            na = ncols(k)
+            xk = Xbuf[k % 2][:bk, :na]
             self._step_label = f"solve_chain{k}"
             with side_ctx():
                 st.wait(True, start)
@@ -959,18 +965,19 @@ class BlockCyclicCholesky:
                 st.wait(True, p_ready.get(k - 1))
                 st.wait(True, u_done.get(k - 2))     # block row k has received the updates 0 ... k-2, X buffer (k-2) is free
                 with self._phase("solve_chain"):
-                    if g.r == rd and mloc:
+                    if g.r == rd and na:
                         li = k // g.pr
-                        Bk = Bloc[self.roff[li]:self.roff[li + 1]]
-                        if k > 0:
+                        Bk = Bloc[self.roff[li]:self.roff[li + 1], :na]
+                        npv = ncols(k - 1) if k > 0 else 0
+                        if npv:
                             # update k-1 of this ONE block row (the bulk update k-1 skips it): first row of panel k-1
                             bp = self.bs(k - 1)
                             ip = self._first_row_after(k - 1)
                             off = self.roff[li] - self.roff[ip]
-                            ops.gemm_nn_sub(Bk, Pbuf[(k - 1) % 2][off: off + bk, :bp], Xbuf[(k - 1) % 2][:bp])
+                            ops.gemm_nn_sub(Bk[:, :npv], Pbuf[(k - 1) % 2][off: off + bk, :bp], Xbuf[(k - 1) % 2][:bp, :npv])
                         ops.trsm_left(Lkk, dinv, Bk)
                         xk.copy_(Bk)
-                    if g.pr > 1 and mloc:
+                    if g.pr > 1 and na:
                         self._bcast(xk, g.rank_of(rd, g.c), g.col_group, col_members)
                 x_ready[k] = st.record(True)
 
@@ -981,10 +988,11 @@ class BlockCyclicCholesky:
             self._step_label = f"solve_update{k}"
             st.wait(False, x_ready.get(k))
             st.wait(False, p_ready.get(k))
+            na = ncols(k)
             with st.main_ctx(), self._phase("solve_update"):
-                if mloc and self.roff[-1] - self.roff[i1] > 0:
+                if na and self.roff[-1] - self.roff[i1] > 0:
                     off = self.roff[i1] - self.roff[i0]
-                    ops.gemm_nn_sub(Bloc[self.roff[i1]:], Pbuf[k % 2][off: self.roff[-1] - self.roff[i0], :bk], Xbuf[k % 2][:bk])
+                    ops.gemm_nn_sub(Bloc[self.roff[i1]:, :na], Pbuf[k % 2][off: self.roff[-1] - self.roff[i0], :bk], Xbuf[k % 2][:bk, :na])
             u_done[k] = st.record(False)
 
         prefetch(0)
@@ -1043,6 +1051,23 @@ class BlockCyclicCholesky:
         w = self.solve_lower_vector(z)
         return 0.5 * (self.n * math.log(2.0 * math.pi) + self.logdet() + float((w * w).sum().item()))
 
+    def inverse_factor_local(self):
+        """T = L^-1 in the FACTOR'S OWN 2-D block-cyclic layout (local rows x local columns, global indices
+        ``global_row_index()`` / ``global_col_index()``): the many-right-hand-side solve on the identity, with the triangular
+        structure exploited -- block row k of T is non-zero in the block columns J <= k only, a PREFIX of the local columns
+        (``active_cols``) -- so the work is n^3 / 3 and every process column carries the same share of it (contiguous column
+        shards would leave the last process column almost idle and the first with all of the work)."""
+        ri, ci = self.global_row_index(), self.global_col_index()
+        eye = self.ops.empty(len(ri), len(ci))
+        eye.zero_()
+        if len(ri) and len(ci):
+            pos = {int(gc): lj for lj, gc in enumerate(ci)}
+            hit = [(li, pos[int(gr)]) for li, gr in enumerate(ri) if int(gr) in pos]
+            if hit:
+                hr, hc = zip(*hit)
+                eye[torch.as_tensor(hr, device=eye.device), torch.as_tensor(hc, device=eye.device)] = 1.0
+        return self.solve_lower_many(eye, active_cols=lambda k: self.coff[self._first_col_after(k)])
+
     def negative_log_restricted_likelihood(self, z, P) -> float:
         """REML criterion (gpmp/core/likelihood.py:92-129) on the distributed factor, with the exact restatement the
         single-GPU path uses: for W an orthonormal basis of Null(P^T),
@@ -1067,49 +1092,50 @@ class BlockCyclicCholesky:
         logdet = self.logdet() + 2.0 * np.sum(np.log(np.diag(cS))) - 2.0 * np.sum(np.log(np.diag(cP)))
         return 0.5 * ((self.n - q) * math.log(2.0 * math.pi) + logdet + float(wz @ wz - y @ y))
 
+    def _kinv_rows(self, T, Y, what):
+        """From the local part of T = L^-1 (block-cyclic columns): X = K^-1 Y for the rows of this process column's column
+        set (X = T^T (L^-1 Y): one pass over T + one all-reduce inside the process column) and diag(K^-1) there (column sums
+        of squares of T).  Y: n x r replicated.  Returns (X (m_c x r), diag (m_c,)) as NumPy arrays, identical on the ranks of
+        a process column."""
+        g, ops = self.grid, self.ops
+        ri, ci = self.global_row_index(), self.global_col_index()
+        r = Y.shape[1]
+        W = self.solve_lower_few(Y)                                      # replicated L^-1 Y
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        part = torch.zeros((r + 1, len(ci)), dtype=torch.float64, device=dev)
+        if len(ri) and len(ci):
+            dots, ssq = ops.coldots_many(T, ops.asarray(W[torch.as_tensor(ri, device=W.device)]))   # (r, m_c), (m_c,)
+            part[:r], part[r] = dots.to(dev), ssq.to(dev)
+        if g.pr > 1:
+            self._step_label = what
+            self._all_reduce(part, dist.ReduceOp.SUM, g.col_group, what)
+        part = part.cpu().numpy()
+        return part[:r].T.copy(), part[r].copy()
+
     def loo(self, z, P=None):
         """Leave-one-out predictions by virtual cross-validation (gpmp/core/loo.py:65-83 zero mean; :103-130 with a linear
         predictor, in the form Qinv = K^-1 - U S^-1 U^T, U = K^-1 P of gpmp_amd/core/loo.py) on the distributed factor.
-        T = L^-1 comes from the many-right-hand-side solve on the identity (its columns split over the process columns like
-        prediction points); diag(K^-1) = column sums of squares of T and K^-1 [z, P] = T^T (L^-1 [z, P]) are ONE pass over
-        the local part of T + one all-reduce inside the process column.  Returns (zloo, sigma2loo, eloo, (j0, j1)): this
-        process column's shard of the n leave-one-out results (identical on the ranks of a process column), NumPy arrays."""
-        from .predict import shard_bounds
-
+        T = L^-1 in the factor's block-cyclic layout (inverse_factor_local: n^3 / 3 flops, balanced); diag(K^-1) = column
+        sums of squares of T and K^-1 [z, P] = T^T (L^-1 [z, P]) are ONE pass over the local part of T + one all-reduce
+        inside the process column.  Returns (zloo, sigma2loo, eloo, idx): the leave-one-out results of the observations
+        ``idx`` (global indices: the block columns this process column owns; identical on its ranks), NumPy arrays."""
         if self.info:
             raise np.linalg.LinAlgError("the distributed factorisation failed (not positive definite): no leave-one-out")
-        g, ops = self.grid, self.ops
+        g = self.grid
         z = np.asarray(z, dtype=np.float64).reshape(-1)
         Y = z.reshape(-1, 1) if P is None else np.hstack((z.reshape(-1, 1), np.asarray(P, dtype=np.float64).reshape(self.n, -1)))
-        r = Y.shape[1]
-        j0, j1 = shard_bounds(self.n, g.pc, g.c)
-        ri = self.global_row_index()
-        eye = ops.empty(len(ri), j1 - j0)
-        eye.zero_()
-        hit = np.nonzero((ri >= j0) & (ri < j1))[0]
-        if len(hit):
-            eye[torch.as_tensor(hit, device=eye.device), torch.as_tensor(ri[hit] - j0, device=eye.device)] = 1.0
-        T = self.solve_lower_many(eye)                                   # local rows x column shard of L^-1
-        W = self.solve_lower_few(Y)                                      # replicated L^-1 [z, P]
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        part = torch.zeros((r + 1, j1 - j0), dtype=torch.float64, device=dev)
-        if len(ri) and j1 > j0:
-            Wloc = ops.asarray(W[torch.as_tensor(ri, device=W.device)])
-            dots, ssq = ops.coldots_many(T, Wloc)                        # (r, m_c): T^T W;  (m_c,): column sums of squares
-            part[:r], part[r] = dots.to(dev), ssq.to(dev)
-        if g.pr > 1:
-            self._step_label = "loo_reduce"
-            self._all_reduce(part, dist.ReduceOp.SUM, g.col_group, "loo")
-        part = part.cpu().numpy()
-        X, dK = part[:r].T, part[r]                                      # K^-1 [z, P] (shard rows), diag(K^-1)
-        zs = z[j0:j1]
+        idx = self.global_col_index()
+        T = self.inverse_factor_local()
+        X, dK = self._kinv_rows(T, Y, "loo")                             # K^-1 [z, P] (rows idx), diag(K^-1)
+        del T
+        zs = z[idx]
         if P is None:
             eloo = X[:, 0] / dK
-            return zs - eloo, 1.0 / dK, eloo, (j0, j1)
-        # S = P^T K^-1 P and z^T K^-1 P need every shard: one small all-reduce over the process ROW (each column shard once)
+            return zs - eloo, 1.0 / dK, eloo, idx
+        # S = P^T K^-1 P and z^T K^-1 P need every column set: one small all-reduce over the process ROW (each set once)
         Pn = np.asarray(P, dtype=np.float64).reshape(self.n, -1)
         U = X[:, 1:]
-        G = torch.as_tensor(np.vstack((z[j0:j1] @ U, Pn[j0:j1].T @ U)))
+        G = torch.as_tensor(np.vstack((zs @ U, Pn[idx].T @ U)))
         G = G.to("cuda") if self.backend == "nccl" else G
         if g.pc > 1:
             self._all_reduce(G, dist.ReduceOp.SUM, g.row_group, "loo_meanspace")
@@ -1119,8 +1145,7 @@ class BlockCyclicCholesky:
         Qz = X[:, 0] - US @ G[0]
         Qd = dK - np.sum(US * U, axis=1)
         eloo = Qz / Qd
-        return zs - eloo, 1.0 / Qd, eloo, (j0, j1)
-
+        return zs - eloo, 1.0 / Qd, eloo, idx
 
     # ---- analytic gradient of the ML / REML criteria on the distributed factor
     def value_and_grad(self, x, z, covparam, p, noise=False, P=None):
@@ -1131,13 +1156,12 @@ class BlockCyclicCholesky:
             g_j = 1/2 sum_ik (Qinv_ik - beta_i beta_k) dK_ik/dtheta_j,  Qinv = K^-1 - U S^-1 U^T, U = K^-1 P, beta = Qinv z
         as gpmp_amd/core/gradients.py, with K^-1 = T^T T never assembled in one place: T = L^-1 is the many-right-hand-side
         solve on the identity (rows over the process rows, columns over the process columns); process column c forms the blocks
-        (shard c, shard c') of T^T T from its own rows -- T travels around the process row (a ring of Pc / 2 shifts, blocks
-        c != c' count twice) -- and traces each block against the matching block of dK in one fused pass
+        (column set c, column set c') of T^T T from its own rows -- T travels around the process row (a ring of Pc / 2 shifts,
+        blocks c != c' count twice) -- and traces each block against the matching block of dK in one fused pass
         (gpmp_matern_grad_trace_cross: dK is recomputed on the fly, the low-rank part is subtracted in registers).  Partial
-        sums over the process rows need no matrix reduction: the trace is linear, so ONE all-reduce of d + 3 doubles ends it.
-        Flops: n^3 / P for T and n^3 / P for the blocks (T's triangle is not exploited: 3x the 2n^3/3 of a blocked potri)."""
-        from .predict import shard_bounds
-
+        sums over the process rows need no matrix reduction: the trace is linear, so ONE all-reduce of 1 + d doubles ends it.
+        Flops: n^3 / 3 for T (triangular structure exploited, balanced over the grid) + about n^3 / 2 for the blocks (a
+        staircase in the contraction index; a blocked in-place potri would need n^3 / 3 for them)."""
         g, ops = self.grid, self.ops
         if self.info:
             return math.inf, np.zeros(len(covparam))
@@ -1150,34 +1174,22 @@ class BlockCyclicCholesky:
         th = np.asarray(covparam, dtype=np.float64)
         sigma2 = math.exp(th[0])
         dev = "cuda" if self.backend == "nccl" else "cpu"
-        # ---- T = L^-1 (local rows x column shard), W = L^-1 [z, P] replicated, X = K^-1 [z, P] = T^T W for my shard
-        j0, j1 = shard_bounds(n, g.pc, g.c)
-        ri = self.global_row_index()
-        eye = ops.empty(len(ri), j1 - j0)
-        eye.zero_()
-        hit = np.nonzero((ri >= j0) & (ri < j1))[0]
-        if len(hit):
-            eye[torch.as_tensor(hit, device=eye.device), torch.as_tensor(ri[hit] - j0, device=eye.device)] = 1.0
-        T = self.solve_lower_many(eye)
+        # ---- T = L^-1 in the factor's block-cyclic layout, X = K^-1 [z, P] = T^T (L^-1 [z, P]) for my column set
+        ci = self.global_col_index()
+        T = self.inverse_factor_local()
         Y = z.reshape(-1, 1) if Pn is None else np.hstack((z.reshape(-1, 1), Pn))
-        W = self.solve_lower_few(Y)
         r1 = Y.shape[1]
-        part = torch.zeros((r1 + 1, j1 - j0), dtype=torch.float64, device=dev)
-        if len(ri) and j1 > j0:
-            dots, ssq = ops.coldots_many(T, ops.asarray(W[torch.as_tensor(ri, device=W.device)]))
-            part[:r1], part[r1] = dots.to(dev), ssq.to(dev)
-        if g.pr > 1:
-            self._step_label = "grad_reduce"
-            self._all_reduce(part, dist.ReduceOp.SUM, g.col_group, "kinv_rows")
-        # every rank needs K^-1 [z, P] for ALL rows (the low-rank factors of other shards' columns): one small all-gather
-        # along the process row, assembled as an all-reduce of a zero-padded n x (1 + q) array
-        Xfull = torch.zeros((n, r1), dtype=torch.float64, device=dev)
-        Xfull[j0:j1] = part[:r1].T
-        trKinv = torch.zeros(1, dtype=torch.float64, device=dev)
-        trKinv[0] = part[r1].sum()
+        X, dK = self._kinv_rows(T, Y, "grad_reduce")
+        # every rank needs K^-1 [z, P] for ALL rows (the low-rank factors of the other column sets): a small all-gather
+        # along the process row, done as an all-reduce of a zero-padded n x (1 + q) array; tr(K^-1) rides along
+        Xfull = torch.zeros((n + 1, r1), dtype=torch.float64, device=dev)
+        if len(ci):
+            Xfull[torch.as_tensor(ci, device=dev)] = torch.as_tensor(X, device=dev)
+            Xfull[n, 0] = float(dK.sum())
         if g.pc > 1:
             self._all_reduce(Xfull, dist.ReduceOp.SUM, g.row_group, "kinv_zp")
-            self._all_reduce(trKinv, dist.ReduceOp.SUM, g.row_group, "trace_kinv")
+        trKinv = Xfull[n, :1].clone()
+        Xfull = Xfull[:n]
         Xh = Xfull.cpu().numpy()
         alpha = Xh[:, 0]
         logdet = self.logdet()
@@ -1199,21 +1211,33 @@ class BlockCyclicCholesky:
             value = 0.5 * ((n - q) * math.log(2.0 * math.pi) + logdet + 2.0 * np.sum(np.log(np.diag(cS))) - 2.0 * np.sum(np.log(np.diag(cP)))
                            + float(z @ alpha - b @ (Sinv @ b)))
             Fh, Gh = np.hstack((US, beta.reshape(-1, 1))), np.hstack((U, beta.reshape(-1, 1)))
-        # ---- blocks (shard c, shard c') of T^T T against dK: ring over the process row, half of it by symmetry
-        xs_c = x[j0:j1]
+        # ---- blocks (column set c, column set c') of T^T T against dK: ring over the process row, half of it by symmetry.
+        # T2's block column J is zero above global row J nb, so its product with T only needs the local rows from block row J
+        # on: one GEMM per block column of T2, a staircase in K (half the flops of the plain product)
+        xs_c = x[ci]
         tot = torch.zeros(1 + d, dtype=torch.float64, device=dev)
         half = g.pc // 2
         for sft in range(half + 1):
             c2 = (g.c + sft) % g.pc
-            T2 = T if sft == 0 else self._ring_shift(T, sft)
+            T2 = T if sft == 0 else ops.asarray(self._ring_shift(T, sft))
             weight = 1.0 if (sft == 0 or (g.pc % 2 == 0 and sft == half)) else 2.0
-            k0, k1 = shard_bounds(n, g.pc, c2)
-            if j1 > j0 and k1 > k0:
-                Mblk = ops.gemm_tn(T, ops.asarray(T2))                      # (shard c) x (shard c2), partial over my rows
+            blocks2 = g.local_col_blocks(self.nblocks, c2)
+            ci2 = np.concatenate([np.arange(J * self.nb, J * self.nb + self.bs(J)) for J in blocks2]) if blocks2 else np.zeros(0, dtype=np.int64)
+            if len(ci) and len(ci2) and len(self.row_blocks):
+                Mblk = ops.empty(len(ci), len(ci2))
+                o2 = 0
+                for J in blocks2:
+                    w2 = self.bs(J)
+                    ro = self.roff[bisect.bisect_left(self.row_blocks, J)]          # first local row of a block row >= J
+                    if ro < self.roff[-1]:
+                        Mblk[:, o2:o2 + w2].copy_(ops.gemm_tn(T[ro:], T2[ro:, o2:o2 + w2]))
+                    else:
+                        Mblk[:, o2:o2 + w2].zero_()
+                    o2 += w2
                 # the low-rank part must enter exactly once per block: on process row 0
-                lowF = Fh[j0:j1] if g.r == 0 else None
-                lowG = Gh[k0:k1] if g.r == 0 else None
-                tot += weight * ops.grad_trace_cross(Mblk, xs_c, x[k0:k1], p, th, noise, lowF, lowG).to(dev)
+                lowF = Fh[ci] if g.r == 0 else None
+                lowG = Gh[ci2] if g.r == 0 else None
+                tot += weight * ops.grad_trace_cross(Mblk, xs_c, x[ci2], p, th, noise, lowF, lowG).to(dev)
                 del Mblk
         self._step_label = "grad_total"
         self._all_reduce(tot, dist.ReduceOp.SUM, g.world_group, "grad_traces")

@@ -331,15 +331,15 @@ def _reml_loo_worker(rank, world, port, pr, pc, n, nb, q, out):
         ch.build_local_gram(_cov, x, th, 1e-6)
         assert ch.factor() == 0
         reml = ch.negative_log_restricted_likelihood(z, P) if q else ch.negative_log_likelihood(z)
-        zloo, s2, eloo, (j0, j1) = ch.loo(z, P)
+        zloo, s2, eloo, idx = ch.loo(z, P)
         gathered = [None] * world
-        dist.all_gather_object(gathered, (grid.r, j0, j1, zloo, s2, eloo, reml))
+        dist.all_gather_object(gathered, (grid.r, idx, zloo, s2, eloo, reml))
         if rank == 0:
             full = np.full((3, n), np.nan)
-            for (r, a, b, zl, s, e, v) in gathered:
+            for (r, ix, zl, s, e, v) in gathered:
                 assert v == reml                                  # the criterion is replicated
                 if r == 0:
-                    full[0, a:b], full[1, a:b], full[2, a:b] = zl, s, e
+                    full[0, ix], full[1, ix], full[2, ix] = zl, s, e
             np.save(out, np.vstack((full, np.full((1, n), reml))))
     finally:
         dist.destroy_process_group()

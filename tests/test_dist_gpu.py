@@ -234,14 +234,14 @@ def _reml_loo_worker(rank, world, port, pr, pc, n, nb, q, out):
         ch.build_local_gram(MaternCovariance(2), x, th, 10.0 * math.exp(th[0]) * gnp.eps)
         assert ch.factor() == 0
         v = ch.negative_log_restricted_likelihood(z, P) if q else ch.negative_log_likelihood(z)
-        zloo, s2, eloo, (j0, j1) = ch.loo(z, P)
+        zloo, s2, eloo, idx = ch.loo(z, P)
         gathered = [None] * world
-        dist.all_gather_object(gathered, (grid.r, j0, j1, zloo, s2, eloo))
+        dist.all_gather_object(gathered, (grid.r, idx, zloo, s2, eloo))
         if rank == 0:
             full = np.full((3, n), np.nan)
-            for (r, a, b, zl, s, e) in gathered:
+            for (r, ix, zl, s, e) in gathered:
                 if r == 0:
-                    full[0, a:b], full[1, a:b], full[2, a:b] = zl, s, e
+                    full[0, ix], full[1, ix], full[2, ix] = zl, s, e
             np.save(out, np.vstack((full, np.full((1, n), v))))
     finally:
         dist.destroy_process_group()

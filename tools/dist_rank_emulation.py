@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=None)
     ap.add_argument("--solve-m", type=int, default=0, help="also time the many-right-hand-side solve for this many prediction points "
                     "(split over the process columns), with and without the prefetch / chain / update overlap")
+    ap.add_argument("--grad", action="store_true", help="also time one ML value + gradient on the factor (T = L^-1 in the block-cyclic "
+                    "layout, the blocks of T^T T around the process row, the fused cross traces), collectives stubbed")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -51,6 +53,13 @@ def main():
         def _bcast(self, t, src_rank, group, members):      # noqa: D401 -- no communication: shapes only
             if self.grid.rank != src_rank:
                 self.bytes_received += t.numel() * 8
+            return t
+
+        def _ring_shift(self, t, shift):                     # the neighbour's part of T has this rank's shape here
+            self.bytes_received += t.numel() * 8
+            return t
+
+        def _all_reduce(self, t, op, group, what):          # (sub-communicators do not exist in the emulation)
             return t
 
     n, d = a.n, 8
@@ -87,12 +96,29 @@ def main():
             solve["overlap" if overlap else "in_order"] = {"s": dt, "rank_share_tflops": solve["rank_share_flops"] / dt / 1e12,
                                                            "phases_ms": {k: round(v, 2) for k, v in ch.phase_times().items()}}
             del B
+    grad = None
+    if a.grad:
+        xh = np.asarray(rng.random((n, d)))
+        zh = np.sin(2 * np.pi * xh[:, 0]) + xh[:, 1:].sum(axis=1)
+        grad = {}
+        for rep in ("warm", "timed"):
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            T = ch.inverse_factor_local()
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            del T
+            ch.value_and_grad(xh, zh, theta, 2)
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            grad[rep] = {"inverse_factor_s": t4 - t3, "inverse_factor_rank_share_tflops": (n ** 3 / 3.0) / (pr * pc) / (t4 - t3) / 1e12,
+                         "value_and_grad_s": t5 - t4, "note": "value_and_grad includes its own inverse factor; ring shifts stubbed"}
     print(json.dumps({"tool": "dist_rank_emulation", "n": n, "grid": a.grid, "coords": a.coords, "block": a.block,
                       "local_shape": [ch.local_rows(), ch.local_cols()], "lookahead": not a.no_lookahead, "reserve_cus": ch.reserve_cus,
                       "gram_s": t1 - t0, "factor_s": t2 - t1, "rank_share_tflops": share / (t2 - t1) / 1e12,
                       "frac_of_fp64_mfma_peak": share / (t2 - t1) / 1e12 / 78.6,
                       "bytes_received_GB": ch.bytes_received / 1e9,
-                      "phases_ms": factor_phases, "solve": solve,
+                      "phases_ms": factor_phases, "solve": solve, "grad": grad,
                       "note": "collectives stubbed: timing and fault check only, values are not a factorisation"}))
     dist.destroy_process_group()
 
