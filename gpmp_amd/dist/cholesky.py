@@ -504,6 +504,11 @@ class BlockCyclicCholesky:
         self.bytes_received += buf.numel() * 8
         return buf if buf.device == t.device else buf.to(t.device)
 
+    def _world_bcast(self, t: torch.Tensor, src_rank: int):
+        self._log(self.grid.world_group, "broadcast", src_rank, t.numel())
+        dist.broadcast(t, src=src_rank, group=self.grid.world_group)
+        return t
+
     def _all_reduce(self, t: torch.Tensor, op, group, what: str):
         self._log(group, f"all_reduce:{what}", -1, t.numel())
         dist.all_reduce(t, op=op, group=group)
@@ -853,8 +858,7 @@ class BlockCyclicCholesky:
                     wk = blk.to(dev)
             wk = wk.contiguous()
             self._step_label = f"vec{k}"
-            self._log(g.world_group, "broadcast", g.rank_of(rd, cd), wk.numel())
-            dist.broadcast(wk, src=g.rank_of(rd, cd), group=g.world_group)
+            self._world_bcast(wk, g.rank_of(rd, cd))
             w[k0:k0 + bk] = wk
             rest = self.n - (k0 + bk)
             if rest <= 0:

@@ -62,6 +62,9 @@ def main():
         def _all_reduce(self, t, op, group, what):          # (sub-communicators do not exist in the emulation)
             return t
 
+        def _world_bcast(self, t, src_rank):
+            return t
+
     n, d = a.n, 8
     rng = np.random.default_rng(1234)
     x = gnp.asarray(rng.random((n, d)))
@@ -101,6 +104,7 @@ def main():
         xh = np.asarray(rng.random((n, d)))
         zh = np.sin(2 * np.pi * xh[:, 0]) + xh[:, 1:].sum(axis=1)
         grad = {}
+        ch.info = 0          # (the stubbed factorisation "fails": the values are meaningless, the kernels and their shapes are not)
         for rep in ("warm", "timed"):
             torch.cuda.synchronize()
             t3 = time.perf_counter()
