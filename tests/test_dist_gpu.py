@@ -106,6 +106,24 @@ def test_step_abi_equals_the_tensor_level_schedule(tmp_path, pr, pc, n, nb, look
     assert np.array_equal(L1, L0) and m1[1] == m0[1]
 
 
+def _spawn_bounded(fn, args, nprocs, limit_s):
+    """mp.spawn with a deadline: a collective that never completes (the RCCL path with more than one rank has not run on
+    hardware yet) must fail THIS test, not hang the suite and the GPU box -- the workers are killed and the test fails."""
+    import time
+    import torch.multiprocessing as mp
+
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    deadline = time.monotonic() + limit_s
+    while not ctx.join(timeout=2.0):
+        if time.monotonic() > deadline:
+            for p in ctx.processes:
+                if p.is_alive():
+                    p.kill()
+            for p in ctx.processes:
+                p.join(10)
+            pytest.fail(f"distributed workers still running after {limit_s:.0f} s: killed (wedged collective?)")
+
+
 def _run_and_check(tmp_path, pr, pc, n, nb, transport, lookahead, backend):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -113,7 +131,7 @@ def _run_and_check(tmp_path, pr, pc, n, nb, transport, lookahead, backend):
 
     world = pr * pc
     out = str(tmp_path / "L.npy")
-    mp.spawn(_worker, args=(world, _free_port(), pr, pc, n, nb, out, transport, lookahead, backend), nprocs=world, join=True)
+    _spawn_bounded(_worker, (world, _free_port(), pr, pc, n, nb, out, transport, lookahead, backend), world, 240.0 if backend == "nccl" else 600.0)
     L = np.load(out)
     info, nll = np.load(out + ".meta.npy")
     x, z = make_xz(n, 4, 11)
