@@ -398,9 +398,6 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
   // (locals, never a store into the parameter block: see gram_kernel_v3)
   const double* __restrict__ pKinv = p.Kinv;
   const double* __restrict__ px = p.x;
-  const double* __restrict__ py = CROSS ? p.y : p.x;
-  const int pm = CROSS ? p.m : 0;
-  (void)pm;
   const double* __restrict__ pF = p.F;
   const double* __restrict__ pG = p.G;
   double* __restrict__ ppartial = p.partial;
@@ -420,6 +417,10 @@ __global__ void __launch_bounds__(256) grad_trace_kernel(GradParams p) {
       pntiles = pntiles_side * (pntiles_side + 1) / 2;
     }
   }
+  // column points: the second set in cross mode, otherwise the (per-problem) row points themselves
+  const double* __restrict__ py = CROSS ? p.y : px;
+  const int pm = CROSS ? p.m : 0;
+  (void)pm;
 
   for (int tile = blockIdx.x; tile < pntiles; tile += gridDim.x) {
     int ti, tj;
