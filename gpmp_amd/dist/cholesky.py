@@ -1014,18 +1014,28 @@ class BlockCyclicCholesky:
         return Bloc
 
     def predict_zero_mean(self, cov, x, z, xt, covparam):
-        """Posterior mean and variance at xt from the distributed factor of K(x, x) (zero-mean kriging,
-        gpmp/core/kriging.py:35-67,170-199 restated as ONE solve: V = L^-1 K(x, xt), mean = V^T (L^-1 z),
-        var = k(xt, xt) - colsumsq(V)).  The prediction points are split over the process COLUMNS, the rows of V over the
-        process ROWS; the local block K(x[rows owned], xt[column shard]) is one Gram call, and the only reductions are
-        two (m_c,) all-reduces inside each process column.  Returns (mean, variance, (j0, j1)): this process column's
-        shard of the results (identical on the ranks of one process column), as NumPy arrays."""
+        """Zero-mean kriging from the distributed factor: see ``predict`` (no mean design)."""
+        return self.predict(cov, x, z, xt, covparam)
+
+    def predict(self, cov, x, z, xt, covparam, P=None, Pt=None):
+        """Posterior mean and variance at xt from the distributed factor of K(x, x).  Zero mean (P None:
+        gpmp/core/kriging.py:35-67,170-199) restated as ONE solve, V = L^-1 K(x, xt), mean = V^T (L^-1 z),
+        var = k(xt, xt) - colsumsq(V); with a linear predictor (universal kriging, kriging.py:70-116; P: n x q mean design at
+        the observations, Pt: m x q at the prediction points) the Schur-complement form of gpmp_amd/core/kriging.py:
+            R = Wp^T V - Pt^T,  mu = S^-1 R,  mean = V^T wz - mu^T (Wp^T wz),  var = k_tt - colsumsq(V) + sum(mu * R),
+        [wz, Wp] = L^-1 [z, P], S = Wp^T Wp -- the (n + q) x (n + q) system of the reference is never formed.
+        The prediction points are split over the process COLUMNS, the rows of V over the process ROWS; the local block
+        K(x[rows owned], xt[column shard]) is one Gram call, and the only reductions are (2 + q) x m_c all-reduced inside each
+        process column.  Returns (mean, variance, (j0, j1)): this process column's shard of the results (identical on the
+        ranks of one process column), as NumPy arrays."""
         from .predict import shard_bounds
 
         if self.info:
             raise np.linalg.LinAlgError("the distributed factorisation failed (not positive definite): no prediction")
         g, ops = self.grid, self.ops
         x, xt = ops.asarray(x), ops.asarray(xt)
+        z = np.asarray(z, dtype=np.float64).reshape(-1)
+        q = 0 if P is None else np.asarray(P).reshape(self.n, -1).shape[1]
         j0, j1 = shard_bounds(xt.shape[0], g.pc, g.c)
         xtc = xt[j0:j1].contiguous()
         ri = self.global_row_index()
@@ -1035,18 +1045,28 @@ class BlockCyclicCholesky:
         else:
             Kit = ops.empty(len(ri), j1 - j0)
         V = self.solve_lower_many(Kit)
-        w = self.solve_lower_vector(z)                                   # replicated L^-1 z
+        Y = z.reshape(-1, 1) if q == 0 else np.hstack((z.reshape(-1, 1), np.asarray(P, dtype=np.float64).reshape(self.n, q)))
+        W = self.solve_lower_few(Y)                                      # replicated L^-1 [z, P]
         dev = "cuda" if self.backend == "nccl" else "cpu"
-        part = torch.zeros((2, j1 - j0), dtype=torch.float64, device=dev)
+        part = torch.zeros((2 + q, j1 - j0), dtype=torch.float64, device=dev)
         if len(ri) and j1 > j0:
-            wloc = ops.asarray(w[torch.as_tensor(ri, device=w.device)])
-            mean_p, ssq_p = ops.coldots(V, wloc)
-            part[0], part[1] = mean_p.to(dev), ssq_p.to(dev)
+            dots, ssq = ops.coldots_many(V, ops.asarray(W[torch.as_tensor(ri, device=W.device)]))
+            part[: 1 + q], part[1 + q] = dots.to(dev), ssq.to(dev)
         if g.pr > 1:
             self._step_label = "predict_reduce"
             self._all_reduce(part, dist.ReduceOp.SUM, g.col_group, "mean_var")
-        prior = ops.pairwise_variance(cov, xtc, covparam).to(dev) if j1 > j0 else part[1]
-        return part[0].cpu().numpy(), (prior - part[1]).cpu().numpy(), (j0, j1)
+        prior = ops.pairwise_variance(cov, xtc, covparam).to(dev) if j1 > j0 else part[1 + q]
+        part = part.cpu().numpy()
+        mean, reduction = part[0].copy(), part[1 + q].copy()
+        if q:
+            Wh = W.cpu().numpy()
+            wz, Wp = Wh[:, 0], Wh[:, 1:]
+            S = Wp.T @ Wp
+            R = part[1: 1 + q] - np.asarray(Pt, dtype=np.float64).reshape(xt.shape[0], q)[j0:j1].T     # S mu
+            mu = np.linalg.solve(0.5 * (S + S.T), R)
+            mean = mean - (Wp.T @ wz) @ mu
+            reduction = reduction - np.sum(mu * R, axis=0)
+        return mean, prior.cpu().numpy() - reduction, (j0, j1)
 
     def negative_log_likelihood(self, z) -> float:
         """1/2 (n ln 2pi + ln|K| + z^T K^-1 z) -- gpmp/core/likelihood.py:18-52 on the distributed factor."""

@@ -423,3 +423,49 @@ def test_block_cyclic_value_and_gradient(tmp_path, pr, pc, n, nb, q, noise):
         v, g = orc.reml_value_and_grad(x, z, np.hstack((np.ones((n, 1)), x))[:, :q], 2, th, noise_index=ni)
     assert abs(got[0] - v) < 1e-8 * abs(v)
     assert np.max(np.abs(got[1:] - g)) < 1e-6 * np.max(np.abs(g)), (got[1:], g)
+
+
+def _uk_worker(rank, world, port, pr, pc, n, m, nb, q, out):
+    _init(rank, world, port)
+    try:
+        from gpmp_amd.dist import BlockCyclicCholesky, ProcessGrid
+        from tests.cpu_local_ops import CpuLocalOps
+
+        x, z = make_xz(n, 3, 7)
+        xt, _ = make_xz(m, 3, 8)
+        th = theta_aniso(3, scale=0.4)
+        mean = lambda a: np.hstack((np.ones((len(a), 1)), a))[:, :q]        # noqa: E731
+        grid = ProcessGrid(pr, pc)
+        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=CpuLocalOps())
+        ch.build_local_gram(_cov, x, th, 1e-6)
+        assert ch.factor() == 0
+        mu, var, (j0, j1) = ch.predict(_cov_full, x, z, xt, th, P=mean(x), Pt=mean(xt))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (grid.r, j0, j1, mu, var))
+        if rank == 0:
+            zpm, zpv = np.full(m, np.nan), np.full(m, np.nan)
+            for (r, a, b, mm, vv) in gathered:
+                if r == 0:
+                    zpm[a:b], zpv[a:b] = mm, vv
+            np.save(out, np.stack([zpm, zpv]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pr,pc,n,m,nb,q", [(2, 2, 700, 211, 128, 1), (1, 2, 500, 77, 128, 4), (2, 4, 1100, 301, 128, 2)])
+def test_block_cyclic_universal_kriging(tmp_path, pr, pc, n, m, nb, q):
+    """prediction with a linear predictor (constant / linear mean) from the block-cyclic factor -- the Schur-complement route
+    on distributed pieces -- against the oracle's block-system solve (gpmp/core/kriging.py:70-116)"""
+    world = pr * pc
+    out = str(tmp_path / "p.npy")
+    mp.spawn(_uk_worker, args=(world, _free_port(), pr, pc, n, m, nb, q, out), nprocs=world, join=True)
+    got = np.load(out)
+    x, z = make_xz(n, 3, 7)
+    xt, _ = make_xz(m, 3, 8)
+    th = theta_aniso(3, scale=0.4)
+    cov = lambda a, b, t, pairwise=False: (orc.maternp_covariance_it(a, a if b is None else b, 2, t, pairwise)            # noqa: E731
+                                           + (1e-6 * np.eye(len(a)) if ((b is None or b is a) and not pairwise) else 0.0))
+    om = orc.OracleModel(lambda a, p: np.hstack((np.ones((len(a), 1)), a))[:, :q], cov, None, th, "linear_predictor")
+    rm, rv = orc.predict(om, x, z, xt, zero_neg_variances=False)
+    assert np.max(np.abs(got[0] - rm)) < 1e-8 * np.max(np.abs(z))
+    assert np.max(np.abs(got[1] - rv)) < 1e-8

@@ -348,3 +348,60 @@ def test_block_cyclic_value_and_gradient_hip(tmp_path, pr, pc, n, nb, q, noise):
     cs = max(1.0, float(ev[-1] / ev[0]) / 1e6)
     assert abs(got[0] - v) < 1e-11 * cs * abs(v)
     assert np.max(np.abs(got[1:] - g)) < 1e-8 * cs * np.max(np.abs(g)), (got[1:], g, cs)
+
+
+def _uk_worker(rank, world, port, pr, pc, n, m, nb, q, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gpmp_amd.num as gnp
+        from gpmp_amd.dist import BlockCyclicCholesky, HipLocalOps, ProcessGrid
+        from gpmp_amd.kernel import MaternCovariance
+
+        x, z = make_xz(n, 4, 11)
+        xt, _ = make_xz(m, 4, 12)
+        th = theta_aniso(4, scale=0.5)
+        mean = lambda a: np.hstack((np.ones((len(a), 1)), a))[:, :q]        # noqa: E731
+        cov = MaternCovariance(2)
+        grid = ProcessGrid(pr, pc)
+        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=HipLocalOps())
+        ch.build_local_gram(cov, x, th, 10.0 * math.exp(th[0]) * gnp.eps)
+        assert ch.factor() == 0
+        mu, var, (j0, j1) = ch.predict(cov, x, z, xt, th, P=mean(x), Pt=mean(xt))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (grid.r, j0, j1, mu, var))
+        if rank == 0:
+            zpm, zpv = np.full(m, np.nan), np.full(m, np.nan)
+            for (r, a, b, mm, vv) in gathered:
+                if r == 0:
+                    zpm[a:b], zpv[a:b] = mm, vv
+            np.save(out, np.stack([zpm, zpv]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pr,pc,n,m,nb,q", [(2, 2, 2000, 901, 256, 1), (1, 2, 1500, 333, 256, 5)])
+def test_block_cyclic_universal_kriging_hip(tmp_path, pr, pc, n, m, nb, q):
+    """universal kriging (constant / linear mean) from the block-cyclic factor with the real kernels against the oracle's
+    block-system solve (gpmp/core/kriging.py:70-116)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+
+    world = pr * pc
+    out = str(tmp_path / "p.npy")
+    mp.spawn(_uk_worker, args=(world, _free_port(), pr, pc, n, m, nb, q, out), nprocs=world, join=True)
+    got = np.load(out)
+    x, z = make_xz(n, 4, 11)
+    xt, _ = make_xz(m, 4, 12)
+    th = theta_aniso(4, scale=0.5)
+    om = orc.OracleModel(lambda a, p: np.hstack((np.ones((len(a), 1)), a))[:, :q],
+                         lambda a, b, t, pairwise=False: orc.maternp_covariance(a, b, 2, t, pairwise), None, th, "linear_predictor")
+    rm, rv = orc.predict(om, x, z, xt, zero_neg_variances=False)
+    ev = np.linalg.eigvalsh(orc.maternp_covariance(x, None, 2, th))
+    cs = max(1.0, float(ev[-1] / ev[0]) / 1e6)
+    assert np.max(np.abs(got[0] - rm)) < 1e-9 * cs * np.max(np.abs(z))
+    assert np.max(np.abs(got[1] - rv)) < 1e-9 * cs
