@@ -7,7 +7,8 @@ The reference has no distributed code.  Two places of the 
 * ``BlockCyclicCholesky``: for n beyond one GPU's HBM, K is 2-D block-cyclic over a Pr x Pc process
   grid; per block column the diagonal factor and the panel are broadcast with RCCL and each rank updates
   its own blocks with the fp64 MFMA GEMM (section 8e.3).  Scalars (log-det, quadratic form) are reduced
-  with one small all-reduce.
+  with one small all-reduce.  On that factor: NLL / REML and their analytic gradient, leave-one-out, zero-mean and universal
+  kriging, and ``fit_covparam`` (SciPy over the distributed criterion).
 
 The host logic is backend independent (``LocalOps``): the product path uses ``HipLocalOps`` (C ABI of
 libgpmp_hip.so); the CPU tests inject a NumPy implementation and run the same schedule over gloo.
@@ -15,5 +16,6 @@ libgpmp_hip.so); the CPU tests inject a NumPy implementation and run the same sc
 from .grid import ProcessGrid
 from .cholesky import BlockCyclicCholesky, HipLocalOps
 from .predict import sharded_predict, shard_bounds
+from .fit import distributed_criterion, fit_covparam
 
-__all__ = ["ProcessGrid", "BlockCyclicCholesky", "HipLocalOps", "sharded_predict", "shard_bounds"]
+__all__ = ["ProcessGrid", "BlockCyclicCholesky", "HipLocalOps", "sharded_predict", "shard_bounds", "distributed_criterion", "fit_covparam"]
