@@ -10,15 +10,29 @@ class ProcessGrid:
             raise ValueError(f"process grid {pr}x{pc} does not match world size {self.world}")
         self.pr, self.pc = pr, pc
         self.r, self.c = divmod(self.rank, pc)
+
+        def new_group(ranks):
+            # RCCL: the communicators' internal streams get HIGH priority -- they carry the panel chain (diagonal messages,
+            # panels, column operands) while a machine-filling GEMM of normal priority runs on the caller's stream; a
+            # collective's few workgroups should take the next free slot, not queue behind the GEMM's own waiting workgroups
+            if dist.get_backend(group) == "nccl" and hasattr(dist, "ProcessGroupNCCL"):
+                try:
+                    opts = dist.ProcessGroupNCCL.Options()
+                    opts.is_high_priority_stream = True
+                    return dist.new_group(ranks, pg_options=opts)
+                except (TypeError, RuntimeError):
+                    pass
+            return dist.new_group(ranks)
+
         # one communicator per process row and per process column (every rank creates all of them)
-        self.row_groups = [dist.new_group([rr * pc + cc for cc in range(pc)]) for rr in range(pr)]
-        self.col_groups = [dist.new_group([rr * pc + cc for rr in range(pr)]) for cc in range(pc)]
+        self.row_groups = [new_group([rr * pc + cc for cc in range(pc)]) for rr in range(pr)]
+        self.col_groups = [new_group([rr * pc + cc for rr in range(pr)]) for cc in range(pc)]
         # a second communicator per process column, used ONLY for the diagonal-block broadcast of the look-ahead
         # Cholesky: that broadcast is enqueued from the diagonal stream while the column exchange of the same process
         # column is enqueued from the side stream.  With one communicator both would serialise on its internal stream in
         # host issue order (correct, but the critical-path diagonal block would queue behind a bulk exchange); with two,
         # every communicator is only ever used from ONE stream and the two kinds of traffic are independent.
-        self.diag_col_groups = [dist.new_group([rr * pc + cc for rr in range(pr)]) for cc in range(pc)]
+        self.diag_col_groups = [new_group([rr * pc + cc for rr in range(pr)]) for cc in range(pc)]
         self.world_group = group
 
     @staticmethod
