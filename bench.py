@@ -599,7 +599,31 @@ def dist_potrf_extra(world, rank, res):
                 torch.cuda.synchronize()
                 entry["nll_solve_s"] = tmax(time.perf_counter() - t3)
             res[f"{transport}_{rep}"] = entry
-            del ch
+            if not (transport == "p2p" and rep == "timed"):
+                del ch
+    # ---- on the last factor (still resident): what a parameter fit and a prediction at this n cost.  LAST on
+    #      purpose: everything above is already in the progress file if one of these wedges.
+    if os.environ.get("GPMP_BENCH_DIST_MORE", "1") != "0" and info == 0:
+        m_pred = 50000
+        res["phase"] = f"predict: zero-mean prediction at {m_pred} points on the block-cyclic factor (overlapped many-RHS solve)"
+        xt = np.random.default_rng(4321).random((m_pred, d))
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mean, var, _ = ch.predict_zero_mean(MaternCovariance(2), xd, z, xt, theta)
+        torch.cuda.synchronize()
+        dt = tmax(time.perf_counter() - t0)
+        res["predict"] = {"m": m_pred, "s": dt, "points_per_s": m_pred / dt, "solve_tflops_aggregate": float(n) * n * m_pred / dt / 1e12,
+                          "finite": bool(np.isfinite(mean).all() and np.isfinite(var).all())}
+        res["phase"] = "value_and_grad: ML value + analytic gradient on the block-cyclic factor (inverse factor + ring of T^T T blocks)"
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        th_noisy = np.concatenate(([theta[0], math.log(1e-4)], theta[1:]))
+        v, g = ch.value_and_grad(x, z, th_noisy, 2, noise=True)
+        torch.cuda.synchronize()
+        dt = tmax(time.perf_counter() - t0)
+        res["value_and_grad"] = {"s": dt, "value": float(v), "grad_norm": float(np.linalg.norm(g)),
+                                 "note": "one criterion + gradient evaluation of a parameter fit at this n (the factorisation above is the rest of it)"}
+    del ch
     res["phase"] = "done"
 
 
