@@ -144,7 +144,7 @@ def _host_threads():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(n, m, d, threads, m_sample=8192, n_sample=8192):
+def cpu_baseline(n, m, d, threads, m_sample=2048, n_sample=8192):
     """The oracle (NumPy / SciPy restatement of the reference's NumPy backend: cdist -> Matern ufuncs -> cholesky ->
     2 x solve_triangular -> einsum) on the host cores, on a BOUNDED sample of the headline workload (~45-60 s of CPU work).
     The full step takes 3.5 minutes on this host (ONE full-size run: tools/cpu_fullsize_step.py, profiles/r3/cpu_fullsize_step.log:
@@ -153,7 +153,7 @@ def cpu_baseline(n, m, d, threads, m_sample=8192, n_sample=8192):
     the FULL n and only the number of prediction points is sampled:
       * Cholesky at the full n (numpy.linalg.cholesky on a stand-in SPD matrix: dpotrf's time does not depend on the entries);
       * with that full-size factor: the two triangular solves (their TFLOP/s is printed), the reductions and the NLL's
-        single-vector solves, for m_sample = 8192 of the m prediction points (2048 columns still ran the host trsm at a third of its full-size rate) (x m / m_sample: linear in m at fixed n);
+        single-vector solves, for m_sample = 2048 of the m prediction points (8192 columns run the host trsm no faster -- 0.55 vs 0.52 TFLOP/s -- and take 88 s of CPU work instead of 48) (x m / m_sample: linear in m at fixed n);
       * Gram(xi, xt_s) at the full n x m_sample (x m / m_sample) and Gram(xi, xi) at n_sample = 8192 observations
         (x (n / n_sample)^2): SciPy cdist + the Matern ufuncs are single-threaded elementwise passes, linear in the entries.
         T = 2 (Gram_ii (n/n_s)^2 + Cholesky(n)) + NLL_tail(n) + m/m_s (Gram_it(n) + Solve(n) + Reductions(n))
@@ -970,7 +970,7 @@ def main():
     ap.add_argument("--dim-d", dest="d", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--cpu-m-sample", type=int, default=8192, help="prediction points of the CPU baseline's bounded sample")
+    ap.add_argument("--cpu-m-sample", type=int, default=2048, help="prediction points of the CPU baseline's bounded sample")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] extras")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--role", choices=("auto", "headline", "dist-extra"), default="auto", help="internal: set by the launcher")
