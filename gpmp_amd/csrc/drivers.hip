@@ -101,7 +101,7 @@ struct PredictLayout {
 PredictLayout predict_layout(int n, int m) {
   PredictLayout l;
   l.ldn = pad16(n);
-  l.ldm = pad16(m);
+  l.ldm = pad16(m + 2);             // K(xi, xt) | z | (a zero column when that keeps the column count even)
   size_t o = 0;
   l.K = o; o += (size_t)n * l.ldn;
   l.dinv = o; o += pad16((long)gpmp_dinv_elems(n));
@@ -142,14 +142,17 @@ extern "C" int gpmp_predict_zero_mean(const double* xi, const double* zi, const 
   if (rc) return rc;
   rc = gpmp_matern_gram(xi, xt, n, m, d, p, theta_host, noise, 0.0, 0, Kit, l.ldm, stream);
   if (rc) return rc;
-  // factorisation and V = L^-1 K(xi, xt) (in place) in one call: the leading half of the solve overlaps the trailing half
-  // of the factorisation
-  rc = gpmp_potrf_trsm_lower_async(K, n, l.ldn, dinv, info_dev, Kit, m, l.ldm, stream);
+  // z rides along as one more right-hand side: [V | w] = L^-1 [K(xi, xt) | z] in ONE solve (the separate single-vector sweep
+  // for w = L^-1 z was 0.17 ms of a 5.3 ms prediction at n = 4096 and waited for the end of the factorisation; as a column of
+  // the panel-by-panel solve it is hidden like the rest).  An even column count keeps the LDS-direct GEMM's fast path.
+  (void)w;
+  const int mb = (m + 1) + ((m + 1) & 1);
+  GPMP_HIP_TRY(hipMemcpy2DAsync(Kit + m, (size_t)l.ldm * sizeof(double), zi, sizeof(double), sizeof(double), n, hipMemcpyDeviceToDevice, st));
+  if (mb > m + 1) GPMP_HIP_TRY(hipMemset2DAsync(Kit + m + 1, (size_t)l.ldm * sizeof(double), 0, sizeof(double), n, st));
+  // factorisation and the solve (in place) in one call: panel by panel behind the factorisation at chain-bound sizes
+  rc = gpmp_potrf_trsm_lower_async(K, n, l.ldn, dinv, info_dev, Kit, mb, l.ldm, stream);
   if (rc) return rc;
-  GPMP_HIP_TRY(hipMemcpy2DAsync(w, 16 * sizeof(double), zi, sizeof(double), sizeof(double), n, hipMemcpyDeviceToDevice, st));
-  rc = gpmp_trsm_lower(K, n, l.ldn, dinv, w, 1, 16, 0, nullptr, stream);                    // w = L^-1 z
-  if (rc) return rc;
-  rc = gpmp_coldots(Kit, n, m, l.ldm, w, 1, 16, D, l.ldm, ws + l.cd, stream);               // V^T w and colsumsq(V)
+  rc = gpmp_coldots(Kit, n, m, l.ldm, Kit + m, 1, l.ldm, D, l.ldm, ws + l.cd, stream);      // V^T w and colsumsq(V)
   if (rc) return rc;
   hipLaunchKernelGGL(predict_finalize_kernel, dim3((m + 255) / 256), dim3(256), 0, st, D, l.ldm, m, sigma2,
                      zero_neg_variances, info_dev, zpm_dev, zpv_dev);

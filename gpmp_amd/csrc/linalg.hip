@@ -371,12 +371,24 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
       if (pb[j] > r0 && pb[j] - r0 >= along_rows) return pb[j];
     return n;
   };
+  // GPMP_POTRF_ALONG_RIGHT (read at every call): 1 = RIGHT-looking updates -- behind the solve of the piece [s0, r0) ALL later
+  // rows receive its contribution at once, B[r0:n] -= L[r0:n, s0:r0] X[s0:r0] (K = one piece), so that when the factorisation ends
+  // the last piece only waits for its own diagonal solve; 0 = left-looking: the next piece alone receives everything solved so
+  // far (K = r0: one long update, the last of which -- K = 3n/4 -- starts only when the third quarter is solved).
+  const int along_right = env_int("GPMP_POTRF_ALONG_RIGHT", 1);
+  int solved_from = 0;                           // start of the piece solved last
   auto early_update = [&](int r0) -> int {       // (a) for the piece that starts at r0 = n1_solved
     if (r0 >= n) return 0;
     const int r1 = piece_end(r0);
     GemmOpts plain;
-    int rcu = launch_gemm(true, false, r1 - r0, sa->m, r0, -1.0, A + (long)r0 * lda, lda, sa->B, sa->ldb, 1.0,
-                          sa->B + (long)r0 * sa->ldb, sa->ldb, plain, g_solve_stream);
+    int rcu;
+    if (along_right)
+      rcu = launch_gemm(true, false, n - r0, sa->m, r0 - solved_from, -1.0, A + (long)r0 * lda + solved_from, lda,
+                        sa->B + (long)solved_from * sa->ldb, sa->ldb, 1.0, sa->B + (long)r0 * sa->ldb, sa->ldb, plain, g_solve_stream);
+    else
+      rcu = launch_gemm(true, false, r1 - r0, sa->m, r0, -1.0, A + (long)r0 * lda, lda, sa->B, sa->ldb, 1.0,
+                        sa->B + (long)r0 * sa->ldb, sa->ldb, plain, g_solve_stream);
+    solved_from = r0;
     upd_end = r1;
     return rcu;
   };
