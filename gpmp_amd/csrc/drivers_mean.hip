@@ -311,7 +311,7 @@ struct PredictMeanLayout {
 PredictMeanLayout predict_mean_layout(int n, int m, int q) {
   PredictMeanLayout l;
   l.ldn = pad16(n);
-  l.ldm = pad16(m);
+  l.ldm = pad16(m + 2 + q);          // K(xi, xt) | z | P | (a zero column when that keeps the column count even)
   l.ldq = pad16(1 + q);
   size_t o = 0;
   auto take = [&](size_t cnt) { size_t at = o; o += (size_t)pad16((long)cnt); return at; };
@@ -461,13 +461,19 @@ extern "C" int gpmp_predict_mean(const double* xi, const double* zi, const doubl
   if (rc) return rc;
   rc = gpmp_matern_gram(xi, xt, n, m, d, p, theta_host, noise, 0.0, 0, Kit, l.ldm, stream);
   if (rc) return rc;
-  rc = gpmp_potrf_trsm_lower_async(K, n, l.ldn, dinv, info_dev, Kit, m, l.ldm, stream);          // V = L^-1 K(xi, xt), in place
-  if (rc) return rc;
-  hipLaunchKernelGGL(pack_zp_kernel, dim3((n + 255) / 256), dim3(256), 0, st, zi, Pi, ldpi, n, q, Y, l.ldq);
+  // [z, P] ride along as 1 + q more right-hand sides: [V | W] = L^-1 [K(xi, xt) | z | P] in ONE solve (gpmp_predict_zero_mean does
+  // the same with z): the separate few-column sweep waited for the end of the factorisation; an even column count keeps the
+  // LDS-direct GEMM's fast path
+  (void)Y;
+  double* W = Kit + m;
+  const long ldw = l.ldm;
+  const int mb = (m + 1 + q) + ((m + 1 + q) & 1);
+  hipLaunchKernelGGL(pack_zp_kernel, dim3((n + 255) / 256), dim3(256), 0, st, zi, Pi, ldpi, n, q, W, ldw);
   GPMP_HIP_TRY(hipGetLastError());
-  rc = gpmp_trsm_lower(K, n, l.ldn, dinv, Y, 1 + q, l.ldq, 0, nullptr, stream);                   // W = L^-1 [z, P]
+  if (mb > m + 1 + q) GPMP_HIP_TRY(hipMemset2DAsync(Kit + m + 1 + q, (size_t)l.ldm * sizeof(double), 0, sizeof(double), n, st));
+  rc = gpmp_potrf_trsm_lower_async(K, n, l.ldn, dinv, info_dev, Kit, mb, l.ldm, stream);         // in place
   if (rc) return rc;
-  rc = gpmp_coldots(Y, n, 1 + q, l.ldq, Y, 1 + q, l.ldq, ws + l.Gm, l.ldq, ws + l.cd, stream);    // W^T W
+  rc = gpmp_coldots(W, n, 1 + q, ldw, W, 1 + q, ldw, ws + l.Gm, l.ldq, ws + l.cd, stream);        // W^T W
   if (rc) return rc;
   rc = gpmp_coldots(Pi, n, q, ldpi, Pi, q, ldpi, ws + l.PtP, l.ldq, ws + l.cd, stream);
   if (rc) return rc;
@@ -479,7 +485,7 @@ extern "C" int gpmp_predict_mean(const double* xi, const double* zi, const doubl
                        ws + l.Sinv, l.ldq, info_dev);
     GPMP_HIP_TRY(hipGetLastError());
   }
-  rc = gpmp_coldots(Kit, n, m, l.ldm, Y, 1 + q, l.ldq, ws + l.D, l.ldm, ws + l.cd, stream);       // V^T [w, Wp] and colsumsq(V)
+  rc = gpmp_coldots(Kit, n, m, l.ldm, W, 1 + q, ldw, ws + l.D, l.ldm, ws + l.cd, stream);         // V^T [w, Wp] and colsumsq(V)
   if (rc) return rc;
   const size_t fin_bytes = sizeof(double) * ((size_t)q * q + q);
   GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(predict_mean_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
