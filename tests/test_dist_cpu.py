@@ -65,6 +65,7 @@ def _chol_worker(rank, world, port, pr, pc, n, nb, out, transport="bcast", looka
     (1, 2, 700, 128, "bcast", True), (2, 1, 700, 128, "bcast", True), (2, 2, 1000, 128, "bcast", True),
     (2, 2, 1100, 256, "p2p", True), (1, 4, 900, 128, "p2p", True), (2, 2, 1000, 128, "bcast", False),
     (2, 2, 200, 128, "p2p", False),      # fewer blocks than the grid is wide: some ranks own nothing in a column
+    (3, 2, 900, 128, "bcast", True), (2, 3, 900, 128, "p2p", True),     # non-square, Pr and Pc coprime: lcm(Pr, Pc) strides in the exchange
     (2, 4, 1900, 128, "bcast", True),    # the grid of BASELINE config 5 (8 ranks) ...
     (2, 4, 1900, 128, "p2p", True)])     # ... with the root fanning out over separate links
 def test_block_cyclic_cholesky_and_nll(tmp_path, pr, pc, n, nb, transport, lookahead):

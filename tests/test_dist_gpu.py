@@ -405,3 +405,74 @@ def test_block_cyclic_universal_kriging_hip(tmp_path, pr, pc, n, m, nb, q):
     cs = max(1.0, float(ev[-1] / ev[0]) / 1e6)
     assert np.max(np.abs(got[0] - rm)) < 1e-9 * cs * np.max(np.abs(z))
     assert np.max(np.abs(got[1] - rv)) < 1e-9 * cs
+
+
+@pytest.mark.parametrize("pr,pc", [(2, 3), (3, 2), (2, 4), (4, 2), (3, 3), (1, 4), (4, 1)])
+@pytest.mark.parametrize("n,nb", [(1900, 128), (2304, 256)])
+def test_step_abi_local_kernels_on_any_grid_single_process(pr, pc, n, nb):
+    """gpmp_dist_exchange_pack / _unpack / _trailing_update for EVERY rank coordinate of non-square grids (lcm(Pr, Pc) strides,
+    ragged last blocks), in ONE process: the buffers a rank would hold after the broadcasts are cut out of a global panel
+    with NumPy, the C entry points run on them, and the results are compared with the block-cyclic definition -- the grids
+    the multi-process GPU tests cannot reach on a one-GPU box (at most six processes may share it)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gpmp_amd.num as gnp
+    from gpmp_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(pr * 100 + pc * 10 + nb)
+    nblk = (n + nb - 1) // nb
+    bs = lambda I: min(nb, n - I * nb)                 # noqa: E731
+    rows_of = lambda blocks: np.concatenate([np.arange(I * nb, I * nb + bs(I)) for I in blocks]) if blocks else np.zeros(0, dtype=np.int64)   # noqa: E731
+    A = rng.standard_normal((n, n))
+    for k in sorted({0, 1, nblk // 2, nblk - 2}):
+        bk = bs(k)
+        Lk = rng.standard_normal((n, bk))             # the (already solved) block column k: rows = global rows
+        for r in range(pr):
+            for c in range(pc):
+                rb, cb = list(range(r, nblk, pr)), list(range(c, nblk, pc))
+                gr, gc = rows_of(rb), rows_of(cb)
+                if len(gr) == 0 or len(gc) == 0:
+                    continue
+                Aloc = gnp.as_matrix(gnp.asarray(A[np.ix_(gr, gc)]), copy=True)
+                prow, crow = rows_of([I for I in rb if I > k]), rows_of([J for J in cb if J > k])
+                panel = gnp.alloc_matrix(max(len(prow), 1), nb, zero=True)
+                if len(prow):
+                    panel[: len(prow), :bk] = gnp.asarray(Lk[prow])
+                colop = gnp.alloc_matrix(max(len(crow), 1), nb, zero=True)
+                # ---- column operand through pack (as the holder rank (rp, c) would) + unpack (as this rank does)
+                for rp in range(pr):
+                    rows = int(lib.gpmp_dist_exchange_rows(n, nb, pr, pc, rp, c, k))
+                    want_rows = rows_of([J for J in cb if J > k and J % pr == rp])
+                    assert rows == len(want_rows)
+                    if rows == 0:
+                        continue
+                    hb = list(range(rp, nblk, pr))                                  # the holder's block rows
+                    hrow = rows_of([I for I in hb if I > k])
+                    hpanel = gnp.alloc_matrix(max(len(hrow), 1), nb, zero=True)
+                    hpanel[: len(hrow), :bk] = gnp.asarray(Lk[hrow])
+                    piece = gnp.alloc_matrix(rows, nb, zero=True)
+                    _lib.check(lib.gpmp_dist_exchange_pack(gnp._ptr(hpanel), gnp._ld(hpanel), gnp._ptr(piece), gnp._ld(piece), n, nb, pr, pc, rp, c, k,
+                                                           bk, gnp._stream()), "pack")
+                    assert np.array_equal(gnp.to_np(piece[:, :bk]), Lk[want_rows])
+                    _lib.check(lib.gpmp_dist_exchange_unpack(gnp._ptr(piece), gnp._ld(piece), gnp._ptr(colop), gnp._ld(colop), n, nb, pr, pc, rp, c, k,
+                                                             bk, gnp._stream()), "unpack")
+                if len(crow):
+                    assert np.array_equal(gnp.to_np(colop[: len(crow), :bk]), Lk[crow])
+                # ---- trailing update of the local blocks I >= J > k
+                _lib.check(lib.gpmp_dist_trailing_update(gnp._ptr(Aloc), gnp._ld(Aloc), n, nb, pr, pc, r, c, k, gnp._ptr(panel), gnp._ld(panel),
+                                                         gnp._ptr(colop), gnp._ld(colop), 0, -1, -1, gnp._stream()), "update")
+                got = gnp.to_np(Aloc)
+                want = A[np.ix_(gr, gc)].copy()
+                full = A - Lk @ Lk.T
+                for li, I in enumerate(rb):
+                    for lj, J in enumerate(cb):
+                        if I >= J > k:
+                            r0, c0 = li * nb, lj * nb
+                            blk_w = full[I * nb: I * nb + bs(I), J * nb: J * nb + bs(J)]
+                            blk_g = got[r0: r0 + bs(I), c0: c0 + bs(J)]
+                            assert np.max(np.abs(blk_g - blk_w)) < 1e-11 * np.max(np.abs(blk_w)), (pr, pc, r, c, k, I, J)
+                # blocks in block columns <= k are never touched
+                for lj, J in enumerate(cb):
+                    if J <= k:
+                        assert np.array_equal(got[:, lj * nb: lj * nb + bs(J)], want[:, lj * nb: lj * nb + bs(J)])
