@@ -101,7 +101,7 @@ class REMLAnalytic:
 
 # ---- many small problems in one call ------------------------------------------------------------------
 BATCH_MAX_N = 2048      # GPMP_BATCH_MAX_N
-BATCH_MAX_Q = 3
+BATCH_MAX_Q = 7
 
 
 def batch_qualifies(model, use_mean=False):
@@ -132,9 +132,9 @@ def batch_values_and_gradients(model, covparams, batches, want_grad=True, use_me
     (gpmp/num/torch_backend.py:607-718) and multi-parameter log_prob evaluations (gpmp/mcmc/param_posterior.py:229-278).
 
     ``batches``: list of (x_b, z_b) device arrays; ``covparams``: one parameter vector (shared) or a (B, ntheta) array.
-    ``use_mean``: REML with ``model.mean`` as the linear predictor (q <= 3 columns), else the zero-mean NLL.
+    ``use_mean``: REML with ``model.mean`` as the linear predictor (q <= 7 columns), else the zero-mean NLL.
     Returns ``(values, grads)`` as NumPy arrays ((B,), (B, ntheta) or None), or ``None`` when the batch does not
-    qualify (not a declared Matern covariance, a batch above 2048 points, more than 3 mean columns): the caller then
+    qualify (not a declared Matern covariance, a batch above 2048 points, more than 7 mean columns): the caller then
     evaluates the batches one after the other.  A failed factorisation raises ``HipLinAlgError`` like the array path."""
     cov = model.covariance
     if not isinstance(cov, MaternCovariance) or len(batches) == 0:

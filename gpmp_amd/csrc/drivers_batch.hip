@@ -1,4 +1,4 @@
-// Many small GP problems at once: B independent criteria (zero-mean NLL, or REML with a mean design of q <= 3 columns)
+// Many small GP problems at once: B independent criteria (zero-mean NLL, or REML with a mean design of q <= 7 columns)
 // with their analytic gradients, every step ONE launch over all problems.  This is the throughput caller of SURVEY 8(f).4:
 //   * mini-batch selection criteria -- the weighted mean over the batches of a loader of the per-batch NLL / REML and its
 //     gradient (gpmp/num/torch_backend.py:607-718, gpmp/dataloader.py:484-513): B batches, ONE parameter vector;
@@ -21,10 +21,10 @@
 namespace gpmp {
 namespace {
 
-constexpr int BQ = 3;              // mean-design columns supported in the batched path
-constexpr int BR = BQ + 1;         // right-hand sides per problem: [z, P]
-constexpr int BSM = 32;            // doubles of per-problem scalars: [0] logdet K, [1] quad, [2] ln|S|, [3] ln|PtP|, [4] fail,
-                                   // [8 + a] c = S^-1 b, [16 + 3 a + b] S^-1
+constexpr int BQ = 7;              // mean-design columns supported in the batched path (round 2: 3; a linear mean in d <= 6 fits now)
+constexpr int BR = BQ + 1;         // right-hand sides per problem: [z, P]; the kernels exist for 4 (q <= 3) and 8 of them
+constexpr int BSM = 80;            // doubles of per-problem scalars: [0] logdet K, [1] quad, [2] ln|S|, [3] ln|PtP|, [4] fail,
+                                   // [8 + a] c = S^-1 b, [16 + BQ a + b] S^-1
 inline long pad16(long v) { return (v + 15) / 16 * 16; }
 
 // identity in the padding of one slot: rows / columns n .. nmax - 1 (lower triangle + diagonal are what the factorisation reads)
@@ -57,11 +57,11 @@ __global__ void batch_pack_kernel(const double* __restrict__ z, long sz, const d
 
 // op(L_b)^-1 Y_b in place, one workgroup (256 threads) per problem; blocks of NB rows, diagonal-block inverses from dinv.
 // Thread t owns row (t & 127) of a block and half (t >> 7) of the 128-wide inner range; halves meet in LDS.
-template <bool TRANS>
+template <bool TRANS, int BRT>
 __global__ void __launch_bounds__(256) batch_trsv_kernel(const double* __restrict__ Lall, long ldl, long sl, const double* __restrict__ dall,
                                                          long sd, double* __restrict__ Yall, long ldy, long sy, int nmax, int r) {
-  __shared__ double xs[NB][BR];
-  __shared__ double part[NB][BR];
+  __shared__ double xs[NB][BRT];
+  __shared__ double part[NB][BRT];
   const double* L = Lall + (long)blockIdx.x * sl;
   const double* dinv = dall + (long)blockIdx.x * sd;
   double* Y = Yall + (long)blockIdx.x * sy;
@@ -72,35 +72,35 @@ __global__ void __launch_bounds__(256) batch_trsv_kernel(const double* __restric
     const int k0 = k * NB;
     const int kb = (nmax - k0) < NB ? (nmax - k0) : NB;
     // right-hand side rows of block k (already updated by the blocks solved before)
-    for (int idx = t; idx < NB * BR; idx += 256) {
-      const int l = idx / BR, c = idx % BR;
+    for (int idx = t; idx < NB * BRT; idx += 256) {
+      const int l = idx / BRT, c = idx % BRT;
       xs[l][c] = (l < kb && c < r) ? Y[(long)(k0 + l) * ldy + c] : 0.0;
     }
     __syncthreads();
     // x_k = op(inv(L_kk)) b_k   (dinv block: NB x NB, identity-padded)
-    double acc[BR];
+    double acc[BRT];
 #pragma unroll
-    for (int c = 0; c < BR; ++c) acc[c] = 0.0;
+    for (int c = 0; c < BRT; ++c) acc[c] = 0.0;
     const double* D = dinv + (size_t)k * NB * NB;
     for (int l = 0; l < 64; ++l) {
       const int ll = half * 64 + l;
       const double m = TRANS ? D[ll * NB + i] : D[i * NB + ll];
 #pragma unroll
-      for (int c = 0; c < BR; ++c) acc[c] = fma(m, xs[ll][c], acc[c]);
+      for (int c = 0; c < BRT; ++c) acc[c] = fma(m, xs[ll][c], acc[c]);
     }
     if (half == 1) {
 #pragma unroll
-      for (int c = 0; c < BR; ++c) part[i][c] = acc[c];
+      for (int c = 0; c < BRT; ++c) part[i][c] = acc[c];
     }
     __syncthreads();
     if (half == 0) {
 #pragma unroll
-      for (int c = 0; c < BR; ++c) xs[i][c] = acc[c] + part[i][c];   // x_k replaces b_k in LDS (all reads of b_k are done)
+      for (int c = 0; c < BRT; ++c) xs[i][c] = acc[c] + part[i][c];   // x_k replaces b_k in LDS (all reads of b_k are done)
     }
     __syncthreads();
     if (half == 0 && i < kb) {
 #pragma unroll
-      for (int c = 0; c < BR; ++c)
+      for (int c = 0; c < BRT; ++c)
         if (c < r) Y[(long)(k0 + i) * ldy + c] = xs[i][c];
     }
     // blocks still to be solved: b_j -= op(L)[j, k] x_k
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) batch_trsv_kernel(const double* __restric
       const int j0 = j * NB;
       const int jb = (nmax - j0) < NB ? (nmax - j0) : NB;
 #pragma unroll
-      for (int c = 0; c < BR; ++c) acc[c] = 0.0;
+      for (int c = 0; c < BRT; ++c) acc[c] = 0.0;
       if (i < jb) {
         const int lmax = (kb - half * 64) < 64 ? (kb - half * 64) : 64;
         for (int l = 0; l < lmax; ++l) {
@@ -117,17 +117,17 @@ __global__ void __launch_bounds__(256) batch_trsv_kernel(const double* __restric
           // forward: L[j0 + i][k0 + ll]; transposed: (L^T)[j0 + i][k0 + ll] = L[k0 + ll][j0 + i]
           const double m = TRANS ? L[(long)(k0 + ll) * ldl + j0 + i] : L[(long)(j0 + i) * ldl + k0 + ll];
 #pragma unroll
-          for (int c = 0; c < BR; ++c) acc[c] = fma(m, xs[ll][c], acc[c]);
+          for (int c = 0; c < BRT; ++c) acc[c] = fma(m, xs[ll][c], acc[c]);
         }
       }
       if (half == 1) {
 #pragma unroll
-        for (int c = 0; c < BR; ++c) part[i][c] = acc[c];
+        for (int c = 0; c < BRT; ++c) part[i][c] = acc[c];
       }
       __syncthreads();
       if (half == 0 && i < jb) {
 #pragma unroll
-        for (int c = 0; c < BR; ++c)
+        for (int c = 0; c < BRT; ++c)
           if (c < r) Y[(long)(j0 + i) * ldy + c] -= acc[c] + part[i][c];
       }
       __syncthreads();
@@ -140,52 +140,65 @@ __global__ void __launch_bounds__(256) batch_trsv_kernel(const double* __restric
 //   q = 0:  value = 1/2 (n ln 2 pi + ln|K| + w^T w)
 //   q > 0:  value = 1/2 ((n - q) ln 2 pi + ln|K| + ln|S| - ln|P^T P| + w^T w - b^T S^-1 b),  S = Wp^T Wp, b = Wp^T w
 // small (BSM doubles per problem) keeps S^-1 and c = S^-1 b for the gradient; info[b] += n + pivot on a singular mean design.
+// QT: mean-design columns the instantiation carries (3 or 7); sums: [0] log L_ii, then the upper triangles of W^T W
+// ((QT + 1) x (QT + 1)) and of P^T P (QT x QT) -- 17 sums for QT = 3, 65 for QT = 7; reduced by wave shuffles, then across the
+// four waves through LDS (a 256 x 65 LDS image would not fit)
+template <int QT>
 __global__ void __launch_bounds__(256) batch_value_kernel(const double* __restrict__ Lall, long ldl, long sl, const double* __restrict__ Wall,
                                                           long ldw, long sw, const double* __restrict__ P, long ldp, long sp, int q,
                                                           const int* __restrict__ ns, int nmax, double* __restrict__ small,
                                                           int* __restrict__ info, double* __restrict__ values) {
-  __shared__ double red[256][17];      // [0] log L_ii, [1 .. 10] upper triangle of W^T W (<= 4 x 4), [11 .. 16] of P^T P (<= 3 x 3)
+  constexpr int RT = QT + 1;
+  constexpr int NS = 1 + RT * (RT + 1) / 2 + QT * (QT + 1) / 2;
+  __shared__ double red[4][NS];
   const int b = blockIdx.x, t = threadIdx.x;
   const double* L = Lall + (long)b * sl;
   const double* W = Wall + (long)b * sw;
   const int n = ns[b];
-  double acc[17];
+  double acc[NS];
 #pragma unroll
-  for (int k = 0; k < 17; ++k) acc[k] = 0.0;
+  for (int k = 0; k < NS; ++k) acc[k] = 0.0;
   for (int i = t; i < nmax; i += 256) {
     acc[0] += log(L[(long)i * ldl + i]);
-    double w[BR], pr[BQ];
-    for (int c = 0; c < BR; ++c) w[c] = (c <= q) ? W[(long)i * ldw + c] : 0.0;
-    for (int c = 0; c < BQ; ++c) pr[c] = (c < q && i < n) ? P[(long)b * sp + (long)i * ldp + c] : 0.0;
+    double w[RT], pr[QT];
+#pragma unroll
+    for (int c = 0; c < RT; ++c) w[c] = (c <= q) ? W[(long)i * ldw + c] : 0.0;
+#pragma unroll
+    for (int c = 0; c < QT; ++c) pr[c] = (c < q && i < n) ? P[(long)b * sp + (long)i * ldp + c] : 0.0;
     int k = 1;
-    for (int c = 0; c < BR; ++c)
-      for (int e = c; e < BR; ++e) acc[k++] += w[c] * w[e];
-    for (int c = 0; c < BQ; ++c)
-      for (int e = c; e < BQ; ++e) acc[k++] += pr[c] * pr[e];
+#pragma unroll
+    for (int c = 0; c < RT; ++c)
+#pragma unroll
+      for (int e = c; e < RT; ++e) acc[k++] += w[c] * w[e];
+#pragma unroll
+    for (int c = 0; c < QT; ++c)
+#pragma unroll
+      for (int e = c; e < QT; ++e) acc[k++] += pr[c] * pr[e];
   }
 #pragma unroll
-  for (int k = 0; k < 17; ++k) red[t][k] = acc[k];
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (t < s)
-      for (int k = 0; k < 17; ++k) red[t][k] += red[t + s][k];
-    __syncthreads();
+  for (int k = 0; k < NS; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((t & 63) == 0) red[t >> 6][k] = v;
   }
+  __syncthreads();
   if (t != 0) return;
   double G[BR][BR], PtP[BQ][BQ];
   {
     int k = 1;
-    for (int c = 0; c < BR; ++c)
-      for (int e = c; e < BR; ++e) { G[c][e] = G[e][c] = red[0][k++]; }
-    for (int c = 0; c < BQ; ++c)
-      for (int e = c; e < BQ; ++e) { PtP[c][e] = PtP[e][c] = red[0][k++]; }
+    for (int c = 0; c < RT; ++c)
+      for (int e = c; e < RT; ++e) { G[c][e] = G[e][c] = red[0][k] + red[1][k] + red[2][k] + red[3][k]; ++k; }
+    for (int c = 0; c < QT; ++c)
+      for (int e = c; e < QT; ++e) { PtP[c][e] = PtP[e][c] = red[0][k] + red[1][k] + red[2][k] + red[3][k]; ++k; }
   }
-  const double logdetK = 2.0 * red[0][0];
+  const double sumlog = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+  const double logdetK = 2.0 * sumlog;
   double* sm = small + (long)b * BSM;
   int fail = 0;
   double ldS = 0.0, ldP = 0.0, quad = G[0][0];
   if (q > 0) {
-    // Cholesky of a q x q matrix (q <= 3) with the relative pivot test of the single-problem driver
+    // Cholesky of a q x q matrix (q <= BQ) with the relative pivot test of the single-problem driver
     auto chol = [&](double (*M)[BQ], double& logdet) {
       double d0[BQ];
       for (int k = 0; k < q; ++k) d0[k] = M[k][k];
@@ -225,7 +238,7 @@ __global__ void __launch_bounds__(256) batch_value_kernel(const double* __restri
       for (int j = 0; j < q; ++j) {
         double s = 0.0;
         for (int l = (i > j ? i : j); l < q; ++l) s += Ri[l][i] * Ri[l][j];
-        sm[16 + 3 * i + j] = s;
+        sm[16 + BQ * i + j] = s;
         ci += s * bvec[j];
       }
       sm[8 + i] = ci;
@@ -254,7 +267,7 @@ __global__ void batch_rows_kernel(const double* __restrict__ Xall, long ldx, lon
   for (int a = 0; a < q; ++a) beta -= xr[1 + a] * sm[8 + a];
   for (int a = 0; a < q; ++a) {
     double s = 0.0;
-    for (int l = 0; l < q; ++l) s += xr[1 + l] * sm[16 + 3 * l + a];
+    for (int l = 0; l < q; ++l) s += xr[1 + l] * sm[16 + BQ * l + a];
     F[a] = s;
     G[a] = xr[1 + a];
   }
@@ -321,7 +334,7 @@ extern "C" int gpmp_nll_grad_batch(const double* x, long stride_x, const double*
                                    double* grads_dev, int* info_dev, gpmp_stream_t stream) {
   GPMP_ARG(x != nullptr, 1, "x is NULL");
   GPMP_ARG(z != nullptr, 3, "z is NULL");
-  GPMP_ARG(q >= 0 && q <= BQ, 8, "q outside [0, 3] (the batched path carries at most 3 mean-design columns)");
+  GPMP_ARG(q >= 0 && q <= BQ, 8, "q outside [0, 7] (the batched path carries at most 7 mean-design columns)");
   GPMP_ARG(q == 0 || (P != nullptr && ldp >= q), 5, "P is NULL or ldp < q");
   GPMP_ARG(nmax >= 1 && nmax <= GPMP_BATCH_MAX_N, 10, "nmax outside [1, GPMP_BATCH_MAX_N]");
   GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 11, "d outside [1, GPMP_MAX_DIM]");
@@ -393,18 +406,31 @@ extern "C" int gpmp_nll_grad_batch(const double* x, long stride_x, const double*
   hipLaunchKernelGGL(batch_pack_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, st, z, stride_z, P, ldp, stride_p, q, ns, nmax, Y,
                      l.ldq, (long)l.sY);
   GPMP_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL((batch_trsv_kernel<false>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, Y, l.ldq, (long)l.sY,
-                     nmax, 1 + q);
-  GPMP_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(batch_value_kernel, dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, Y, l.ldq, (long)l.sY, P, ldp, stride_p, q, ns,
-                     nmax, ws + l.small, info_dev, values_dev);
+  // (two instantiations: 4 right-hand sides for q <= 3 -- every reference example -- and 8 for q <= 7)
+  if (q <= 3) {
+    hipLaunchKernelGGL((batch_trsv_kernel<false, 4>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, Y, l.ldq, (long)l.sY,
+                       nmax, 1 + q);
+    GPMP_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(batch_value_kernel<3>, dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, Y, l.ldq, (long)l.sY, P, ldp, stride_p, q, ns,
+                       nmax, ws + l.small, info_dev, values_dev);
+  } else {
+    hipLaunchKernelGGL((batch_trsv_kernel<false, 8>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, Y, l.ldq, (long)l.sY,
+                       nmax, 1 + q);
+    GPMP_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(batch_value_kernel<7>, dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, Y, l.ldq, (long)l.sY, P, ldp, stride_p, q, ns,
+                       nmax, ws + l.small, info_dev, values_dev);
+  }
   GPMP_HIP_TRY(hipGetLastError());
   if (!grad) return 0;
   // ---- gradient: X = L^-T W = K^-1 [z, P]; F, G; K^-1 = T^T T over the factor's slot; trace per problem
   double* X = ws + l.X;
   GPMP_HIP_TRY(hipMemcpyAsync(X, Y, sizeof(double) * l.sY * B, hipMemcpyDeviceToDevice, st));
-  hipLaunchKernelGGL((batch_trsv_kernel<true>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, X, l.ldq, (long)l.sY,
-                     nmax, 1 + q);
+  if (q <= 3)
+    hipLaunchKernelGGL((batch_trsv_kernel<true, 4>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, X, l.ldq, (long)l.sY,
+                       nmax, 1 + q);
+  else
+    hipLaunchKernelGGL((batch_trsv_kernel<true, 8>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, X, l.ldq, (long)l.sY,
+                       nmax, 1 + q);
   GPMP_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(batch_rows_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, st, X, l.ldq, (long)l.sY, ws + l.small, q, ns,
                      ws + l.F, ws + l.G, l.ldq, (long)l.sY);

@@ -205,7 +205,7 @@ class BatchDifferentiableSelectionCriterion:
                 pending.append((xb, zb))
                 nmax = max(nmax, bs)
                 # q is not known here (the mean is a user callable): size the piece for the widest design the kernel takes
-                lim = limit_fn(nmax, int(xb.shape[1]), 3, want_grad, xb.device) if limit_fn is not None else 64
+                lim = limit_fn(nmax, int(xb.shape[1]), 7, want_grad, xb.device) if limit_fn is not None else 64
                 if len(pending) >= max(1, lim):
                     flush()
             else:

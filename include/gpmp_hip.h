@@ -295,7 +295,7 @@ int gpmp_predict_mean(const double* xi, const double* zi, const double* Pi, long
 
 /* ---- many small problems at once (mini-batch criteria, posterior samplers) ------------------------------------- */
 
-/* B independent criteria -- the zero-mean NLL (q = 0) or REML with a mean design of q <= 3 columns -- and, when
+/* B independent criteria -- the zero-mean NLL (q = 0) or REML with a mean design of q <= 7 columns -- and, when
  * grads_dev != NULL, their gradients with respect to the covariance parameters, every step ONE launch over all
  * problems (problem = blockIdx.y / .z of the diagonal-block, GEMM and solve kernels).  Callers: the weighted mean over
  * the batches of a loader (gpmp/num/torch_backend.py:607-718, gpmp/dataloader.py:484-513: B batches, one parameter

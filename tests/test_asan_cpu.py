@@ -29,7 +29,7 @@ for n in (0, 1, 127, 128, 129, 1000, 1024, 1025, 4096, 32768, 131072):
             lib.gpmp_nll_grad_ws_elems(n, d, q)
 for nmax in (1, 128, 300, 1024, 1025):
     for B in (1, 7, 256):
-        for q in (0, 3, 4):
+        for q in (0, 3, 4, 7, 8):
             lib.gpmp_batch_ws_elems(nmax, 5, q, B, 1); lib.gpmp_batch_ws_elems(nmax, 5, q, B, 0)
 for d in (1, 4, 8, 16, 20, 33, 64):
     lib.gpmp_grad_ws_elems(1000, d)

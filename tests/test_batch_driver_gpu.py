@@ -102,7 +102,7 @@ def _cond_scale(K):
 
 
 @pytest.mark.parametrize("noise", [0, 1])
-@pytest.mark.parametrize("q", [0, 1, 3])
+@pytest.mark.parametrize("q", [0, 1, 3, 4, 7])
 @pytest.mark.parametrize("sizes", [(2048, 1300, 1537), (300, 128, 77, 257)])
 def test_batch_driver_against_the_oracle_at_its_edges(env, sizes, q, noise):
     """the batched kernel against the CPU ORACLE (not against another HIP driver): ragged slots up to the 2048-point limit,
@@ -117,7 +117,8 @@ def test_batch_driver_against_the_oracle_at_its_edges(env, sizes, q, noise):
         th = np.concatenate(([th[0], math.log(1e-4)], th[1:]))
     data = [_data(n, d, 100 + n + k) for k, n in enumerate(sizes)]
     xs, zs = [a for a, _ in data], [b for _, b in data]
-    Ps = None if q == 0 else [np.hstack((np.ones((len(x), 1)), x))[:, :q] for x in xs]
+    # mean design: columns of [1, x, x^2] (q = 4: the linear mean of d = 3; q = 7: the widest the batched path carries)
+    Ps = None if q == 0 else [np.hstack((np.ones((len(x), 1)), x, x * x))[:, :q] for x in xs]
     vals, grads, info = _batch(env, xs, zs, Ps, th, shared=True, noise=noise)
     assert np.all(info == 0)
     cov = orc.noisy_maternp_covariance if noise else orc.maternp_covariance
@@ -169,7 +170,7 @@ def test_batch_driver_failure_is_per_problem(env, golden):
         v, gr, _ = _single(env, xs[b], zs[b], None, thetas[b])
         assert abs(vals[b] - v) < 1e-8 * abs(v) and rel_err(grads[b], gr) < 1e-6      # (ill-conditioned at these length scales)
     torch, gnp, _lib, lib = env
-    assert lib.gpmp_batch_ws_elems(2049, 3, 0, 4, 1) == 0 and lib.gpmp_batch_ws_elems(512, 3, 4, 4, 1) == 0
+    assert lib.gpmp_batch_ws_elems(2049, 3, 0, 4, 1) == 0 and lib.gpmp_batch_ws_elems(512, 3, 8, 4, 1) == 0 and lib.gpmp_batch_ws_elems(512, 3, 7, 4, 1) > 0
 
 
 def test_batch_criterion_fast_path_equals_one_at_a_time(env, golden):
