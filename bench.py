@@ -217,6 +217,9 @@ def cpu_baseline(n, m, d, threads, m_sample=2048, n_sample=8192):
                       f"measured step: {step:.0f} s per predict+NLL step ASSEMBLED from these; CPU work done {sum(t.values()):.0f} s; BLAS threads={threads}. "
                       f"One full-size run of the same step (tools/cpu_fullsize_step.py, 64 threads): 209.7 s",
             "cpu_trsm_tflops": trsm_tflops,
+            # the ONE full-size CPU run of this step (another box of the pool, 64 BLAS threads): what the model above should be read against
+            "full_size_run": {"s_per_step": 209.7, "points_per_s": 238.4, "threads": 64, "log": "profiles/r3/cpu_fullsize_step.log",
+                              "tool": "tools/cpu_fullsize_step.py"} if (n, m, d) == (32768, 50000, 8) else None,
             "host_potrf": {"n": n, "s": t["cholesky"], "tflops": n ** 3 / 3.0 / t["cholesky"] / 1e12},
             "measured_s": {k_: round(v_, 3) for k_, v_ in t.items()},
             "extrapolated_s": {k_: round(v_, 2) for k_, v_ in ext.items()}}
