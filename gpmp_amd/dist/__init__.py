@@ -17,5 +17,6 @@ from .grid import ProcessGrid
 from .cholesky import BlockCyclicCholesky, HipLocalOps
 from .predict import sharded_predict, shard_bounds
 from .fit import distributed_criterion, fit_covparam
+from .model import DistributedModel
 
-__all__ = ["ProcessGrid", "BlockCyclicCholesky", "HipLocalOps", "sharded_predict", "shard_bounds", "distributed_criterion", "fit_covparam"]
+__all__ = ["ProcessGrid", "BlockCyclicCholesky", "HipLocalOps", "sharded_predict", "shard_bounds", "distributed_criterion", "fit_covparam", "DistributedModel"]

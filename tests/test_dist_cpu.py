@@ -530,3 +530,57 @@ def test_distributed_parameter_fit_follows_the_single_process_optimiser(tmp_path
     assert ref.fun < fun(th0)[0] - 1.0                                   # the fit really moved
     assert abs(got[4] - ref.fun) < 1e-6 * abs(ref.fun)
     assert np.max(np.abs(got[:4] - ref.x)) < 1e-3
+
+
+def _model_worker(rank, world, port, pr, pc, meantype, out):
+    _init(rank, world, port)
+    try:
+        from gpmp_amd.dist import DistributedModel, ProcessGrid
+        from tests.cpu_local_ops import CpuLocalOps
+
+        n, m = 420, 57
+        x, z = make_xz(n, 3, 7)
+        xt, _ = make_xz(m, 3, 8)
+        th = theta_aniso(3, scale=0.4)
+        mean = {"zero": None, "parameterized": lambda a, p: (p[0] + p[1] * a[:, 0]).reshape(-1, 1),
+                "linear_predictor": lambda a, p: np.hstack((np.ones((len(a), 1)), a))}[meantype]
+        mp_ = np.array([0.3, -0.7]) if meantype == "parameterized" else None
+        model = DistributedModel(ProcessGrid(pr, pc), mean, _cov_full, mp_, th, meantype, nb=128, ops=CpuLocalOps())
+        zpm, zpv = model.predict(x, z, xt)
+        zloo, s2, eloo = model.loo(x, z)
+        crit = {"zero": lambda: model.negative_log_likelihood_zero_mean(th, x, z),
+                "parameterized": lambda: model.negative_log_likelihood(mp_, th, x, z),
+                "linear_predictor": lambda: model.negative_log_restricted_likelihood(th, x, z)}[meantype]()
+        if rank == world - 1:                          # every rank holds the full results: take them from the LAST one
+            np.save(out, np.concatenate((zpm, zpv, zloo, s2, eloo, [crit])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pr,pc,meantype", [(2, 2, "zero"), (1, 2, "parameterized"), (2, 2, "linear_predictor")])
+def test_distributed_model_surface_matches_the_oracle_model(tmp_path, pr, pc, meantype):
+    """DistributedModel (gpmp/core/model.py's predict / loo / likelihood surface on the block-cyclic factor) against the oracle's
+    Model for the three mean types: same calls on every rank, full-length results on every rank"""
+    world = pr * pc
+    out = str(tmp_path / "m.npy")
+    mp.spawn(_model_worker, args=(world, _free_port(), pr, pc, meantype, out), nprocs=world, join=True)
+    got = np.load(out)
+    n, m = 420, 57
+    x, z = make_xz(n, 3, 7)
+    xt, _ = make_xz(m, 3, 8)
+    th = theta_aniso(3, scale=0.4)
+    mean = {"zero": None, "parameterized": lambda a, p: (p[0] + p[1] * a[:, 0]).reshape(-1, 1),
+            "linear_predictor": lambda a, p: np.hstack((np.ones((len(a), 1)), a))}[meantype]
+    mp_ = np.array([0.3, -0.7]) if meantype == "parameterized" else None
+    om = orc.OracleModel(mean, _cov_full, mp_, th, meantype)
+    rm, rv = orc.predict(om, x, z, xt)
+    rz, rs, re_ = orc.loo(om, x, z)
+    rc = {"zero": lambda: orc.negative_log_likelihood_zero_mean(om, th, x, z), "parameterized": lambda: orc.negative_log_likelihood(om, mp_, th, x, z),
+          "linear_predictor": lambda: orc.negative_log_restricted_likelihood(om, th, x, z)}[meantype]()
+    zs = np.max(np.abs(z))
+    o = 0
+    for ref, tol in ((rm, 1e-8 * zs), (rv, 1e-8), (rz, 1e-7 * zs), (rs, 1e-7 * np.max(rs)), (re_, 1e-7 * zs)):
+        seg = got[o: o + len(ref)]
+        o += len(ref)
+        assert np.max(np.abs(seg - ref)) < tol
+    assert abs(got[-1] - float(rc)) < 1e-9 * abs(float(rc))

@@ -476,3 +476,59 @@ def test_step_abi_local_kernels_on_any_grid_single_process(pr, pc, n, nb):
                 for lj, J in enumerate(cb):
                     if J <= k:
                         assert np.array_equal(got[:, lj * nb: lj * nb + bs(J)], want[:, lj * nb: lj * nb + bs(J)])
+
+
+def _model_worker(rank, world, port, pr, pc, meantype, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gpmp_amd.dist import DistributedModel, ProcessGrid
+        from gpmp_amd.kernel import MaternCovariance
+
+        n, m = 1800, 333
+        x, z = make_xz(n, 4, 11)
+        xt, _ = make_xz(m, 4, 12)
+        th = theta_aniso(4, scale=0.5)
+        mean = None if meantype == "zero" else (lambda a, p: np.hstack((np.ones((len(a), 1)), a)))
+        model = DistributedModel(ProcessGrid(pr, pc), mean, MaternCovariance(2), None, th, meantype, nb=256)
+        zpm, zpv = model.predict(x, z, xt)
+        zloo, s2, eloo = model.loo(x, z)
+        crit = model.negative_log_likelihood_zero_mean(th, x, z) if meantype == "zero" else model.negative_log_restricted_likelihood(th, x, z)
+        if rank == world - 1:
+            np.save(out, np.concatenate((zpm, zpv, zloo, s2, eloo, [crit])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pr,pc,meantype", [(2, 2, "linear_predictor"), (1, 2, "zero")])
+def test_distributed_model_surface_hip(tmp_path, pr, pc, meantype):
+    """DistributedModel.predict / loo / criterion with the real kernels (ranks share the test GPU over gloo) against the oracle's Model"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+
+    world = pr * pc
+    out = str(tmp_path / "m.npy")
+    mp.spawn(_model_worker, args=(world, _free_port(), pr, pc, meantype, out), nprocs=world, join=True)
+    got = np.load(out)
+    n, m = 1800, 333
+    x, z = make_xz(n, 4, 11)
+    xt, _ = make_xz(m, 4, 12)
+    th = theta_aniso(4, scale=0.5)
+    mean = None if meantype == "zero" else (lambda a, p: np.hstack((np.ones((len(a), 1)), a)))
+    om = orc.OracleModel(mean, lambda a, b, t, pairwise=False: orc.maternp_covariance(a, b, 2, t, pairwise), None, th, meantype)
+    rm, rv = orc.predict(om, x, z, xt)
+    rz, rs, re_ = orc.loo(om, x, z)
+    rc = float(orc.negative_log_likelihood_zero_mean(om, th, x, z)) if meantype == "zero" else float(orc.negative_log_restricted_likelihood(om, th, x, z))
+    ev = np.linalg.eigvalsh(orc.maternp_covariance(x, None, 2, th))
+    cs = max(1.0, float(ev[-1] / ev[0]) / 1e6)
+    zs = np.max(np.abs(z))
+    o = 0
+    for ref, tol in ((rm, 1e-9 * cs * zs), (rv, 1e-9 * cs), (rz, 1e-8 * cs * zs), (rs, 1e-8 * cs * np.max(rs)), (re_, 1e-8 * cs * zs)):
+        seg = got[o: o + len(ref)]
+        o += len(ref)
+        assert np.max(np.abs(seg - ref)) < tol
+    assert abs(got[-1] - rc) < 1e-11 * cs * abs(rc)
