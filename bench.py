@@ -482,7 +482,10 @@ def finish_with_dist_extra(line, world):
 
 def launcher_main(args, argv):
     """`python bench.py --gpus N` (N > 1, no RANK in the environment).  Makes no GPU call."""
-    assert "torch" not in sys.modules, "the launcher must not import torch (a GPU-initialised parent may not start GPU children safely)"
+    # the launcher itself never imports torch; if the interpreter came with it preloaded, what matters is that no GPU call was made
+    if "torch" in sys.modules and sys.modules["torch"].cuda.is_initialized():
+        sys.stderr.write("[bench] the launcher process has an initialised GPU context: refusing to start GPU workers from it\n")
+        return EXIT_ERROR
     got = spawn_ranks(args.gpus, ["--role", "headline"] + argv, float(os.environ.get("GPMP_BENCH_HEADLINE_TIMEOUT", "1500")))
     line = _last_json_line(got["stdout0"])
     if got["status"] != "ok" or line is None:
