@@ -592,6 +592,7 @@ int trtri_doubling(const double* L, int n, long ldl, const double* dinv, double*
   const long sl = pb != nullptr ? pb->stride_a : 0;
   int rc = launch_diag_blocks(T, n, ldt, dinv, st, nprob, stride_t, pb != nullptr ? pb->stride_dinv : 0);
   if (rc) return rc;
+  const int trtri_nn = env_int("GPMP_TRTRI_NN", 1);          // (read at every call: tests and A/Bs compare both forms)
   for (long s = NB; s < n; s *= 2) {
     const int npairs = (int)(n / (2 * s));                  // pairs with two full halves
     const long tail0 = (long)npairs * 2 * s;                // a ragged pair starts here if tail0 + s < n
@@ -605,6 +606,25 @@ int trtri_doubling(const double* L, int n, long ldl, const double* dinv, double*
       double* Wt = T + o * ldt + (o + s);                    // s x len2, W^T = T11^T L21^T
       double* T21 = T + (o + s) * ldt + o;
       const double* T22 = T + (o + s) * ldt + (o + s);
+      if (part == 0 && trtri_nn) {
+        // full pairs (len2 == s): W = L21 T11 kept UNtransposed in the T12 block, so that both products are of the NN kind --
+        // the LDS-direct kernel's best operand layout (k-contiguous left operand, n-contiguous right operand: 91-92 % of peak
+        // at K >= 2048 against 82 % for the transposed-left kind the W^T form needs for its first product)
+        double* W = Wt;
+        GemmOpts g1;
+        g1.kstart_col = 1;                                   // T11(l, j) = 0 for l < j
+        g1.batch = batch; g1.stride_a = 2 * s * (ldl + 1); g1.stride_b = 2 * s * (ldt + 1); g1.stride_c = 2 * s * (ldt + 1);
+        g1.batch2 = nprob; g1.stride2_a = sl; g1.stride2_b = stride_t; g1.stride2_c = stride_t;
+        rc = launch_gemm(true, false, len2, (int)s, (int)s, 1.0, L21, ldl, T11, ldt, 0.0, W, ldt, g1, st);
+        if (rc) return rc;
+        GemmOpts g2;
+        g2.kend_row = 1;                                     // T22(i, l) = 0 for l > i
+        g2.batch = batch; g2.stride_a = g2.stride_b = g2.stride_c = 2 * s * (ldt + 1);
+        g2.batch2 = nprob; g2.stride2_a = g2.stride2_b = g2.stride2_c = stride_t;
+        rc = launch_gemm(true, false, len2, (int)s, len2, -1.0, T22, ldt, W, ldt, 0.0, T21, ldt, g2, st);
+        if (rc) return rc;
+        continue;
+      }
       GemmOpts g1;
       g1.kstart_row = 1;                                     // (T11^T)(i, l) = T11(l, i) = 0 for l < i
       g1.batch = batch; g1.stride_a = 2 * s * (ldt + 1); g1.stride_b = 2 * s * (ldl + 1); g1.stride_c = 2 * s * (ldt + 1);

@@ -36,6 +36,8 @@ SOLVE_SETTINGS = [
     {"GPMP_TRSM_LEAF_MIN_STRIPS": "0"},
     {"GPMP_TRSM_LEAF_MIN_STRIPS": "1000000"},
     {"GPMP_TRSM_FUSED_LEAF": "1", "GPMP_TRSM_LEAF_NARROW_BELOW": "0"},
+    {"GPMP_POTRF_ALONG_RIGHT": "0"},                  # (round 3) left-looking updates in the panel-by-panel solve
+    {"GPMP_POTRF_ALONG_RIGHT": "0", "GPMP_POTRF_ALONG_ROWS": "512"},
 ]
 
 
@@ -86,3 +88,25 @@ def test_factor_and_solve_under_every_schedule_switch(problem, setting, monkeypa
         assert rel_err(L, Lref) < 1e-10, (n, setting)
         ref = sla.solve_triangular(Lref, B, lower=True)
         assert rel_err(gnp.to_np(V), ref) < 1e-9, (n, setting)
+
+
+@pytest.mark.parametrize("n", [2500, 4096, 5003])
+def test_inverse_factor_both_forms(problem, n, monkeypatch):
+    """GPMP_TRTRI_NN (round 3): W = L21 T11 kept untransposed, both products of the NN kind (default) against the W^T form --
+    the same k order in every accumulation, so the two inverse factors are IDENTICAL, and both are the LAPACK inverse"""
+    import torch
+    gnp, _ = problem
+    from oracle import gp_oracle as orc
+
+    rng = np.random.default_rng(n)
+    x = rng.random((n, 4))
+    K = orc.maternp_covariance(x, None, 2, np.array([0.0, 1.2, 1.0, 0.8, 1.1])) + 1e-6 * np.eye(n)
+    F = gnp.cholesky_factor(gnp.asarray(K))
+    monkeypatch.setenv("GPMP_TRTRI_NN", "1")
+    T1 = F.inverse_factor().clone()
+    monkeypatch.setenv("GPMP_TRTRI_NN", "0")
+    T0 = F.inverse_factor().clone()
+    assert torch.equal(T0, T1)
+    L = np.tril(gnp.to_np(F.L))
+    assert rel_err(gnp.to_np(T1) @ L, np.eye(n)) < 1e-9
+
