@@ -64,8 +64,7 @@ def _worker(rank, world, port, pr, pc, n, nb, out, transport, lookahead, backend
 
 
 @pytest.mark.parametrize("pr,pc,n,nb,transport,lookahead", [(1, 1, 1500, 512, "bcast", True), (1, 2, 1500, 256, "bcast", True),
-                                                             (2, 2, 2000, 256, "p2p", True), (2, 2, 2000, 256, "bcast", False),
-                                                             (1, 1, 4096, 512, "bcast", True)])
+                                                             (2, 2, 2000, 256, "p2p", True), (2, 2, 2000, 256, "bcast", False)])
 def test_block_cyclic_cholesky_hip(tmp_path, pr, pc, n, nb, transport, lookahead):
     _run_and_check(tmp_path, pr, pc, n, nb, transport, lookahead, "gloo")
 
@@ -84,8 +83,7 @@ def test_block_cyclic_cholesky_rccl(tmp_path, pr, pc, n, nb, transport, lookahea
     _run_and_check(tmp_path, pr, pc, n, nb, transport, lookahead, "nccl")
 
 
-@pytest.mark.parametrize("pr,pc,n,nb,lookahead", [(2, 2, 2000, 256, True), (1, 2, 1500, 256, True), (2, 1, 1500, 256, False), (1, 1, 2304, 1024, True),
-                                                   (2, 2, 3100, 256, True)])
+@pytest.mark.parametrize("pr,pc,n,nb,lookahead", [(1, 2, 1500, 256, True), (2, 1, 1500, 256, False), (2, 2, 3100, 256, True)])
 def test_step_abi_equals_the_tensor_level_schedule(tmp_path, pr, pc, n, nb, lookahead):
     """gpmp_dist_* (diag_factor / panel_solve / exchange_pack + unpack / trailing_update: what a C++ RCCL host calls) against
     the tensor-level code of gpmp_amd/dist for the same schedule: the same kernels on the same operands in the same order,
@@ -189,7 +187,7 @@ def _predict_worker(rank, world, port, pr, pc, n, m, nb, out, transport, overlap
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("pr,pc,n,m,nb,transport,overlap", [(1, 1, 1500, 700, 512, "bcast", True), (2, 2, 2000, 901, 256, "bcast", True),
+@pytest.mark.parametrize("pr,pc,n,m,nb,transport,overlap", [(1, 1, 1500, 700, 512, "bcast", True),
                                                             (1, 2, 1500, 333, 256, "p2p", True), (2, 2, 2000, 901, 256, "p2p", False),
                                                             (2, 2, 3100, 1201, 256, "bcast", True), (2, 1, 2304, 513, 256, "bcast", True)])
 def test_block_cyclic_predict_hip(tmp_path, pr, pc, n, m, nb, transport, overlap):
@@ -407,8 +405,8 @@ def test_block_cyclic_universal_kriging_hip(tmp_path, pr, pc, n, m, nb, q):
     assert np.max(np.abs(got[1] - rv)) < 1e-9 * cs
 
 
-@pytest.mark.parametrize("pr,pc", [(2, 3), (3, 2), (2, 4), (4, 2), (3, 3), (1, 4), (4, 1)])
-@pytest.mark.parametrize("n,nb", [(1900, 128), (2304, 256)])
+@pytest.mark.parametrize("pr,pc,n,nb", [(2, 3, 1900, 128), (3, 2, 1900, 128), (2, 4, 1900, 128), (4, 2, 1900, 128), (3, 3, 1900, 128), (1, 4, 1900, 128),
+                                        (4, 1, 1900, 128), (2, 3, 2304, 256), (3, 3, 2304, 256)])
 def test_step_abi_local_kernels_on_any_grid_single_process(pr, pc, n, nb):
     """gpmp_dist_exchange_pack / _unpack / _trailing_update for EVERY rank coordinate of non-square grids (lcm(Pr, Pc) strides,
     ragged last blocks), in ONE process: the buffers a rank would hold after the broadcasts are cut out of a global panel
@@ -425,7 +423,7 @@ def test_step_abi_local_kernels_on_any_grid_single_process(pr, pc, n, nb):
     bs = lambda I: min(nb, n - I * nb)                 # noqa: E731
     rows_of = lambda blocks: np.concatenate([np.arange(I * nb, I * nb + bs(I)) for I in blocks]) if blocks else np.zeros(0, dtype=np.int64)   # noqa: E731
     A = rng.standard_normal((n, n))
-    for k in sorted({0, 1, nblk // 2, nblk - 2}):
+    for k in sorted({0, nblk // 2, nblk - 2}):
         bk = bs(k)
         Lk = rng.standard_normal((n, bk))             # the (already solved) block column k: rows = global rows
         for r in range(pr):
