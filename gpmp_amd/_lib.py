@@ -46,6 +46,10 @@ SIGNATURES = {
     "gpmp_dgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_double, _P, c_long, _P, c_long, c_double, _P, c_long, c_int, _P]),
     "gpmp_coldots": (c_int, [_P, c_int, c_int, c_long, _P, c_int, c_long, _P, c_long, _P, _P]),
     "gpmp_coldots_ws_rows": (c_int, [c_int]),
+    "gpmp_device_release": (c_int, []),
+    "gpmp_device_state_count": (c_int, []),
+    "gpmp_debug_device_table_selftest": (c_int, [c_int, c_int, c_int]),
+    "gpmp_coldots_pair": (c_int, [_P, c_long, _P, c_long, c_int, c_int, _P, _P, _P]),
     "gpmp_logdet_chol": (c_int, [_P, c_int, c_long, _P, _P]),
     "gpmp_matern_grad_trace": (c_int, [_P, c_long, _P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, c_long, _P, _P, _P]),
     "gpmp_matern_grad_trace_cross": (c_int, [_P, c_long, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, c_long, _P, _P, _P]),

@@ -22,6 +22,7 @@ from .. import num as gnp
 from .utils import mean_values as _mean_values
 from ..config import get_config
 from .linalg import covariance_factor
+from ..num.householder import HouseholderQR as _Reflectors
 
 
 def _chunk_cols(n, m):
@@ -90,60 +91,6 @@ class _Predictor:
         return mean, reduction, lam, mu
 
 
-class _Reflectors:
-    """Householder QR of the n x q mean design, P = Q [R; 0] with Q = H_0 ... H_{q-1}, H_k = I - tau_k v_k v_k^T.
-    Q (n x n in the reference: gpmp/core/kriging.py:229, linalg.py:68-70) is never formed: its action on an n x m
-    matrix is q rank-one updates on the library GEMM, and Q^T K Q is q symmetric rank-two updates."""
-
-    def __init__(self, P):
-        A = gnp.asarray(P).clone()
-        n, q = A.shape
-        if q >= n:
-            raise numpy.linalg.LinAlgError("mean design has at least as many columns as observations")
-        self.n, self.q, self.v, self.tau = n, q, [], []
-        scale = [float(torch.linalg.vector_norm(A[:, k])) for k in range(q)]
-        for k in range(q):
-            x = A[k:, k]
-            nx = float(torch.linalg.vector_norm(x))
-            if not nx > n * gnp.eps * scale[k]:
-                raise numpy.linalg.LinAlgError("singular mean design: P is rank deficient")
-            alpha = -nx if float(x[0]) >= 0.0 else nx
-            v = gnp.zeros((n,))
-            v[k:] = x
-            v[k] -= alpha
-            tau = 2.0 / float(torch.sum(v * v))
-            A[:, k:] -= tau * v.reshape(-1, 1) * torch.sum(v.reshape(-1, 1) * A[:, k:], dim=0).reshape(1, -1)   # O(n q)
-            self.v.append(v)
-            self.tau.append(tau)
-        self.R = torch.triu(A[:q, :q])
-
-    def _rank_update(self, B, cols_a, cols_b):
-        """B -= [a_1 .. a_r] [b_1 .. b_r]^T on the library GEMM (B n x m in place; a_j: n, b_j: m)."""
-        lib = gnp._lib.load()
-        A_ = gnp.as_matrix(torch.stack(cols_a, dim=1), copy=True)
-        B_ = gnp.as_matrix(torch.stack(cols_b, dim=1), copy=True)
-        gnp._lib.check(lib.gpmp_dgemm(0, 1, B.shape[0], B.shape[1], len(cols_a), -1.0, gnp._ptr(A_), gnp._ld(A_), gnp._ptr(B_),
-                                      gnp._ld(B_), 1.0, gnp._ptr(B), gnp._ld(B), 0, gnp._stream()), "gpmp_dgemm")
-
-    def apply(self, B, transpose):
-        """B <- Q^T B (transpose) or Q B, in place; B is an n x m matrix."""
-        order = range(self.q) if transpose else range(self.q - 1, -1, -1)
-        for k in order:
-            c = gnp.coldots(B, self.v[k].reshape(-1, 1))[0]          # v^T B
-            self._rank_update(B, [self.tau[k] * self.v[k]], [c])
-        return B
-
-    def congruence(self, K):
-        """K <- Q^T K Q in place (K symmetric, full storage)."""
-        for k in range(self.q):
-            v, tau = self.v[k], self.tau[k]
-            w = gnp.matmul(K, v)
-            s = float(torch.sum(v * w))
-            u = tau * w - (0.5 * tau * tau * s) * v
-            self._rank_update(K, [v, u], [u, v])
-        return K
-
-
 class _ContrastPredictor:
     """Universal kriging in the contrast space Null(P^T), for covariances that are only conditionally positive
     definite.  With lambda = Q [beta; a] (first q coordinates fixed by the unbiasedness constraint R^T beta = Pt^T):
@@ -180,7 +127,7 @@ class _ContrastPredictor:
             # reads the upper triangle of Rq.T only, i.e. diag(Rq) -- exact for q = 1, not beyond.  Reproduced as is.
             beta = Pt.T / torch.diagonal(self.hq.R).reshape(-1, 1)
         else:
-            beta = torch.linalg.solve_triangular(self.hq.R.T.contiguous(), Pt.T.contiguous(), upper=False)   # q x m
+            beta = gnp.solve_triangular(self.hq.R.T.contiguous(), Pt.T.contiguous(), lower=True)   # q x m
         C1 = Kit[:q].clone()
         rhs = gnp.as_matrix(Kit[q:], copy=True)
         if not self.ref:
@@ -213,7 +160,7 @@ def _run(model, xi, zi_centered, xt, use_mean, want_lambda, contrast=None):
     else:
         try:
             pred = _Predictor(model, xi, zi_centered, use_mean, xt_first=xt[: max(mc, 1)] if m > 0 else None)
-        except (numpy.linalg.LinAlgError, torch.linalg.LinAlgError):
+        except numpy.linalg.LinAlgError:
             # K has no Cholesky factor / P^T K^-1 P is singular: with a mean design the contrast space may still be
             # positive definite (conditionally positive definite kernels); without one the reference raises as well
             if not use_mean:

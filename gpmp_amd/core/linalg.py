@@ -107,10 +107,10 @@ def norm_k_sqrd(model, xi, zi, covparam):
 # ---- explicit contrast matrices (API parity; the criteria above never form them) --------------------------------
 def compute_contrast_matrix(P):
     """gpmp/core/linalg.py:49-70: W = Q[:, q:] of the complete QR of P (n x (n - q), orthonormal, W^T P = 0)."""
-    P = gnp.asarray(P)
-    q = P.shape[1]
-    Q, _ = gnp.qr(P, mode="complete")
-    return Q[:, q:]
+    from ..num.householder import HouseholderQR
+
+    h = HouseholderQR(P)                  # Q is never formed: W = Q [0; I] is q rank-one updates of n x (n - q) columns
+    return h.columns(h.q, h.n)
 
 
 def compute_contrast_covariance(W, K):
@@ -120,7 +120,7 @@ def compute_contrast_covariance(W, K):
 
 def qr_nullspace(P):
     """gpmp/core/linalg.py:91-110: (Q1, W, R1) with P = Q1 R1 and W spanning Null(P^T)."""
-    P = gnp.asarray(P)
-    q = P.shape[1]
-    Q, R = gnp.qr(P, mode="complete")
-    return Q[:, :q], Q[:, q:], R[:q, :q]
+    from ..num.householder import HouseholderQR
+
+    h = HouseholderQR(P)
+    return h.columns(0, h.q), h.columns(h.q, h.n), h.R

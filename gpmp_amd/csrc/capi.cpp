@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <vector>
 #include <cstdlib>
+#include <mutex>
 
 namespace gpmp {
 namespace {
@@ -29,6 +30,7 @@ struct Rec { hipEvent_t a, b; int kind; double work; };
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t g_open[PK_COUNT];
+std::mutex g_prof_mu;      // the records are one table per process: profiling is a diagnostic of ONE device at a time
 hipEvent_t get_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e; (void)hipEventCreate(&e); return e;
@@ -36,12 +38,14 @@ hipEvent_t get_event() {
 }  // namespace
 void prof_start(int kind, hipStream_t st) {
   if (!((g_prof_mask >> kind) & 1u)) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   hipEvent_t e = get_event();
   (void)hipEventRecord(e, st);
   g_open[kind] = e;
 }
 void prof_stop(int kind, hipStream_t st, double work) {
   if (!((g_prof_mask >> kind) & 1u)) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   hipEvent_t e = get_event();
   (void)hipEventRecord(e, st);
   g_recs.push_back({g_open[kind], e, kind, work});
@@ -49,6 +53,7 @@ void prof_stop(int kind, hipStream_t st, double work) {
 }  // namespace gpmp
 
 extern "C" int gpmp_profile_begin_kinds(unsigned kinds) {
+  std::lock_guard<std::mutex> lk(gpmp::g_prof_mu);
   for (auto& r : gpmp::g_recs) { gpmp::g_pool.push_back(r.a); gpmp::g_pool.push_back(r.b); }
   gpmp::g_recs.clear();
   gpmp::g_prof_mask = kinds;
@@ -60,6 +65,7 @@ extern "C" int gpmp_profile_begin(void) { return gpmp_profile_begin_kinds(0xFFFF
 extern "C" int gpmp_profile_end(double* table_host) {
   gpmp::g_prof_on = false;
   if (table_host == nullptr) return -1;
+  std::lock_guard<std::mutex> lk(gpmp::g_prof_mu);
   for (int i = 0; i < 3 * gpmp::PK_COUNT; ++i) table_host[i] = 0.0;
   FILE* dump = nullptr;
   if (const char* path = getenv("GPMP_PROF_DUMP")) dump = fopen(path, "w");

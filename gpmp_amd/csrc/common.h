@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include "../../include/gpmp_hip.h"
 
 namespace gpmp {
@@ -29,6 +30,21 @@ int hip_fail(hipError_t e, const char* what);
   } while (0)
 
 inline hipStream_t as_stream(gpmp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Per-device one-time setup (kernel attributes belong to the device that was current when they were set): one bit per device
+// ordinal in a function-local mask.  `done` is set by the caller AFTER the setup succeeded; two host threads racing on the same
+// device both run the (idempotent) setup.  A thread-per-GPU host drives every device of the node through one copy of the library.
+struct DeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  // > 0: this device still needs its setup (the value is the bit to pass to done()); 0: already done; < 0: HIP error
+  long long need() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 62) return -1;
+    const unsigned long long bit = 1ull << dev;
+    return (mask.load(std::memory_order_acquire) & bit) ? 0 : (long long)bit;
+  }
+  void done(long long bit) { mask.fetch_or((unsigned long long)bit, std::memory_order_release); }
+};
 
 // ---- opt-in per-kernel timing with HIP events on the launch stream (capi.cpp) -------------------
 // Kinds index the table returned by gpmp_profile_end().

@@ -37,7 +37,7 @@ struct Layout {
 
 int make_layout(Layout& L, int n, int nb, int pr, int pc, int r, int c) {
   GPMP_ARG(n > 0, 1, "n <= 0");
-  GPMP_ARG(nb > 0 && nb % NB == 0, 2, "block size must be a positive multiple of 128");
+  GPMP_ARG(nb > 0 && nb % NB == 0 && nb <= 2 * OUTER_BLOCKS * NB, 2, "block size must be a multiple of 128 in (0, 1024]");
   GPMP_ARG(pr > 0 && pc > 0, 3, "empty process grid");
   GPMP_ARG(r >= 0 && r < pr && c >= 0 && c < pc, 5, "rank coordinates outside the grid");
   L = Layout{n, nb, pr, pc, r, c, (n + nb - 1) / nb};
@@ -220,7 +220,8 @@ extern "C" int gpmp_dist_trailing_update(double* A, long lda, int n, int nb, int
   const int bk = L.bs(k);
   GPMP_ARG(ldp >= bk && ldc >= bk, 11, "operand leading dimension below the block width");
   const int G = 4;                                                   // block rows per GEMM of the staircase
-  const int first = rows_after >= 0 ? L.first_row_after(rows_after) : i0;
+  int first = rows_after >= 0 ? L.first_row_after(rows_after) : i0;
+  if (first < i0) first = i0;                                        // rows_after < k: the panel has no rows above block k
   for (int lg = first; lg < nrb; lg += G) {
     const int le = lg + G < nrb ? lg + G : nrb;
     const int I_last = r + (le - 1) * pr;

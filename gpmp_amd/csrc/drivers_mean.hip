@@ -259,11 +259,12 @@ int factor_and_meanspace(const MeanLayout& l, const double* x, const double* z, 
     rc = gpmp_coldots(P, n, q, ldp, P, q, ldp, ws + l.PtP, l.ldq, ws + l.cd, stream);
     if (rc) return rc;
     const size_t ms_bytes = sizeof(double) * (2 * QLD * (QLD + 1) + 3 * QLD);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (const long long dev_bit = attr_once.need()) {
+    if (dev_bit < 0) { set_error("hipGetDevice failed or device ordinal above 62"); return -1; }
       GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(meanspace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)ms_bytes));
-      attr_done = true;
+      attr_once.done(dev_bit);
     }
     hipLaunchKernelGGL(meanspace_kernel, dim3(1), dim3(256), ms_bytes, st, ws + l.Gm, l.ldq, ws + l.PtP, l.ldq, q, n, ws + l.small,
                        ws + l.Sinv, l.ldq, info_dev);

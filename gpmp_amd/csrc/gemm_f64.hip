@@ -1019,15 +1019,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(10, 10
 
 template <bool AKC, bool BKC, bool CACC>
 int launch_t(const GemmParams& p, hipStream_t st) {
-  static bool attr_done = false;
+  static DeviceOnce attr_once;
   const size_t lds = sizeof(double) * 4 * TILE;        // v1: 73,728 B
   const size_t lds2 = sizeof(double) * 4 * V2_TILE;    // v2: 65,536 B
-  if (!attr_done) {
+  if (const long long dev_bit = attr_once.need()) {
+    if (dev_bit < 0) { set_error("hipGetDevice failed or device ordinal above 62"); return -1; }
     GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<AKC, BKC, CACC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_v2<AKC, BKC, CACC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    attr_done = true;
+    attr_once.done(dev_bit);
   }
   static int use_v2 = -1;
   if (use_v2 < 0) { const char* e = getenv("GPMP_GEMM_V2"); use_v2 = e ? atoi(e) : 1; }
@@ -1089,9 +1090,10 @@ int launch_trsm_leaf_forward(const double* L, long ldl, const double* dinv_leaf,
     hipLaunchKernelGGL(build_leaf_g_kernel, dim3(nb, nb), dim3(256), 0, st, g);
     GPMP_HIP_TRY(hipGetLastError());
   }
-  static bool attr_done = false;
+  static DeviceOnce attr_once;
   const size_t lds2 = sizeof(double) * 4 * V2_TILE;
-  if (!attr_done) {
+  if (const long long dev_bit = attr_once.need()) {
+    if (dev_bit < 0) { set_error("hipGetDevice failed or device ordinal above 62"); return -1; }
     GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_leaf_kernel<128>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_leaf_kernel<64>),
@@ -1100,7 +1102,7 @@ int launch_trsm_leaf_forward(const double* L, long ldl, const double* dinv_leaf,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_leaf_kernel<16>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    attr_done = true;
+    attr_once.done(dev_bit);
   }
   // A leaf has one workgroup per strip, each walking the nb blocks one after the other (MFMA-bound on its compute unit:
   // 68 us for a 64-column strip of a 512-row leaf): the strips are narrowed until there are about GPMP_TRSM_LEAF_MIN_STRIPS of

@@ -742,11 +742,12 @@ int grad_tier(int d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ?
 template <int DT>
 int launch_grad(GradParams& gp, int nblocks, hipStream_t st) {
   const size_t lds = sizeof(double) * (2 * DT * GT + 2 * (size_t)gp.r * GT);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_once;
+  if (const long long dev_bit = attr_once.need()) {
+    if (dev_bit < 0) { set_error("hipGetDevice failed or device ordinal above 62"); return -1; }
     GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(grad_trace_kernel<DT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_done = true;
+    attr_once.done(dev_bit);
   }
   hipLaunchKernelGGL((grad_trace_kernel<DT>), dim3(nblocks, gp.nprob > 1 ? gp.nprob : 1), dim3(256), lds, st, gp);
   GPMP_HIP_TRY(hipGetLastError());

@@ -12,6 +12,10 @@
 #include <vector>
 #include <cstdlib>
 #include <mutex>
+#include <map>
+#include <memory>
+#include <thread>
+#include <atomic>
 
 namespace gpmp {
 namespace {
@@ -214,13 +218,24 @@ struct LookAhead {
     return pool[used++];
   }
 };
-LookAhead g_la;
-// The helper stream, the event pool and the solve stream belong to the device that was current when they were created,
-// and the pool is reset at every factorisation: ONE device per process and one look-ahead factorisation being enqueued at
-// a time.  Both are enforced here rather than assumed: a second host thread waits at the mutex (enqueueing takes
-// microseconds), a call on another device is refused with an error.
-std::mutex g_la_mu;
-int g_la_device = -1;
+// The helper streams, the event pool and the solve stream belong to the device that was current when they were created, and
+// the pool is reset at every factorisation: ONE look-ahead factorisation being enqueued at a time PER DEVICE.  State is kept
+// per device ordinal (round 4; rounds 1-3 kept one set and refused a second device), so a host that drives several GPUs from one
+// process -- one thread per GPU, each with its device current -- uses one copy of the library: threads on different devices do
+// not wait for each other, a second thread on the same device waits at that device's mutex (enqueueing takes microseconds).
+struct DeviceState {
+  LookAhead la;
+  hipStream_t solve_stream = nullptr;
+  std::mutex mu;
+};
+std::mutex g_dev_table_mu;
+std::map<int, std::unique_ptr<DeviceState>> g_dev_table;
+DeviceState* device_state(int dev) {
+  std::lock_guard<std::mutex> lk(g_dev_table_mu);
+  auto it = g_dev_table.find(dev);
+  if (it == g_dev_table.end()) it = g_dev_table.emplace(dev, std::make_unique<DeviceState>()).first;
+  return it->second.get();
+}
 
 // Factor the panel of columns [p0, p1) (p0, p1 multiples of NB; rows p0 .. n): diagonal blocks in LDS,
 // panel scaling, rank-128 updates inside 512-column sub-panels and rank-512 updates between them.
@@ -294,20 +309,14 @@ struct SolveAlong {
   // the solve stream -- so only the last panel's rows are left when the factorisation ends.
   int every_panel = 0;
 };
-hipStream_t g_solve_stream = nullptr;
 
 int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hipStream_t s0, const SolveAlong* sa = nullptr) {
-  std::lock_guard<std::mutex> la_lock(g_la_mu);
-  {
-    int dev = 0;
-    GPMP_HIP_TRY(hipGetDevice(&dev));
-    if (g_la_device < 0) g_la_device = dev;
-    if (dev != g_la_device) {
-      set_error("the library's helper streams were created on device %d; this call runs on device %d (one device per process)",
-                g_la_device, dev);
-      return -1;
-    }
-  }
+  int dev = 0;
+  GPMP_HIP_TRY(hipGetDevice(&dev));
+  DeviceState* ds = device_state(dev);
+  std::lock_guard<std::mutex> la_lock(ds->mu);
+  LookAhead& g_la = ds->la;
+  hipStream_t& g_solve_stream = ds->solve_stream;
   // panel boundaries: 1024-wide panels while the trailing matrix is large (rank-1024 updates run at
   // ~89 % of the MFMA peak against ~84 % for rank-512, and the longer panel still hides behind them),
   // 512-wide afterwards (shorter latency-bound tail)
@@ -664,6 +673,75 @@ int lauum_lower_batch(const double* T, int n, long ldt, long stride_t, double* K
 }  // namespace gpmp
 
 using namespace gpmp;
+
+// ---- per-device state of the look-ahead factorisation (helper streams, event pool, solve stream) ----------------------
+namespace gpmp {
+namespace {
+int release_device_state(int dev) {
+  std::unique_ptr<DeviceState> ds;
+  {
+    std::lock_guard<std::mutex> lk(g_dev_table_mu);
+    auto it = g_dev_table.find(dev);
+    if (it == g_dev_table.end()) return 0;
+    ds = std::move(it->second);
+    g_dev_table.erase(it);
+  }
+  std::lock_guard<std::mutex> lk(ds->mu);          // an enqueue section still running on another thread finishes first
+  // (streams are synchronised before they go: their kernels may still be running)
+  for (hipStream_t st : {ds->la.helper, ds->la.side, ds->solve_stream})
+    if (st != nullptr) {
+      GPMP_HIP_TRY(hipStreamSynchronize(st));
+      GPMP_HIP_TRY(hipStreamDestroy(st));
+    }
+  for (hipEvent_t e : ds->la.pool) GPMP_HIP_TRY(hipEventDestroy(e));
+  return 0;
+}
+}  // namespace
+}  // namespace gpmp
+
+extern "C" int gpmp_device_state_count(void) {
+  std::lock_guard<std::mutex> lk(g_dev_table_mu);
+  return (int)g_dev_table.size();
+}
+
+extern "C" int gpmp_device_release(void) {
+  int dev = 0;
+  GPMP_HIP_TRY(hipGetDevice(&dev));
+  return release_device_state(dev);
+}
+
+// Host-only self-test of the device table (no HIP call: the entries it makes hold no stream): `threads` host threads look up
+// `ordinals` made-up device ordinals (1000, 1001, ...) `iters` times each, every thread must see ONE state object per ordinal,
+// then the entries are released.  0 = consistent.  Run under the host-side sanitizer build (tests/test_asan_cpu.py).
+extern "C" int gpmp_debug_device_table_selftest(int threads, int ordinals, int iters) {
+  GPMP_ARG(threads > 0 && threads <= 64, 1, "threads outside [1, 64]");
+  GPMP_ARG(ordinals > 0 && ordinals <= 64, 2, "ordinals outside [1, 64]");
+  const int before = gpmp_device_state_count();
+  std::vector<std::vector<DeviceState*>> seen(threads, std::vector<DeviceState*>(ordinals, nullptr));
+  std::atomic<int> bad{0};
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t)
+    pool.emplace_back([&, t] {
+      for (int it = 0; it < iters; ++it)
+        for (int o = 0; o < ordinals; ++o) {
+          DeviceState* ds = device_state(1000 + (o + t) % ordinals);
+          std::lock_guard<std::mutex> lk(ds->mu);           // what an enqueue section does
+          ds->la.used = 0;
+          DeviceState*& slot = seen[t][(o + t) % ordinals];
+          if (slot == nullptr) slot = ds;
+          else if (slot != ds) bad.fetch_add(1);
+        }
+    });
+  for (auto& th : pool) th.join();
+  for (int t = 1; t < threads; ++t)
+    for (int o = 0; o < ordinals; ++o)
+      if (seen[t][o] != seen[0][o]) bad.fetch_add(1);
+  if (gpmp_device_state_count() != before + ordinals) bad.fetch_add(1);
+  for (int o = 0; o < ordinals; ++o)
+    if (release_device_state(1000 + o)) bad.fetch_add(1);
+  if (gpmp_device_state_count() != before) bad.fetch_add(1);
+  return bad.load();
+}
 
 extern "C" size_t gpmp_dinv_elems(int n) {
   if (n <= 0) return 0;

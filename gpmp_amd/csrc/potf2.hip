@@ -542,11 +542,12 @@ constexpr size_t POTF2_LDS = sizeof(double) * (NPACK * 256 + NSB * 256 + NB);   
 
 int launch_factor(double* A, long lda, int jb, double* dinv, int* info_dev, int offset, hipStream_t st, int nprob, long prob_stride_a,
                   long prob_stride_dinv) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_once;
+  if (const long long dev_bit = attr_once.need()) {
+    if (dev_bit < 0) { set_error("hipGetDevice failed or device ordinal above 62"); return -1; }
     GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS));
-    attr_done = true;
+    attr_once.done(dev_bit);
   }
   {
     ProfScope ps(PK_POTF2, st, (double)nprob);
@@ -569,11 +570,12 @@ int launch_potf2_inv_batch(double* A, long lda, int jb, double* dinv, int* info_
 }
 int launch_trtri_blocks(const double* L, long ldl, int n, double* dinv, hipStream_t st) {
   if (n <= 0) return 0;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_once;
+  if (const long long dev_bit = attr_once.need()) {
+    if (dev_bit < 0) { set_error("hipGetDevice failed or device ordinal above 62"); return -1; }
     GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trtri_blocks_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS));
-    attr_done = true;
+    attr_once.done(dev_bit);
   }
   const int nblocks = (n + NB - 1) / NB;
   {

@@ -11,18 +11,23 @@ class ProcessGrid:
         self.pr, self.pc = pr, pc
         self.r, self.c = divmod(self.rank, pc)
 
+        # RCCL: the communicators' internal streams get HIGH priority -- they carry the panel chain (diagonal messages,
+        # panels, column operands) while a machine-filling GEMM of normal priority runs on the caller's stream; a
+        # collective's few workgroups should take the next free slot, not queue behind the GEMM's own waiting workgroups.
+        # Whether the option exists is decided ONCE, from the signature, before any communicator is created: every rank
+        # runs the same torch, so every rank makes the same number of `new_group` calls with the same arguments (a
+        # try / except around the collective constructor could leave the ranks with different call counts).
+        opts = None
+        if dist.get_backend(group) == "nccl" and hasattr(dist, "ProcessGroupNCCL"):
+            import inspect
+
+            if "pg_options" in inspect.signature(dist.new_group).parameters and hasattr(dist.ProcessGroupNCCL, "Options"):
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+        self.high_priority_comms = opts is not None
+
         def new_group(ranks):
-            # RCCL: the communicators' internal streams get HIGH priority -- they carry the panel chain (diagonal messages,
-            # panels, column operands) while a machine-filling GEMM of normal priority runs on the caller's stream; a
-            # collective's few workgroups should take the next free slot, not queue behind the GEMM's own waiting workgroups
-            if dist.get_backend(group) == "nccl" and hasattr(dist, "ProcessGroupNCCL"):
-                try:
-                    opts = dist.ProcessGroupNCCL.Options()
-                    opts.is_high_priority_stream = True
-                    return dist.new_group(ranks, pg_options=opts)
-                except (TypeError, RuntimeError):
-                    pass
-            return dist.new_group(ranks)
+            return dist.new_group(ranks, pg_options=opts) if opts is not None else dist.new_group(ranks)
 
         # one communicator per process row and per process column (every rank creates all of them)
         self.row_groups = [new_group([rr * pc + cc for cc in range(pc)]) for rr in range(pr)]

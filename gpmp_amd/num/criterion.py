@@ -155,14 +155,16 @@ class BatchDifferentiableSelectionCriterion:
 
     use_batched_kernel = True      # set False to force the one-batch-at-a-time route (tests compare both)
 
-    def _accumulate(self, p_arr, want_grad):
+    def _accumulate(self, p_arr, want_grad, p_call=None):
         """Sum of (batch value x batch size), points seen and -- with ``want_grad`` -- the sum of (batch gradient x batch size)
         over the batches of this evaluation, STREAMING the loader: whether the batched kernel applies is decided first (a
         declared Matern covariance: model level, no data touched) and per batch from its size on the host (<= 2048 points);
         qualifying batches are collected into pieces of at most one library call's workspace budget
         (``batch_piece_limit``) and go through gpmp_nll_grad_batch piece by piece, every other batch is evaluated on its own
-        and dropped -- at no time more than one piece of the loader is resident on the device."""
+        and dropped -- at no time more than one piece of the loader is resident on the device.  ``p_call`` is what a
+        non-analytic criterion callable receives (the caller's own object, as in the reference: torch_backend.py:664-676)."""
         an = self._analytic
+        p_call = p_arr if p_call is None or an is not None else p_call
         fn = getattr(an, "batch_values_and_gradients", None)
         can_batch = fn is not None and self.use_batched_kernel and (getattr(an, "batch_qualifies", None) is None or an.batch_qualifies())
         max_pts = getattr(an, "batch_max_points", 0) if can_batch else 0
@@ -178,16 +180,17 @@ class BatchDifferentiableSelectionCriterion:
                 value, state = an.value_and_state(p_arr, xb, zb)
                 grad += bs * numpy.asarray(an.gradient_from_state(state), dtype=numpy.float64)
             else:
-                value = self.crit(p_arr, xb, zb)
+                value = self.crit(p_call, xb, zb)
             total += float(value) * bs
             n += bs
 
         def flush():
-            nonlocal total, n, grad, pending, nmax
+            nonlocal total, n, grad, pending, nmax, can_batch
             if not pending:
                 return
             out = fn(p_arr, pending, want_grad)
-            if out is None:                      # (e.g. more mean columns than the batched kernel carries): one by one
+            if out is None:                      # (e.g. more mean columns than the batched kernel carries): one by one,
+                can_batch = False                # and for the REST of this evaluation -- the design does not change between pieces
                 for xb, zb in pending:
                     one(xb, zb)
             else:
@@ -215,7 +218,7 @@ class BatchDifferentiableSelectionCriterion:
 
     def evaluate(self, p):
         p_arr = numpy.array(numpy.asarray(p, dtype=numpy.float64), copy=True)
-        total, n, _ = self._accumulate(p_arr, False)
+        total, n, _ = self._accumulate(p_arr, False, p_call=p)
         return self._reduce(total, n)
 
     def evaluate_no_grad(self, p):
@@ -229,7 +232,7 @@ class BatchDifferentiableSelectionCriterion:
     def evaluate_pre_grad(self, p):
         p_arr = numpy.array(numpy.asarray(p, dtype=numpy.float64), copy=True)
         if self._analytic is None:
-            return self.evaluate_no_grad(p_arr)
+            return self.evaluate_no_grad(p)
         try:
             total, n, grad = self._accumulate(p_arr, True)
         except Exception as exc:

@@ -21,10 +21,13 @@
  *    (or gpmp_stream_destroy for the library's own streams) -- a caller that creates and destroys streams calls
  *    gpmp_stream_release before destroying one; otherwise the block stays allocated until the process ends (16.4 KB per
  *    stream ever used) and a later stream with the same handle value reuses it (harmless: it is zeroed before every solve).
- *  - ONE DEVICE PER PROCESS (the launch model is one process per GPU): the helper streams and events of the look-ahead
- *    factorisation are created on the device of the first call, and a call made with another current device returns -1
- *    with a message.  A host that drives several GPUs from one process starts one worker process per GPU, each loading
- *    the library.  One calling thread at a time per stream.
+ *  - DEVICES: every call works on the CURRENT device (hipSetDevice) and its pointers / stream must belong to it.  What the
+ *    library keeps on the host -- the helper streams and events of the look-ahead factorisation, the flag blocks above,
+ *    one-time kernel attributes -- is kept PER DEVICE ORDINAL (round 4; earlier versions refused a second device), so
+ *    both launch models work with one copy of the library: one process per GPU (what bench.py and gpmp_amd/dist do), or
+ *    one process with one host thread per GPU, each thread with its device current.  Threads on different devices do not
+ *    wait for each other; two threads on the same device are serialised while they enqueue a factorisation.  One calling
+ *    thread at a time per stream.  gpmp_device_release() returns what the library holds for the current device.
  *  - covparam layout (gpmp/kernel/matern.py:78-79,88-89): theta = [log sigma^2, log(1/rho_1..d)];
  *    with `noise` != 0 the layout is [log sigma^2, log sigma_noise^2, log(1/rho_1..d)]
  *    (examples/gpmp_example07_nd_regression.py:95-131).
@@ -148,6 +151,15 @@ int gpmp_solve_status(gpmp_stream_t stream, int* status_host);
  * stream.  0 when the stream holds nothing (no HIP call is made then).  Call it before destroying a stream that ran
  * single-vector solves; a later solve on the same handle simply allocates a fresh block. */
 int gpmp_stream_release(gpmp_stream_t stream);
+/* Per-device host state (helper streams / events of the look-ahead factorisation; created at a device's first large
+ * factorisation).  gpmp_device_release: synchronises and destroys what the CURRENT device holds (0 if nothing; the next
+ * factorisation on it creates fresh ones).  gpmp_device_state_count: devices that hold such state (host only, no HIP call).
+ * gpmp_debug_device_table_selftest: host-only consistency check of that table under `threads` concurrent host threads
+ * (made-up ordinals, no HIP call; 0 = consistent) -- what tests/test_asan_cpu.py runs under ASan + UBSan.
+ * No counterpart in the reference (single-threaded Python, no device code). */
+int gpmp_device_release(void);
+int gpmp_device_state_count(void);
+int gpmp_debug_device_table_selftest(int threads, int ordinals, int iters);
 
 /* B <- B L^-T for an M x k row-major B and a k x k lower-triangular L (right-side solve: the panel step
  * A21 <- A21 inv(L11)^T of a blocked / distributed Cholesky).  dinv as produced by gpmp_potrf_lower_async
@@ -192,6 +204,13 @@ int gpmp_dgemm(int ta, int tb, int M, int N, int K, double alpha, const double* 
 int gpmp_coldots(const double* V, int n, int m, long ldv, const double* Y, int r, long ldy,
                  double* out, long ldo, double* ws, gpmp_stream_t stream);
 int gpmp_coldots_ws_rows(int n);
+
+/* out[j] = sum_i A[i,j] * B[i,j]  (A, B n x m row-major, lda / ldb): the matrix x matrix form of einsum("i..., i...") --
+ * the reference's posterior-variance reduction over lambda_t and Kit (gpmp/core/kriging.py:194), taken when the
+ * kriging weights are requested (gpmp/core/model.py:305-306).  ws: m * gpmp_coldots_ws_rows(n) doubles (more than needed).
+ * Enqueue only. */
+int gpmp_coldots_pair(const double* A, long lda, const double* B, long ldb, int n, int m, double* out, double* ws,
+                      gpmp_stream_t stream);
 
 /* *out_dev (device double) = 2 * sum_i log(L[i,i])  (gpmp/core/likelihood.py:50).  Enqueue only. */
 int gpmp_logdet_chol(const double* L, int n, long ldl, double* out_dev, gpmp_stream_t stream);

@@ -103,6 +103,17 @@ assert lib.gpmp_dist_trailing_update(N, 256, 256, 256, 1, 1, 0, 0, 0, N, 256, N,
 for h in (None, ctypes.c_void_p(0x1000), ctypes.c_void_p(0x1000)):
     assert lib.gpmp_stream_release(h) == 0
 assert lib.gpmp_stream_destroy(None) == 0
+# per-device state table (round 4): 8 host threads x 8 made-up device ordinals, every thread sees one state object per
+# ordinal, the table grows by 8 and shrinks back; no HIP call is made (the entries hold no stream)
+assert lib.gpmp_device_state_count() == 0
+assert lib.gpmp_debug_device_table_selftest(8, 8, 200) == 0
+assert lib.gpmp_device_state_count() == 0
+assert lib.gpmp_debug_device_table_selftest(0, 8, 1) < 0 and lib.gpmp_last_error()
+# new reduction: argument validation + empty input
+assert lib.gpmp_coldots_pair(N, 4, N, 4, 4, 4, N, N, N) < 0
+assert lib.gpmp_coldots_pair(ctypes.c_void_p(8), 4, ctypes.c_void_p(8), 4, 4, 0, ctypes.c_void_p(8), ctypes.c_void_p(8), N) == 0
+# a block size above 1024 is refused when the layout is made, not at step 0
+assert lib.gpmp_dist_local_shape(4096, 2048, 1, 1, 0, 0, None, None) < 0
 print("ASAN-CHILD-OK")
 '''
 

@@ -97,7 +97,7 @@ def test_step_abi_equals_the_tensor_level_schedule(tmp_path, pr, pc, n, nb, look
     outs = []
     for abi in ("1", "0"):
         out = str(tmp_path / f"L{abi}.npy")
-        mp.spawn(_worker, args=(world, _free_port(), pr, pc, n, nb, out, "bcast", lookahead, "gloo", abi), nprocs=world, join=True)
+        _spawn_bounded(_worker, (world, _free_port(), pr, pc, n, nb, out, "bcast", lookahead, "gloo", abi), world, 600.0)
         outs.append((np.load(out), np.load(out + ".meta.npy")))
     (L1, m1), (L0, m0) = outs
     assert m1[0] == 0 and m0[0] == 0
@@ -200,7 +200,7 @@ def test_block_cyclic_predict_hip(tmp_path, pr, pc, n, m, nb, transport, overlap
 
     world = pr * pc
     out = str(tmp_path / "p.npy")
-    mp.spawn(_predict_worker, args=(world, _free_port(), pr, pc, n, m, nb, out, transport, overlap), nprocs=world, join=True)
+    _spawn_bounded(_predict_worker, (world, _free_port(), pr, pc, n, m, nb, out, transport, overlap), world, 600.0)
     got = np.load(out)
     x, z = make_xz(n, 4, 11)
     xt, _ = make_xz(m, 4, 12)
@@ -273,7 +273,7 @@ def test_block_cyclic_reml_and_loo_hip(tmp_path, pr, pc, n, nb, q):
 
     world = pr * pc
     out = str(tmp_path / "r.npy")
-    mp.spawn(_reml_loo_worker, args=(world, _free_port(), pr, pc, n, nb, q, out), nprocs=world, join=True)
+    _spawn_bounded(_reml_loo_worker, (world, _free_port(), pr, pc, n, nb, q, out), world, 600.0)
     got = np.load(out)
     x, z = make_xz(n, 4, 11)
     th = theta_aniso(4, scale=0.5)
@@ -330,7 +330,7 @@ def test_block_cyclic_value_and_gradient_hip(tmp_path, pr, pc, n, nb, q, noise):
 
     world = pr * pc
     out = str(tmp_path / "g.npy")
-    mp.spawn(_grad_worker, args=(world, _free_port(), pr, pc, n, nb, q, noise, out), nprocs=world, join=True)
+    _spawn_bounded(_grad_worker, (world, _free_port(), pr, pc, n, nb, q, noise, out), world, 600.0)
     got = np.load(out)
     x, z = make_xz(n, 4, 11)
     th = theta_aniso(4, scale=0.5)
@@ -391,7 +391,7 @@ def test_block_cyclic_universal_kriging_hip(tmp_path, pr, pc, n, m, nb, q):
 
     world = pr * pc
     out = str(tmp_path / "p.npy")
-    mp.spawn(_uk_worker, args=(world, _free_port(), pr, pc, n, m, nb, q, out), nprocs=world, join=True)
+    _spawn_bounded(_uk_worker, (world, _free_port(), pr, pc, n, m, nb, q, out), world, 600.0)
     got = np.load(out)
     x, z = make_xz(n, 4, 11)
     xt, _ = make_xz(m, 4, 12)
@@ -510,7 +510,7 @@ def test_distributed_model_surface_hip(tmp_path, pr, pc, meantype):
 
     world = pr * pc
     out = str(tmp_path / "m.npy")
-    mp.spawn(_model_worker, args=(world, _free_port(), pr, pc, meantype, out), nprocs=world, join=True)
+    _spawn_bounded(_model_worker, (world, _free_port(), pr, pc, meantype, out), world, 600.0)
     got = np.load(out)
     n, m = 1800, 333
     x, z = make_xz(n, 4, 11)

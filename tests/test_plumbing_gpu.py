@@ -1,0 +1,105 @@
+"""Round 4: the last backend-namespace names that ran on vendor libraries now run on the library's own kernels --
+``gnp.qr`` (Householder reflectors on the fp64 GEMM + column dots; gpmp/core/linalg.py:49-110 call it with mode="complete")
+and the matrix x matrix ``einsum("i..., i...")`` (gpmp/core/kriging.py:194) through ``gpmp_coldots_pair``."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gnp():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gpmp_amd.num as gnp
+
+    return gnp
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (7, 3), (300, 257), (4097, 1000), (129, 5003)])
+def test_coldots_pair_vs_numpy(gnp, n, m):
+    rng = np.random.default_rng(n * 31 + m)
+    a, b = rng.standard_normal((n, m)), rng.standard_normal((n, m))
+    ref = np.einsum("ij,ij->j", a, b)
+    out = gnp.to_np(gnp.einsum("i..., i...", gnp.asarray(a), gnp.asarray(b)))
+    assert out.shape == (m,)
+    scale = np.sqrt(n) * np.max(np.abs(a)) * np.max(np.abs(b))
+    assert np.max(np.abs(out - ref)) < 1e-14 * max(scale, 1.0) * np.sqrt(n)
+    # strided views (a column block of a wider matrix) take the same route without a copy of the parent
+    wide = gnp.asarray(rng.standard_normal((n, m + 5)))
+    v = wide[:, 2 : 2 + m]
+    out2 = gnp.to_np(gnp.einsum("i..., i...", v, gnp.asarray(b)))
+    np.testing.assert_allclose(out2, np.einsum("ij,ij->j", gnp.to_np(v), b), atol=1e-13 * max(scale, 1.0))
+
+
+@pytest.mark.parametrize("n,q", [(50, 1), (300, 4), (1000, 9)])
+def test_qr_on_library_kernels_vs_lapack(gnp, n, q):
+    rng = np.random.default_rng(n + q)
+    A = np.hstack((np.ones((n, 1)), rng.random((n, q - 1)))) if q > 1 else np.ones((n, 1))
+    Qc, Rc = (gnp.to_np(t) for t in gnp.qr(gnp.asarray(A), mode="complete"))
+    Qr, Rr = (gnp.to_np(t) for t in gnp.qr(gnp.asarray(A), mode="reduced"))
+    assert Qc.shape == (n, n) and Rc.shape == (n, q) and Qr.shape == (n, q) and Rr.shape == (q, q)
+    np.testing.assert_allclose(Qc @ Rc, A, atol=1e-13)
+    np.testing.assert_allclose(Qr @ Rr, A, atol=1e-13)
+    np.testing.assert_allclose(Qc.T @ Qc, np.eye(n), atol=1e-13)
+    assert np.allclose(np.tril(Rr, -1), 0.0) and np.all(Rc[q:] == 0.0)
+    # LAPACK's sign convention: the factors themselves agree, not only the subspaces
+    Ql, Rl = np.linalg.qr(A, mode="complete")
+    np.testing.assert_allclose(Rc, Rl, atol=1e-12)
+    np.testing.assert_allclose(Qc[:, :q], Ql[:, :q], atol=1e-12)
+    # the contrast projector W W^T = I - Q1 Q1^T is basis-independent
+    from gpmp_amd.core import linalg as L
+
+    W = gnp.to_np(L.compute_contrast_matrix(gnp.asarray(A)))
+    assert W.shape == (n, n - q)
+    np.testing.assert_allclose(W @ W.T, np.eye(n) - Ql[:, :q] @ Ql[:, :q].T, atol=1e-12)
+    np.testing.assert_allclose(W.T @ A, 0.0, atol=1e-12)
+
+
+def test_per_device_state_two_host_threads_and_release(gnp):
+    """Round 4: the look-ahead factorisation's helper streams / events are kept per device ordinal behind a per-device mutex.
+    Two host threads enqueue look-ahead factorisations (n > 2048) on their own streams of the one device at the same time;
+    both factors must match LAPACK; gpmp_device_release returns the device's state and the next call rebuilds it."""
+    import threading
+
+    import torch
+
+    from gpmp_amd import _lib
+    from oracle import gp_oracle as orc
+
+    lib = _lib.load()
+    d = 4
+    th = np.concatenate(([0.0], -np.log(0.4 * (1.0 + np.arange(d) / d))))
+    sizes = (3000, 2700)
+    mats = [orc.maternp_covariance(np.random.default_rng(s).random((s, d)), None, 2, th) for s in sizes]
+    refs = [np.linalg.cholesky(K) for K in mats]
+    out, errs = [None, None], []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    F = gnp.cholesky_factor(gnp.asarray(mats[i]))
+                    out[i] = torch.tril(F.L).cpu().numpy()
+            s.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert np.max(np.abs(out[i] - refs[i])) < 1e-10 * np.max(np.abs(refs[i]))
+    torch.cuda.synchronize()
+    assert lib.gpmp_device_state_count() == 1
+    assert lib.gpmp_device_release() == 0 and lib.gpmp_device_state_count() == 0
+    assert lib.gpmp_device_release() == 0                      # nothing held: a no-op
+    F = gnp.cholesky_factor(gnp.asarray(mats[0]))
+    assert np.max(np.abs(torch.tril(F.L).cpu().numpy() - refs[0])) < 1e-10 * np.max(np.abs(refs[0]))
+    assert lib.gpmp_device_state_count() == 1
