@@ -500,6 +500,74 @@ def launcher_main(args, argv):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# who ran: one record per rank, gathered through the process group itself (so the record proves the group's membership)
+# ------------------------------------------------------------------------------------------------------------------
+def _device_identity(have_gpu):
+    """(index, name, uuid, pci bus id) of this process's current GPU; Nones without one (stub runs)."""
+    if not have_gpu:
+        return {"device_index": None, "device_name": None, "uuid": None, "pci_bus_id": None}
+    import torch
+
+    idx = torch.cuda.current_device()
+    out = {"device_index": idx, "device_name": torch.cuda.get_device_name(idx), "uuid": None, "pci_bus_id": None}
+    try:
+        props = torch.cuda.get_device_properties(idx)
+        u = getattr(props, "uuid", None)
+        out["uuid"] = str(u) if u is not None else None
+        if all(hasattr(props, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            out["pci_bus_id"] = "%04x:%02x:%02x" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+    except Exception as e:  # noqa: BLE001 -- identity is evidence, never a reason to lose the measurement
+        out["identity_error"] = f"{type(e).__name__}: {e}"[:120]
+    return out
+
+
+def gather_ranks_seen(dist_mod, rank, world, backend, have_gpu):
+    """All-gather of (rank, pid, host, LOCAL_RANK, current device index / name / uuid / PCI bus id) over the process group
+    that produced the numbers beside it, + the RCCL version torch was built with: the record then shows N distinct DEVICES
+    under RCCL, not just N PIDs.  Every rank gets the full record; `distinct_devices` counts (host, uuid or PCI id or index)."""
+    import socket
+
+    me = {"rank": rank, "pid": os.getpid(), "host": socket.gethostname(), "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}
+    me.update(_device_identity(have_gpu))
+    recs = [me]
+    if dist_mod is not None and world > 1:
+        recs = [None] * world
+        dist_mod.all_gather_object(recs, me)
+    rccl = None
+    if have_gpu:
+        try:
+            import torch
+
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            rccl = None
+    ident = {(r["host"], r.get("uuid") or r.get("pci_bus_id") or r.get("device_index")) for r in recs}
+    return {"backend": backend, "rccl_version": rccl, "world": world, "ranks": recs,
+            "distinct_pids": len({(r["host"], r["pid"]) for r in recs}),
+            "distinct_devices": len(ident) if have_gpu else 0}
+
+
+def time_block_cyclic_strong_scaling(runner, dist_mod, world, rank, reps, tmax):
+    """Timing harness of extra.strong_scaling_block_cyclic (shared with tests/bench_stub.py): the headline STEP -- predict at
+    m points + one zero-mean NLL at the same n -- with K DISTRIBUTED over the grid instead of factored on every rank.
+    `runner.step(shared_factor)`: one step; shared_factor False = K built and factored twice (what the single-GPU headline step
+    does: no cache), True = once for both calls.  One warm-up step each, then `reps` steps between barrier + sync pairs, max over
+    ranks.  `runner.check()` (every rank calls it; rank 0 compares with its own single-GPU result) -> dict of deviations."""
+    out = {}
+    for key, shared in (("two_factorisations", False), ("shared_factor", True)):
+        runner.step(shared)
+        runner.sync(); dist_mod.barrier(); runner.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            runner.step(shared)
+        runner.sync(); dist_mod.barrier(); runner.sync()
+        dt = tmax(time.perf_counter() - t0) / reps
+        out[key] = {"steps": reps, "ms_per_step": 1e3 * dt, "points_per_s": runner.m / dt}
+    out["values_check"] = runner.check()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs[4]: the distributed extra (worker side)
 # ------------------------------------------------------------------------------------------------------------------
 DIST_N = {2: 65536, 4: 90112, 8: 131072}     # about 17 GB of local matrix per GPU; 8 GPUs = BASELINE.json configs[4]
@@ -607,6 +675,14 @@ def dist_potrf_extra(world, rank, res):
             res[f"{transport}_{rep}"] = entry
             if not (transport == "p2p" and rep == "timed"):
                 del ch
+    # ---- strong scaling on the path that can scale: the HEADLINE workload (n = 32768, m = 50000 in total) through
+    #      DistributedModel.predict + NLL on this grid -- K distributed, nothing replicated
+    if os.environ.get("GPMP_BENCH_DIST_STRONG", "1") != "0":
+        res["phase"] = "strong_scaling_block_cyclic: headline workload on the block-cyclic factor"
+        res["strong_scaling_block_cyclic"] = strong_block_cyclic_extra(world, rank, grid, tmax, res)
+        vc = res["strong_scaling_block_cyclic"].get("values_check")
+        if rank == 0 and not (vc and vc.get("ok")):
+            raise RuntimeError(f"strong_scaling_block_cyclic: distributed results differ from the single-GPU ones: {vc}")
     # ---- on the last factor (still resident): what a parameter fit and a prediction at this n cost.  LAST on
     #      purpose: everything above is already in the progress file if one of these wedges.
     if os.environ.get("GPMP_BENCH_DIST_MORE", "1") != "0" and info == 0:
@@ -633,6 +709,65 @@ def dist_potrf_extra(world, rank, res):
     res["phase"] = "done"
 
 
+class _BlockCyclicHeadline:
+    """The headline step on the block-cyclic factor (one instance per rank; every rank makes the same calls)."""
+
+    def __init__(self, grid, n, m, d, rank):
+        import torch
+
+        from gpmp_amd.dist import DistributedModel
+        from gpmp_amd.kernel import MaternCovariance
+
+        self.torch, self.rank, self.n, self.m, self.d = torch, rank, n, m, d
+        self.xi, self.zi, self.xt, self.theta = synth(n, m, d, 0)
+        self.model = DistributedModel(grid, None, MaternCovariance(2), None, self.theta, "zero")
+        self.out = None
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def step(self, shared_factor):
+        self.model._cache = None
+        zpm, zpv = self.model.predict(self.xi, self.zi, self.xt)
+        if not shared_factor:
+            self.model._cache = None
+        nll = self.model.negative_log_likelihood_zero_mean(self.theta, self.xi, self.zi)
+        self.out = (zpm, zpv, float(nll))
+
+    def check(self):
+        """rank 0: the same step on ITS OWN GPU alone (the single-GPU product path), deviations of the distributed results"""
+        zpm, zpv, nll = self.out
+        res = None
+        if self.rank == 0:
+            import gpmp_amd as gp
+            from gpmp_amd.kernel import MaternCovariance
+
+            self.model._cache = None
+            self.torch.cuda.empty_cache()
+            ref = gp.Model(None, MaternCovariance(2), None, self.theta, "zero")
+            rpm, rpv = ref.predict(self.xi, self.zi, self.xt)
+            rnll = float(ref.negative_log_likelihood_zero_mean(self.theta, self.xi, self.zi))
+            res = {"max_abs_dmean": float(np.max(np.abs(zpm - rpm))), "max_abs_dvar": float(np.max(np.abs(zpv - rpv))),
+                   "nll_block_cyclic": nll, "nll_single_gpu": rnll, "nll_rel_diff": abs(nll - rnll) / abs(rnll),
+                   "against": "rank 0's single-GPU Model.predict / NLL on the same inputs"}
+            res["ok"] = bool(res["max_abs_dmean"] < 1e-6 and res["max_abs_dvar"] < 1e-6 and res["nll_rel_diff"] < 1e-9)
+        return res
+
+
+def strong_block_cyclic_extra(world, rank, grid, tmax, res):
+    import torch.distributed as dist
+
+    n, m, d = 32768, 50000, 8
+    if os.environ.get("GPMP_BENCH_STRONG_NM"):
+        n, m = (int(v) for v in os.environ["GPMP_BENCH_STRONG_NM"].split(","))
+    runner = _BlockCyclicHeadline(grid, n, m, d, rank)
+    out = {"n": n, "m_total": m, "d": d, "grid": f"{grid.pr}x{grid.pc}", "block": runner.model.nb,
+           "note": "fixed total work: the single-GPU headline step (predict at m points + one NLL, inputs as host arrays, results as "
+                   "host arrays on every rank) with K 2-D block-cyclic over the grid; compare with the N = 1 headline ms_per_step"}
+    out.update(time_block_cyclic_strong_scaling(runner, dist, world, rank, 3, tmax))
+    return out
+
+
 def dist_extra_worker(args):
     """One rank of the distributed extra's own process group (started by spawn_ranks).  Exit code 0 / 4; a hang is the
     launcher's business (it kills the group at its time limit)."""
@@ -648,6 +783,7 @@ def dist_extra_worker(args):
             import torch.distributed as dist
 
             dist.init_process_group(os.environ.get("GPMP_BENCH_BACKEND", "gloo"))
+            res["ranks_seen"] = gather_ranks_seen(dist, rank, world, dist.get_backend(), False)
             stub.dist_extra(world, rank, res)
         else:
             import torch
@@ -662,6 +798,8 @@ def dist_extra_worker(args):
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             else:
                 dist.init_process_group(backend)
+            res["phase"] = "setup: all-gather of the rank records"
+            res["ranks_seen"] = gather_ranks_seen(dist, rank, world, backend, True)
             dist_potrf_extra(world, rank, res)
         res["status"] = "ok"
         dist.barrier()
@@ -931,6 +1069,8 @@ def headline_worker(args):
                   "note": "fixed total work: the m points of ONE GPU's headline step split over the ranks, K factored on every rank "
                           "(Amdahl bound at N = 8: 2 potrf = 372 ms replicated + 763 / N ms of solve)"}
 
+    ranks_seen = gather_ranks_seen(dist if dist_on else None, rank, world, backend if dist_on else None, have_gpu)
+
     rc = 0
     line = None
     if rank == 0:
@@ -949,6 +1089,7 @@ def headline_worker(args):
                        "n": n, "m_per_gpu": m, "d": d,
                        "parallelism": f"xt-sharded x{world} (m points per rank); K built and factored on EVERY rank (replicated, "
                                       f"no data-path collective) -- weak scaling is ~N x by construction, see extra.strong_scaling"},
+            "ranks_seen": ranks_seen,
             "extra": {"worker_pids": pids, "backend": backend if dist_on else None, "strong_scaling": strong},
         }
         wl.report(line)

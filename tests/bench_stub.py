@@ -46,9 +46,30 @@ class Workload:
         pass
 
 
+class _StubBlockCyclicRunner:
+    """what bench.time_block_cyclic_strong_scaling drives: step(shared_factor), sync(), check(), .m"""
+
+    m = 50000
+
+    def __init__(self, rank):
+        self.rank, self.calls = rank, []
+
+    def sync(self):
+        pass
+
+    def step(self, shared_factor):
+        self.calls.append(bool(shared_factor))
+        time.sleep(0.004 if shared_factor else 0.008)
+
+    def check(self):
+        return {"ok": True, "calls": len(self.calls)} if self.rank == 0 else None
+
+
 def dist_extra(world, rank, res):
     import torch
     import torch.distributed as dist
+
+    import bench
 
     mode = os.environ.get("GPMP_STUB_DIST", "ok")
     res["phase"] = "stub: all-reduce"
@@ -56,6 +77,13 @@ def dist_extra(world, rank, res):
     dist.all_reduce(t)
     assert int(t.item()) == world
     res["pids_sum_check"] = int(t.item())
+    def tmax(v):
+        t_ = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        return float(t_.item())
+
+    res["phase"] = "stub: strong_scaling_block_cyclic"
+    res["strong_scaling_block_cyclic"] = bench.time_block_cyclic_strong_scaling(_StubBlockCyclicRunner(rank), dist, world, rank, 2, tmax)
     if mode == "error" and rank == world - 1:
         raise RuntimeError("stub failure on the last rank")
     if mode == "hang":

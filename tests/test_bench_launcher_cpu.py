@@ -66,6 +66,17 @@ def test_launcher_starts_n_ranks_and_relays_rank0_line():
     dp = line["extra"]["dist_potrf"]
     assert dp["status"] == "ok" and dp["phase"] == "done" and dp["worker_rc"] == [0, 0]
     assert len(set(dp["worker_pids"]) | set(pids)) == 4
+    # round 4: the record proves its own membership -- one gathered (rank, pid, host, device) entry per rank, in the headline
+    # line and in the extra's own process group; and the block-cyclic strong-scaling entry of the headline workload
+    for seen, who in ((line["ranks_seen"], pids), (dp["ranks_seen"], dp["worker_pids"])):
+        assert seen["world"] == 2 and seen["backend"] == "gloo" and seen["distinct_pids"] == 2
+        assert [r["rank"] for r in seen["ranks"]] == [0, 1] and sorted(r["pid"] for r in seen["ranks"]) == sorted(who)
+        assert all(set(r) >= {"host", "local_rank", "device_index", "uuid", "pci_bus_id"} for r in seen["ranks"])
+    sb = dp["strong_scaling_block_cyclic"]
+    for key, floor_ms in (("two_factorisations", 8.0), ("shared_factor", 4.0)):
+        assert sb[key]["steps"] == 2 and sb[key]["ms_per_step"] >= floor_ms
+        assert abs(sb[key]["points_per_s"] - 50000 / (sb[key]["ms_per_step"] * 1e-3)) < 1e-6 * sb[key]["points_per_s"]
+    assert sb["values_check"] == {"ok": True, "calls": 6}          # (1 warm-up + 2 timed) x 2 variants on rank 0
 
 
 def test_hung_collective_in_the_extra_is_killed_and_costs_only_the_extra():
