@@ -179,6 +179,19 @@ class HipLocalOps:
                                             g._stream()), "gpmp_dgemm")
         return out
 
+    def gemm_tn_into(self, A, B, C):
+        """C <- A^T B through the library GEMM, C a (strided) view of the right shape: no temporary, no copy."""
+        g = self.gnp
+        K, M = A.shape
+        N = B.shape[1]
+        if M == 0 or N == 0:
+            return
+        if K == 0:
+            C.zero_()
+            return
+        self._lib.check(self.lib.gpmp_dgemm(1, 0, M, N, K, 1.0, g._ptr(A), g._ld(A), g._ptr(B), g._ld(B), 0.0, g._ptr(C), g._ld(C), 0,
+                                            g._stream()), "gpmp_dgemm")
+
     def grad_trace_cross(self, M, xr, xc, p, covparam, noise, F, G):
         """[sum M sigma^2 Kc, sum M dK/dlog(1/rho_j) ...] over the rectangular block M (rows: points xr, columns: points xc),
         M <- M - F G^T in registers: gpmp_matern_grad_trace_cross.  Returns a (1 + d,) device vector."""
@@ -1184,8 +1197,8 @@ class BlockCyclicCholesky:
         blocks c != c' count twice) -- and traces each block against the matching block of dK in one fused pass
         (gpmp_matern_grad_trace_cross: dK is recomputed on the fly, the low-rank part is subtracted in registers).  Partial
         sums over the process rows need no matrix reduction: the trace is linear, so ONE all-reduce of 1 + d doubles ends it.
-        Flops: n^3 / 3 for T (triangular structure exploited, balanced over the grid) + about n^3 / 2 for the blocks (a
-        staircase in the contraction index; a blocked in-place potri would need n^3 / 3 for them)."""
+        Flops: n^3 / 3 for T (triangular structure exploited, balanced over the grid) + n^3 / 3 for the blocks (round 4: every
+        unordered pair of block columns once, contraction from the later of the two on -- the blocked lauum's count)."""
         g, ops = self.grid, self.ops
         if self.info:
             return math.inf, np.zeros(len(covparam))
@@ -1235,33 +1248,85 @@ class BlockCyclicCholesky:
             value = 0.5 * ((n - q) * math.log(2.0 * math.pi) + logdet + 2.0 * np.sum(np.log(np.diag(cS))) - 2.0 * np.sum(np.log(np.diag(cP)))
                            + float(z @ alpha - b @ (Sinv @ b)))
             Fh, Gh = np.hstack((US, beta.reshape(-1, 1))), np.hstack((U, beta.reshape(-1, 1)))
-        # ---- blocks (column set c, column set c') of T^T T against dK: ring over the process row, half of it by symmetry.
-        # T2's block column J is zero above global row J nb, so its product with T only needs the local rows from block row J
-        # on: one GEMM per block column of T2, a staircase in K (half the flops of the plain product)
+        # ---- K^-1 = T^T T against dK, block pair by block pair, every unordered pair of block columns {I, J} ONCE with its exact
+        # contraction range -- the distributed form of the blocked lauum (gpmp_lauum_lower; numpy_backend.py:458-463 forms the
+        # inverse): block (I, J) = sum over the block rows k >= max(I, J) of T[k, I]^T T[k, J], n^3 / 3 flops in all (round 3 formed
+        # whole (column set, column set) blocks with the contraction cut on one side only: 0.75 n^3).  The rows k are split over the
+        # process rows and the trace is linear, so the partial products are traced where they are (no matrix reduction); the
+        # column sets meet around the process row (ring of Pc / 2 shifts).  Per shift, with I in my column set c, J in set c2:
+        #   row strip of I:     M[I, J <= I] = T[ro(I):, I]^T T2[ro(I):, J <= I]     (the J <= I are a PREFIX of T2's local columns)
+        #   column strip of J:  M[I < J, J]  = T[ro(J):, I < J]^T T2[ro(J):, J]      (the I < J are a prefix of T's local columns)
+        # sft = 0 (c2 = c): row strips only (the lower block triangle; diagonal blocks count once, the others twice);
+        # 0 < sft < Pc / 2: both kinds = the whole (c, c2) block, twice (its mirror (c2, c) is never formed);
+        # sft = Pc / 2 (Pc even): row strips only, twice -- the partner rank's row strips are the mirror of my column strips.
         xs_c = x[ci]
         tot = torch.zeros(1 + d, dtype=torch.float64, device=dev)
         half = g.pc // 2
+        nrows_loc = self.roff[-1]
+        my_blocks = self.col_blocks
+
+        def row_start(I):                         # first local row of a block row >= I
+            return self.roff[bisect.bisect_left(self.row_blocks, I)]
+
         for sft in range(half + 1):
             c2 = (g.c + sft) % g.pc
             T2 = T if sft == 0 else ops.asarray(self._ring_shift(T, sft))
-            weight = 1.0 if (sft == 0 or (g.pc % 2 == 0 and sft == half)) else 2.0
+            strips_only = sft == 0 or (g.pc % 2 == 0 and sft == half)
             blocks2 = g.local_col_blocks(self.nblocks, c2)
+            off2 = self._offsets(blocks2)
             ci2 = np.concatenate([np.arange(J * self.nb, J * self.nb + self.bs(J)) for J in blocks2]) if blocks2 else np.zeros(0, dtype=np.int64)
-            if len(ci) and len(ci2) and len(self.row_blocks):
-                Mblk = ops.empty(len(ci), len(ci2))
-                o2 = 0
-                for J in blocks2:
-                    w2 = self.bs(J)
-                    ro = self.roff[bisect.bisect_left(self.row_blocks, J)]          # first local row of a block row >= J
-                    if ro < self.roff[-1]:
-                        Mblk[:, o2:o2 + w2].copy_(ops.gemm_tn(T[ro:], T2[ro:, o2:o2 + w2]))
+            if not (len(ci) and len(ci2) and len(self.row_blocks)):
+                continue
+            lowG_all = Gh[ci2] if g.r == 0 else None          # the low-rank part enters exactly once per block: on process row 0
+            if strips_only:
+                for li, I in enumerate(my_blocks):
+                    oI, wI = self.coff[li], self.bs(I)
+                    pref = off2[bisect.bisect_right(blocks2, I)]                  # local columns of the J <= I in set c2
+                    ro = row_start(I)
+                    if pref == 0:
+                        continue
+                    strip = ops.empty(wI, pref)
+                    if ro < nrows_loc:
+                        ops.gemm_tn_into(T[ro:, oI:oI + wI], T2[ro:, :pref], strip)
                     else:
-                        Mblk[:, o2:o2 + w2].zero_()
-                    o2 += w2
-                # the low-rank part must enter exactly once per block: on process row 0
+                        strip.zero_()                                            # no local row below: only the low-rank part is left
+                    lowF = Fh[ci[oI:oI + wI]] if g.r == 0 else None
+                    xr = xs_c[oI:oI + wI]
+                    if sft == 0:
+                        # the diagonal block (I, I) is the last wI columns of the strip: once; everything left of it: twice
+                        if pref > wI:
+                            tot += 2.0 * ops.grad_trace_cross(strip[:, :pref - wI], xr, x[ci2[:pref - wI]], p, th, noise, lowF,
+                                                              None if lowG_all is None else lowG_all[:pref - wI]).to(dev)
+                        tot += ops.grad_trace_cross(strip[:, pref - wI:], xr, x[ci2[pref - wI:pref]], p, th, noise, lowF,
+                                                    None if lowG_all is None else lowG_all[pref - wI:pref]).to(dev)
+                    else:
+                        tot += 2.0 * ops.grad_trace_cross(strip, xr, x[ci2[:pref]], p, th, noise, lowF,
+                                                          None if lowG_all is None else lowG_all[:pref]).to(dev)
+                    del strip
+            else:
+                Mblk = ops.empty(len(ci), len(ci2))
+                for li, I in enumerate(my_blocks):                               # row strips: J <= I
+                    oI, wI = self.coff[li], self.bs(I)
+                    pref = off2[bisect.bisect_right(blocks2, I)]
+                    ro = row_start(I)
+                    if pref == 0:
+                        continue
+                    if ro < nrows_loc:
+                        ops.gemm_tn_into(T[ro:, oI:oI + wI], T2[ro:, :pref], Mblk[oI:oI + wI, :pref])
+                    else:
+                        Mblk[oI:oI + wI, :pref].zero_()
+                for lj, J in enumerate(blocks2):                                 # column strips: I < J
+                    o2, w2 = off2[lj], self.bs(J)
+                    pref = self.coff[bisect.bisect_left(my_blocks, J)]
+                    ro = row_start(J)
+                    if pref == 0:
+                        continue
+                    if ro < nrows_loc:
+                        ops.gemm_tn_into(T[ro:, :pref], T2[ro:, o2:o2 + w2], Mblk[:pref, o2:o2 + w2])
+                    else:
+                        Mblk[:pref, o2:o2 + w2].zero_()
                 lowF = Fh[ci] if g.r == 0 else None
-                lowG = Gh[ci2] if g.r == 0 else None
-                tot += weight * ops.grad_trace_cross(Mblk, xs_c, x[ci2], p, th, noise, lowF, lowG).to(dev)
+                tot += 2.0 * ops.grad_trace_cross(Mblk, xs_c, x[ci2], p, th, noise, lowF, lowG_all).to(dev)
                 del Mblk
         self._step_label = "grad_total"
         self._all_reduce(tot, dist.ReduceOp.SUM, g.world_group, "grad_traces")

@@ -32,6 +32,9 @@ def main():
                     "(split over the process columns), with and without the prefetch / chain / update overlap")
     ap.add_argument("--grad", action="store_true", help="also time one ML value + gradient on the factor (T = L^-1 in the block-cyclic "
                     "layout, the blocks of T^T T around the process row, the fused cross traces), collectives stubbed")
+    ap.add_argument("--step-m", type=int, default=0, help="also time one emulated HEADLINE STEP on the block-cyclic factor: (Gram + factor + "
+                    "zero-mean prediction at this many points) + (Gram + factor + NLL), what extra.strong_scaling_block_cyclic of bench.py "
+                    "runs on the real grid; compute only (collectives stubbed)")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -80,6 +83,7 @@ def main():
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     factor_phases = {k: round(v, 2) for k, v in ch.phase_times().items()}
+    local_shape, reserve_cus, bytes_received = [ch.local_rows(), ch.local_cols()], ch.reserve_cus, ch.bytes_received
     share = (n ** 3 / 3.0) / (pr * pc)
     solve = None
     if a.solve_m > 0:
@@ -117,12 +121,45 @@ def main():
             t5 = time.perf_counter()
             grad[rep] = {"inverse_factor_s": t4 - t3, "inverse_factor_rank_share_tflops": (n ** 3 / 3.0) / (pr * pc) / (t4 - t3) / 1e12,
                          "value_and_grad_s": t5 - t4, "note": "value_and_grad includes its own inverse factor; ring shifts stubbed"}
+    step = None
+    if a.step_m > 0:
+        from gpmp_amd.dist import shard_bounds
+
+        xh = rng.random((n, d))
+        zh = np.sin(2 * np.pi * xh[:, 0]) + xh[:, 1:].sum(axis=1)
+        xt = np.random.default_rng(4321).random((a.step_m, d))
+        del ch
+        torch.cuda.empty_cache()
+        step = {"m_total": a.step_m, "m_local": shard_bounds(a.step_m, pc, c)[1] - shard_bounds(a.step_m, pc, c)[0]}
+        for rep in ("warm", "timed"):
+            parts = {}
+            torch.cuda.synchronize()
+            t_begin = time.perf_counter()
+            for what in ("predict", "nll"):
+                t3 = time.perf_counter()
+                c2 = Emulated(grid, n, nb=a.block, ops=HipLocalOps(), lookahead=not a.no_lookahead)
+                c2.backend = "nccl"          # scalars and the few-column solve stay on the device, as under RCCL (nothing is sent: stubs)
+                c2.build_local_gram(MaternCovariance(2), gnp.asarray(xh), theta, 1e-4)
+                c2.factor()
+                c2.info = 0
+                torch.cuda.synchronize()
+                t4 = time.perf_counter()
+                if what == "predict":
+                    c2.predict_zero_mean(MaternCovariance(2), xh, zh, xt, theta)
+                else:
+                    c2.negative_log_likelihood(zh)
+                torch.cuda.synchronize()
+                t5 = time.perf_counter()
+                parts[what] = {"gram_and_factor_s": t4 - t3, "rest_s": t5 - t4}
+                del c2
+            step[rep] = {"step_s": time.perf_counter() - t_begin, "parts": parts}
+        ch = None
     print(json.dumps({"tool": "dist_rank_emulation", "n": n, "grid": a.grid, "coords": a.coords, "block": a.block,
-                      "local_shape": [ch.local_rows(), ch.local_cols()], "lookahead": not a.no_lookahead, "reserve_cus": ch.reserve_cus,
+                      "local_shape": local_shape, "lookahead": not a.no_lookahead, "reserve_cus": reserve_cus,
                       "gram_s": t1 - t0, "factor_s": t2 - t1, "rank_share_tflops": share / (t2 - t1) / 1e12,
                       "frac_of_fp64_mfma_peak": share / (t2 - t1) / 1e12 / 78.6,
-                      "bytes_received_GB": ch.bytes_received / 1e9,
-                      "phases_ms": factor_phases, "solve": solve, "grad": grad,
+                      "bytes_received_GB": bytes_received / 1e9,
+                      "phases_ms": factor_phases, "solve": solve, "grad": grad, "headline_step": step,
                       "note": "collectives stubbed: timing and fault check only, values are not a factorisation"}))
     dist.destroy_process_group()
 
