@@ -48,6 +48,7 @@ struct GemmParams {
   int batch2;   // gridDim.z independent problems (outer batch)
   int pair16;   // v2 epilogue: 16-byte stores after a lane-pair exchange
   int prio;     // small NT kernels: raise the wave priority (GPMP_CHAIN_PRIO)
+  int gm;       // plain tile order: tile rows per group (8 = the 64 co-resident workgroups of an XCD cover 8 x 8 tiles)
   long sa, sb, sc;   // element strides of A, B, C per batch index
   long sa2, sb2, sc2;   // ... per outer batch index (blockIdx.z)
 };
@@ -88,7 +89,7 @@ __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& t
       tj = v - r * p.tiles_n;
     }
   } else {
-    constexpr int GM = 8;
+    const int GM = p.gm;
     const int per_group = GM * p.tiles_n;
     const int g = v / per_group;
     const int first = g * GM;
@@ -1157,6 +1158,11 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   static int chain_prio = -1;
   if (chain_prio < 0) { const char* e = getenv("GPMP_CHAIN_PRIO"); chain_prio = e ? atoi(e) : 1; }
   p.prio = chain_prio;
+  // (GPMP_GEMM_GM, read once: 8 is the measured optimum -- with 64 co-resident 128 x 128 tiles per XCD the L2-side traffic per
+  //  tile is (A panel) / columns + (B panel) / rows of the co-resident block, smallest for the square 8 x 8)
+  static int gm = -1;
+  if (gm < 0) { const char* e = getenv("GPMP_GEMM_GM"); gm = e ? atoi(e) : 8; if (gm < 1) gm = 8; }
+  p.gm = gm;
   p.batch = o.batch > 1 ? o.batch : 1;
   p.sa = o.stride_a; p.sb = o.stride_b; p.sc = o.stride_c;
   p.batch2 = o.batch2 > 1 ? o.batch2 : 1;

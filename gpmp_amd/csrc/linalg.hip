@@ -280,12 +280,22 @@ int factor_panel(double* A, int n, long lda, double* dinv, int* info_dev, int p0
         if (rc) return rc;
       }
     }
-    const int rest_cols = imin(p1, n) - s1;   // remaining columns of this (wide) panel
-    if (rest_cols > 0) {
+    // Between sub-panels: binary blocking.  After sub-panel j (0-based inside the panel) the aligned block of W = sub << ctz(j + 1)
+    // columns that ends here is complete, and the next W columns receive it in ONE update of rank W:
+    //   1024-column panel:  S0 -> S1 (rank 512)                                  [what rounds 1-3 did]
+    //   2048-column panel:  S0 -> S1 (512), [S0 S1] -> [S2 S3] (rank 1024), S2 -> S3 (512)
+    // (round 1 updated ALL remaining columns of a wide panel after every sub-panel: rank 512 throughout, which is why 2048-wide
+    //  panels did not pay then.)
+    const int j = (s0 - p0) / sub;
+    int W = sub;
+    for (int t = j + 1; (t & 1) == 0; t >>= 1) W <<= 1;
+    const int k0 = s1 - W;                     // >= p0 by construction (s1 - p0 is a multiple of W)
+    const int rest_cols = imin(imin(p1, n), s1 + W) - s1;
+    if (rest_cols > 0 && k0 >= p0) {
       { int rcw = need_cols(s1 + rest_cols); if (rcw) return rcw; }
-      // A[s1:, s1:p1] -= A[s1:, s0:s1] A[s1:p1, s0:s1]^T
-      int rc = launch_gemm(true, true, n - s1, rest_cols, s1 - s0, -1.0, A + (long)s1 * lda + s0, lda,
-                           A + (long)s1 * lda + s0, lda, 1.0, A + (long)s1 * lda + s1, lda, lower, st);
+      // A[s1:, s1:s1+W] -= A[s1:, k0:s1] A[s1:s1+W, k0:s1]^T
+      int rc = launch_gemm(true, true, n - s1, rest_cols, s1 - k0, -1.0, A + (long)s1 * lda + k0, lda,
+                           A + (long)s1 * lda + k0, lda, 1.0, A + (long)s1 * lda + s1, lda, lower, st);
       if (rc) return rc;
     }
   }
@@ -330,12 +340,17 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   //  the blocked factorisation of what is left, all on the chain stream.  On its own the blocked route wins up to 2048
   //  columns (potrf_lower), as the tail of this one it changes nothing: n = 4096: 2.19 vs 2.20 ms, 8192: 6.75 vs 6.75.)
   const int tail_blocked = (sa != nullptr && sa->every_panel) ? 0 : env_int("GPMP_POTRF_TAIL_BLOCKED_BELOW", 0);
+  // Two-level panels (round 4): 2048 columns at a time while more than `super_above` rows are left -- the trailing update then
+  // has rank 2048 (the LDS-direct GEMM is 92 % MFMA-busy there against 88 % at rank 1024), and inside the panel the second half
+  // receives the first in ONE rank-1024 update (factor_panel's binary blocking).  0 = off.
+  const int super_above = env_int("GPMP_POTRF_SUPER_ABOVE", 0) > 0 ? imax(env_int("GPMP_POTRF_SUPER_ABOVE", 0), wide_thresh) : (1 << 30);
   std::vector<int> pb;
   for (int p = 0; p < n;) {
     pb.push_back(p);
     const int rest = n - p;
     if (p > 0 && rest <= tail_blocked) break;
-    p += rest > wide_thresh ? 2 * OUTER_BLOCKS * NB : (rest <= w128_below ? NB : (rest <= w256_below ? 2 * NB : OUTER_BLOCKS * NB));
+    p += rest > super_above ? 4 * OUTER_BLOCKS * NB
+                            : (rest > wide_thresh ? 2 * OUTER_BLOCKS * NB : (rest <= w128_below ? NB : (rest <= w256_below ? 2 * NB : OUTER_BLOCKS * NB)));
   }
   pb.push_back(n);
   const int np = (int)pb.size() - 1;
@@ -428,10 +443,11 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     // on the critical path.)
     const int la_split = env_int("GPMP_POTRF_LA_SPLIT", 1);
     const int la_split_above = env_int("GPMP_POTRF_LA_SPLIT_ABOVE", 8192);   // (below, the pieces are too small to be worth two more events: n = 8192 loses 2 %)
-    ColsReady ready[2];
+    ColsReady ready[3];
     int nready = 0;
-    if (la_split && p2 - p1 == 2 * OUTER_BLOCKS * NB && p2 <= n && n - p1 > la_split_above) {
-      const int cuts[4] = {p1, p1 + NB, p1 + OUTER_BLOCKS * NB, p2};
+    if (la_split && (p2 - p1 == 2 * OUTER_BLOCKS * NB || p2 - p1 == 4 * OUTER_BLOCKS * NB) && p2 <= n && n - p1 > la_split_above) {
+      const int ncuts = p2 - p1 == 4 * OUTER_BLOCKS * NB ? 4 : 3;
+      const int cuts[5] = {p1, p1 + NB, p1 + OUTER_BLOCKS * NB, ncuts == 4 ? p1 + 2 * OUTER_BLOCKS * NB : p2, p2};
       // the side stream reads panel k: it waits for an event recorded HERE, behind that panel on the chain stream (e_f is
       // only renewed where somebody else waits for it -- need_ef below -- and may be an older panel's; found by
       // tests/test_switches_gpu.py with the split enabled below 4096 rows, where the shipped thresholds never combine the two)
@@ -439,7 +455,7 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
       GPMP_HIP_TRY(hipEventRecord(e_panel, s1));
       GPMP_HIP_TRY(hipStreamWaitEvent(sside, e_panel, 0));
       if (e_u2) GPMP_HIP_TRY(hipStreamWaitEvent(sside, e_u2, 0));
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < ncuts; ++q) {
         const int ca = cuts[q], cb = cuts[q + 1];
         hipStream_t sq = q == 0 ? s1 : sside;
         rc = launch_gemm(true, true, n - ca, cb - ca, w, -1.0, A + (long)ca * lda + p0, lda, A + (long)ca * lda + p0, lda,

@@ -8,6 +8,8 @@ else memory-hungry beside it:
         GPMP_BACKEND=numpy python3 /root/repo/tests/golden/make_fullsize_fixtures.py config3      # ~25 min, ~50 GB
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg PYTHONPATH=/root/reference \
         GPMP_BACKEND=torch python3 /root/repo/tests/golden/make_fullsize_fixtures.py config4      # ~15 min, ~31 GB
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg PYTHONPATH=/root/reference \
+        GPMP_BACKEND=numpy python3 /root/repo/tests/golden/make_fullsize_fixtures.py config4np    # after config4: ~10 min, ~15 GB
 
 config3 -> ref_config3_n32768.npz : the bench workload (d = 8, n = 32768, seeds 1234 / 4321), the reference's
            NumPy-backend `Model.predict` (core/model.py:227-307) at a seeded 2048-point subset of the 50000 bench targets and
@@ -17,6 +19,10 @@ config3 -> ref_config3_n32768.npz : the bench workload (d = 8, n = 32
 config4 -> ref_config4_n16384.npz : d = 20, n = 16384, rho_j in [0.5, 1.5]; the reference's torch-CPU backend: ML (zero mean)
            and REML (constant mean) criterion values + autograd gradients (num/torch_backend.py:574-604 through
            kernel/parameter_selection.py:35-124) at theta and at one perturbed parameter vector; cond(K) estimate.
+
+config4np -> adds to ref_config4_n16384.npz the criterion VALUES of the NumPy backend at the same parameter vectors (the
+           parity target BASELINE.json names; its `cdist` takes direct differences, the torch backend's expands the norms, so the
+           two reference backends agree to ~1e-10 only): ml_val_numpy, reml_val_numpy.
 
 Only inputs' seeds and outputs (plain arrays) are stored; no reference source is copied.
 """
@@ -29,7 +35,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 mode = sys.argv[1]
-backend = {"config3": "numpy", "config4": "torch"}[mode]
+backend = {"config3": "numpy", "config4": "torch", "config4np": "numpy"}[mode]
 os.environ["GPMP_BACKEND"] = backend
 os.environ.setdefault("GPMP_LOG_LEVEL", "WARNING")
 
@@ -143,4 +149,30 @@ def config4():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
-{"config3": config3, "config4": config4}[mode]()
+def config4np():
+    path = os.path.join(HERE, "ref_config4_n16384.npz")
+    g = dict(np.load(path))
+    n, d = int(g["n"]), int(g["d"])
+    rng = np.random.default_rng(1234)
+    xi = rng.random((n, d))
+    zi = np.sin(2 * np.pi * xi[:, 0]) + xi[:, 1:].sum(axis=1)
+    assert xi.sum() == float(g["xi_sum"]) and zi.sum() == float(g["zi_sum"])
+
+    def cm(x, param):
+        return gnp.ones((x.shape[0], 1))
+
+    mz = gp.core.Model(None, kernel, None, None, "zero")
+    mc = gp.core.Model(cm, kernel, None, None, "linear_predictor")
+    ml, reml = [], []
+    for t in g["thetas"]:
+        t0 = time.time()
+        ml.append(float(mz.negative_log_likelihood_zero_mean(t, xi, zi)))
+        reml.append(float(mc.negative_log_restricted_likelihood(t, xi, zi)))
+        print("numpy backend: ml %.15g reml %.15g  %.0f s, maxrss %.1f GB" % (ml[-1], reml[-1], time.time() - t0, rss_gb()), flush=True)
+    g["ml_val_numpy"], g["reml_val_numpy"] = np.array(ml), np.array(reml)
+    print("torch - numpy backend: ml", g["ml_val"] - g["ml_val_numpy"], "reml", g["reml_val"] - g["reml_val_numpy"])
+    np.savez_compressed(path, **g)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+{"config3": config3, "config4": config4, "config4np": config4np}[mode]()

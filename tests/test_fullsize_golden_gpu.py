@@ -1,0 +1,150 @@
+"""BASELINE configs 3 and 4 at their STATED sizes against vectors the REFERENCE ITSELF produced at those sizes
+(tests/golden/make_fullsize_fixtures.py, run in the build container: gpmp 0.9.37 imported from /root/reference).
+
+  config 3  d = 8, n = 32768: `Model.predict` (gpmp/core/model.py:227-307) at a seeded 2048-point subset of the 50000 bench
+            targets and `negative_log_likelihood_zero_mean` (gpmp/core/likelihood.py:18-52), NumPy backend
+            -> ref_config3_n32768.npz.  The HIP path predicts ALL 50000 points in one call (the bench step) and is compared on
+            the subset; a second call on the subset alone must agree with it.
+  config 4  d = 20, n = 16384: ML (zero mean) and REML (constant mean) criterion values + autograd gradients of the torch-CPU
+            backend (gpmp/num/torch_backend.py:574-604 through gpmp/kernel/parameter_selection.py:35-124) at two parameter
+            vectors -> ref_config4_n16384.npz; checked through the Python criteria AND the fused C driver gpmp_nll_grad.
+
+            Values are ALSO pinned by the NumPy backend at the same vectors (ml_val_numpy / reml_val_numpy: rel 1e-12); against the
+            torch backend's own values the bar is rel 1e-9 (its cdist expands the norms, as in tests/test_c_abi_mean_drivers_gpu.py).
+
+Tolerances are SURVEY 8(c)'s: value rel 1e-12, mean abs 1e-10 |z|_inf, variance abs 1e-10 sigma^2, gradient rel 1e-7, each
+times max(1, cond(K) / 1e6) with the cond(K) the generator measured on the reference's own matrix (power / inverse
+iteration; stored in the file).  Inputs are regenerated from the seeds and checked against stored checksums."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gpmp_amd
+
+    return gpmp_amd
+
+
+def _load(name):
+    path = os.path.join(GOLD, name)
+    if not os.path.exists(path):
+        pytest.fail(f"{name} is missing: generate it with tests/golden/make_fullsize_fixtures.py (build container)")
+    return np.load(path)
+
+
+# ---------------------------------------------------------------------------------------------- config 4
+def _config4_inputs(g):
+    n, d = int(g["n"]), int(g["d"])
+    rng = np.random.default_rng(1234)
+    xi = rng.random((n, d))
+    zi = np.sin(2 * np.pi * xi[:, 0]) + xi[:, 1:].sum(axis=1)
+    assert xi.sum() == float(g["xi_sum"]) and zi.sum() == float(g["zi_sum"])          # same inputs as the generator
+    return n, d, xi, zi
+
+
+@pytest.mark.parametrize("name", ["ml", "reml"])
+def test_config4_value_and_gradient_vs_reference_autograd_n16384_d20(gp, name):
+    import torch
+
+    import gpmp_amd.num as gnp
+    from gpmp_amd.core.gradients import MLZeroMeanAnalytic, REMLAnalytic
+
+    g = _load("ref_config4_n16384.npz")
+    n, d, xi, zi = _config4_inputs(g)
+    assert (n, d) == (16384, 20)
+    xid, zid = gnp.asarray(xi), gnp.asarray(zi)
+    cm = lambda x, p: gnp.ones((x.shape[0], 1))  # noqa: E731
+    if name == "ml":
+        crit = MLZeroMeanAnalytic(gp.Model(None, gp.kernel.MaternCovariance(2), None, g["thetas"][0], "zero"))
+    else:
+        crit = REMLAnalytic(gp.Model(cm, gp.kernel.MaternCovariance(2), None, g["thetas"][0], "linear_predictor"))
+    for k, th in enumerate(g["thetas"]):
+        lmax, lmin = g["lambda_max_min"][k]
+        scale = max(1.0, (lmax / lmin) / 1e6)
+        rv, rg = float(g[f"{name}_val"][k]), g[f"{name}_grad"][k]
+        value, state = crit.value_and_state(th, xid, zid)
+        grad = np.asarray(crit.gradient_from_state(state))
+        del state
+        torch.cuda.empty_cache()
+        assert abs(value - rv) < 1e-9 * scale * abs(rv), (name, k, value, rv)                 # torch backend (norm-expansion cdist)
+        rn = float(g[f"{name}_val_numpy"][k])
+        assert abs(value - rn) < 1e-12 * scale * abs(rn), (name, k, value, rn)                # NumPy backend: the parity target
+        assert np.max(np.abs(grad - rg)) < 1e-7 * scale * np.linalg.norm(rg), (name, k, np.max(np.abs(grad - rg)), np.linalg.norm(rg))
+
+
+@pytest.mark.parametrize("name", ["ml", "reml"])
+def test_config4_fused_c_driver_vs_reference_autograd_n16384_d20(gp, name):
+    """the same vectors through ONE call of gpmp_nll_grad (include/gpmp_hip.h), as a non-Python host would make it"""
+    import torch
+
+    import gpmp_amd.num as gnp
+    from gpmp_amd import _lib
+
+    lib = _lib.load()
+    g = _load("ref_config4_n16384.npz")
+    n, d, xi, zi = _config4_inputs(g)
+    dev = gnp._dev()
+    X, Z = torch.as_tensor(xi, device=dev), torch.as_tensor(zi, device=dev)
+    q = 0 if name == "ml" else 1
+    P = None if q == 0 else torch.ones((n, 1), dtype=torch.float64, device=dev)
+    ws = torch.empty(int(lib.gpmp_nll_grad_ws_elems(n, d, q)), dtype=torch.float64, device=dev)
+    val = torch.empty(1, dtype=torch.float64, device=dev)
+    gr = torch.empty(d + 1, dtype=torch.float64, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    for k, th in enumerate(g["thetas"]):
+        lmax, lmin = g["lambda_max_min"][k]
+        scale = max(1.0, (lmax / lmin) / 1e6)
+        _lib.check(lib.gpmp_nll_grad(gnp._ptr(X), gnp._ptr(Z), gnp._ptr(P), max(q, 1), n, d, q, 2, _lib.host_vec(th), 0, gnp._ptr(ws),
+                                     gnp._ptr(val), gnp._ptr(gr), gnp._ptr(info), gnp._stream()), "gpmp_nll_grad")
+        assert int(info.item()) == 0
+        rv, rg = float(g[f"{name}_val"][k]), g[f"{name}_grad"][k]
+        assert abs(float(val.item()) - rv) < 1e-9 * scale * abs(rv), (name, k, float(val.item()), rv)
+        rn = float(g[f"{name}_val_numpy"][k])
+        assert abs(float(val.item()) - rn) < 1e-12 * scale * abs(rn), (name, k, float(val.item()), rn)
+        err = np.max(np.abs(gr.cpu().numpy() - rg))
+        assert err < 1e-7 * scale * np.linalg.norm(rg), (name, k, err, np.linalg.norm(rg))
+
+
+# ---------------------------------------------------------------------------------------------- config 3
+def test_config3_predict_and_nll_vs_reference_n32768_m50000(gp):
+    import torch
+
+    import gpmp_amd.num as gnp
+
+    g = _load("ref_config3_n32768.npz")
+    n, m_all, d = int(g["n"]), int(g["m_all"]), int(g["d"])
+    assert (n, m_all, d) == (32768, 50000, 8)
+    rng = np.random.default_rng(1234)
+    xi = rng.random((n, d))
+    zi = np.sin(2 * np.pi * xi[:, 0]) + xi[:, 1:].sum(axis=1)
+    xt = np.random.default_rng(4321).random((m_all, d))
+    idx, th = g["idx"], g["theta"]
+    assert xi.sum() == float(g["xi_sum"]) and zi.sum() == float(g["zi_sum"]) and xt[idx].sum() == float(g["xt_sum"])
+    scale = max(1.0, float(g["lambda_max"]) / float(g["lambda_min"]) / 1e6)
+    s2 = math.exp(th[0])
+    model = gp.Model(None, gp.kernel.MaternCovariance(2), None, th, "zero")
+    xid, zid, xtd = gnp.asarray(xi), gnp.asarray(zi), gnp.asarray(xt)
+    # the bench step: all 50000 points in one call (1024-wide panels, look-ahead pieces, K >= 2048 LDS-direct updates, the ragged
+    # last column tile), compared on the reference's subset
+    zpm, zpv = model.predict(xid, zid, xtd, convert_in=False)
+    dm, dv = np.max(np.abs(zpm[idx] - g["zpm"])), np.max(np.abs(zpv[idx] - g["zpv"]))
+    assert dm < 1e-10 * scale * np.max(np.abs(zi)), (dm, scale)
+    assert dv < 1e-10 * scale * s2, (dv, scale)
+    torch.cuda.empty_cache()
+    nll = float(model.negative_log_likelihood_zero_mean(th, xid, zid))
+    assert abs(nll - float(g["nll"])) < 1e-12 * scale * abs(float(g["nll"])), (nll, float(g["nll"]), scale)
+    # the subset alone (m = 2048: other tile counts, same answers)
+    zpm2, zpv2 = model.predict(xid, zid, xtd[torch.as_tensor(idx, device=xtd.device)].contiguous(), convert_in=False)
+    assert np.max(np.abs(zpm2 - g["zpm"])) < 1e-10 * scale * np.max(np.abs(zi))
+    assert np.max(np.abs(zpv2 - g["zpv"])) < 1e-10 * scale * s2

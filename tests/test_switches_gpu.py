@@ -25,6 +25,9 @@ SETTINGS = [
     {"GPMP_POTRF_BLOCKED_BELOW": "100000"},
     {"GPMP_GEMM_SMALL_ROWS16_BELOW": "0"},
     {"GPMP_GEMM_SMALL_ROWS16_BELOW": "1000000"},
+    # (round 4) two-level 2048-column panels: binary blocking inside the panel, rank-2048 trailing updates, four look-ahead pieces
+    {"GPMP_POTRF_SUPER_ABOVE": "2048", "GPMP_POTRF_WIDE_ABOVE": "2048", "GPMP_POTRF_LA_SPLIT_ABOVE": "1024"},
+    {"GPMP_POTRF_SUPER_ABOVE": "2048", "GPMP_POTRF_WIDE_ABOVE": "2048", "GPMP_POTRF_LA_SPLIT": "0"},
 ]
 SOLVE_SETTINGS = [
     {},
@@ -38,6 +41,7 @@ SOLVE_SETTINGS = [
     {"GPMP_TRSM_FUSED_LEAF": "1", "GPMP_TRSM_LEAF_NARROW_BELOW": "0"},
     {"GPMP_POTRF_ALONG_RIGHT": "0"},                  # (round 3) left-looking updates in the panel-by-panel solve
     {"GPMP_POTRF_ALONG_RIGHT": "0", "GPMP_POTRF_ALONG_ROWS": "512"},
+    {"GPMP_POTRF_SUPER_ABOVE": "2048", "GPMP_POTRF_WIDE_ABOVE": "2048"},      # (round 4) 2048-column panels under the panel-by-panel solve
 ]
 
 

@@ -47,6 +47,10 @@ int main(int argc, char** argv) {
   if (which < 0 || which == 8) run("panel scale N=128 K=128", 0, 1, 32640, 128, 128, 0, 0.0, reps);
   if (which == 30) { for (int M : {128, 1024, 4096, 32640}) { run("panel scale NT N=128 K=128 b0", 0, 1, M, 128, 128, 0, 0.0, reps); run("rank-128 update NT N=384 b1", 0, 1, M, 384, 128, 0, 1.0, reps); run("NN K=128 N=4096 b1", 0, 0, M, 4096, 128, 0, 1.0, reps); } }
   if (which == 40) { for (int M : {3584, 3072, 2560, 2048, 1792, 1536, 1024, 512}) run("syrk trailing, chain-bound tail K=256", 0, 1, M, M, 256, 1, 1.0, reps); }
+  // the triangular solve's updates of the headline step (B2 -= L21 X1: M = K = R rows, N = 50000) and the Cholesky's trailing
+  // updates at rank 1024 / 2048 -- the shapes whose L2-side traffic DESIGN section 4 discusses (run under rocprofv3 --pmc FETCH_SIZE)
+  if (which == 50) { for (int R : {16384, 8192, 4096, 2048}) run("solve update NN M=K=R N=50000", 0, 0, R, 50000, R, 0, 1.0, reps); }
+  if (which == 51) { for (int K : {1024, 2048}) run("potrf trailing NT lower M=N=24576", 0, 1, 24576, 24576, K, 1, 1.0, reps); }
   if (which == 20) { for (int K : {128, 256, 512, 1024, 2048, 4096}) { run("NN beta=1 K sweep", 0, 0, 16384, 16384, K, 0, 1.0, reps); run("NN beta=0 K sweep", 0, 0, 16384, 16384, K, 0, 0.0, reps); } }
   return 0;
 }
