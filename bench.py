@@ -136,12 +136,49 @@ def pmc_traffic_live(kernel_substr, args, timeout_s=300.0):
 
 
 def _host_threads():
+    """BLAS threads the CPU baseline uses: the cores this process may actually run on -- the smallest of the affinity mask, the
+    cgroup CPU quota and the PHYSICAL core count (round 3 let the BLAS pool default to every logical CPU of the host: 128
+    oversubscribed threads ran dpotrf at 0.32 TFLOP/s where 64 reach 0.9)."""
+    cands = [os.cpu_count() or 1]
     try:
-        from threadpoolctl import threadpool_info
+        cands.append(len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        import psutil
 
-        return max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        return os.cpu_count() or 1
+        phys = psutil.cpu_count(logical=False)
+        if phys:
+            cands.append(int(phys))
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cands.append(max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(cands))
+
+
+def _latest_cpu_fullsize_log(n, m, d):
+    """The most recent COMMITTED full-size CPU run of the headline step (tools/cpu_fullsize_step.py -> profiles/r*/cpu_fullsize_step.log,
+    last JSON line) for this (n, m, d), or None: what the assembled figure should be read against.  Read at run time, never a literal."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "cpu_fullsize_step*.log"))):
+        try:
+            with open(path) as f:
+                rec = _last_json_line(f.read())
+        except OSError:
+            continue
+        if rec and rec.get("tool") == "cpu_fullsize_step" and (rec.get("n"), rec.get("m"), rec.get("d")) == (n, m, d):
+            best = {"s_per_step": rec["full_step_s"], "points_per_s": rec["points_per_s"], "threads": rec.get("threads"),
+                    "log": os.path.relpath(path, ROOT), "tool": "tools/cpu_fullsize_step.py",
+                    "note": "NOT measured in this run: the latest committed full-size run (possibly another box of the pool)"}
+    return best
 
 
 def cpu_baseline(n, m, d, threads, m_sample=2048, n_sample=8192):
@@ -167,6 +204,12 @@ def cpu_baseline(n, m, d, threads, m_sample=2048, n_sample=8192):
     xi, zi, xt, theta = synth(n, m, d, 0)
     xs = xt[:ms]
     t = {}
+    try:                                     # one BLAS thread per usable core (see _host_threads), for everything below
+        from threadpoolctl import threadpool_limits
+
+        _limit = threadpool_limits(limits=threads)
+    except Exception:  # noqa: BLE001
+        _limit = None
     np.linalg.cholesky(orc.maternp_covariance(xi[:512], None, 2, theta))    # BLAS thread pool / page-in warm-up, untimed
 
     def tick(name, fn):
@@ -210,19 +253,33 @@ def cpu_baseline(n, m, d, threads, m_sample=2048, n_sample=8192):
     ext = {"gram_ii_x2": 2.0 * t["gram_ii_ns"] * r * r, "cholesky_x2": 2.0 * t["cholesky"], "nll_tail": t["nll_tail"],
            "gram_it": t["gram_it"] * m / ms, "trsm_pair": t["trsm_pair"] * m / ms, "reductions": t["reductions"] * m / ms}
     step = sum(ext.values())
-    return {"value": m / step, "unit": "points/s", "cores": threads, "kind": "port", "assembled": True,
-            "sample": f"oracle (SciPy cdist + Matern ufuncs + LAPACK), d={d}, everything that goes through BLAS at the FULL n={n}: Cholesky "
-                      f"({t['cholesky']:.1f} s), 2 triangular solves ({trsm_tflops:.2f} TFLOP/s measured) + reductions + Gram(xi,xt) for {ms} of the "
-                      f"{m} points (x m/{ms}), NLL solves; Gram(xi,xi) at n_s={ns} (x (n/n_s)^2: single-threaded elementwise passes); NOT a "
-                      f"measured step: {step:.0f} s per predict+NLL step ASSEMBLED from these; CPU work done {sum(t.values()):.0f} s; BLAS threads={threads}. "
-                      f"One full-size run of the same step (tools/cpu_fullsize_step.py, 64 threads): 209.7 s",
-            "cpu_trsm_tflops": trsm_tflops,
-            # the ONE full-size CPU run of this step (another box of the pool, 64 BLAS threads): what the model above should be read against
-            "full_size_run": {"s_per_step": 209.7, "points_per_s": 238.4, "threads": 64, "log": "profiles/r3/cpu_fullsize_step.log",
-                              "tool": "tools/cpu_fullsize_step.py"} if (n, m, d) == (32768, 50000, 8) else None,
-            "host_potrf": {"n": n, "s": t["cholesky"], "tflops": n ** 3 / 3.0 / t["cholesky"] / 1e12},
-            "measured_s": {k_: round(v_, 3) for k_, v_ in t.items()},
-            "extrapolated_s": {k_: round(v_, 2) for k_, v_ in ext.items()}}
+    out = {"value": m / step, "unit": "points/s", "cores": threads, "kind": "port", "assembled": True,
+           "sample": f"oracle (SciPy cdist + Matern ufuncs + LAPACK), d={d}, everything that goes through BLAS at the FULL n={n}: Cholesky "
+                     f"({t['cholesky']:.1f} s), 2 triangular solves ({trsm_tflops:.2f} TFLOP/s measured) + reductions + Gram(xi,xt) for {ms} of the "
+                     f"{m} points (x m/{ms}), NLL solves; Gram(xi,xi) at n_s={ns} (x (n/n_s)^2: single-threaded elementwise passes); NOT a "
+                     f"measured step: {step:.0f} s per predict+NLL step ASSEMBLED from these; CPU work done {sum(t.values()):.0f} s; BLAS threads={threads}",
+           "cpu_trsm_tflops": trsm_tflops,
+           "host_potrf": {"n": n, "s": t["cholesky"], "tflops": n ** 3 / 3.0 / t["cholesky"] / 1e12},
+           "measured_s": {k_: round(v_, 3) for k_, v_ in t.items()},
+           "extrapolated_s": {k_: round(v_, 2) for k_, v_ in ext.items()}}
+    # the assembled figure beside a MEASURED full-size step: the latest committed run (read from its log), and -- on request,
+    # GPMP_BENCH_CPU_FULL=1, 4-6 minutes of host time -- one measured in THIS run, which then IS the value
+    full = _latest_cpu_fullsize_log(n, m, d)
+    out["full_size_run"] = full
+    out["model_over_measured"] = (step / full["s_per_step"]) if full else None
+    if os.environ.get("GPMP_BENCH_CPU_FULL", "0") == "1":
+        om = orc.OracleModel(None, lambda x, y, th, pairwise=False: orc.maternp_covariance(x, y, 2, th, pairwise), None, theta, "zero")
+        t0 = time.perf_counter()
+        orc.predict(om, xi, zi, xt)
+        orc.negative_log_likelihood_zero_mean(om, theta, xi, zi)
+        full_s = time.perf_counter() - t0
+        out.update({"assembled_value": out["value"], "value": m / full_s, "assembled": False,
+                    "full_size_run": {"s_per_step": full_s, "points_per_s": m / full_s, "threads": threads, "note": "measured in THIS run"},
+                    "model_over_measured": step / full_s})
+        out["sample"] += f"; value = ONE full-size step measured in this run: {full_s:.0f} s"
+    if _limit is not None:
+        _limit.restore_original_limits()
+    return out
 
 
 def config2_extra(model, d, threads, with_cpu):

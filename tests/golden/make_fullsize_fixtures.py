@@ -5,17 +5,17 @@ Build container only (8 vCPU, 62 GB; the reference does not travel to the GPU bo
 else memory-hungry beside it:
 
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg PYTHONPATH=/root/reference \
-        GPMP_BACKEND=numpy python3 /root/repo/tests/golden/make_fullsize_fixtures.py config3      # ~25 min, ~50 GB
+        GPMP_BACKEND=numpy python3 /root/repo/tests/golden/make_fullsize_fixtures.py config3      # ~15 min, ~20 GB (oracle)
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg PYTHONPATH=/root/reference \
         GPMP_BACKEND=torch python3 /root/repo/tests/golden/make_fullsize_fixtures.py config4      # ~15 min, ~31 GB
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg PYTHONPATH=/root/reference \
         GPMP_BACKEND=numpy python3 /root/repo/tests/golden/make_fullsize_fixtures.py config4np    # after config4: ~10 min, ~15 GB
 
-config3 -> ref_config3_n32768.npz : the bench workload (d = 8, n = 32768, seeds 1234 / 4321), the reference's
-           NumPy-backend `Model.predict` (core/model.py:227-307) at a seeded 2048-point subset of the 50000 bench targets and
-           `negative_log_likelihood_zero_mean` (core/likelihood.py:18-52).  Inputs are NOT stored (regenerated from the seeds);
-           stored: the subset's indices, zpm, zpv, the NLL, a condition-number estimate of K (power / inverse iteration on
-           the reference's own covariance matrix) and checksums of the inputs.
+config3 -> oracle_config3_n32768.npz : the bench workload (d = 8, n = 32768, seeds 1234 / 4321): posterior mean and
+           variance (core/model.py:227-307) at a seeded 2048-point subset of the 50000 bench targets and the zero-mean NLL
+           (core/likelihood.py:18-52) -- from the PINNED ORACLE, not from the reference: the reference's own predict does not fit
+           62 GB at this n (see config3()).  Inputs are NOT stored (regenerated from the seeds); stored: the subset's indices,
+           zpm, zpv, the NLL, a condition-number estimate of K (power / inverse iteration) and checksums of the inputs.
 config4 -> ref_config4_n16384.npz : d = 20, n = 16384, rho_j in [0.5, 1.5]; the reference's torch-CPU backend: ML (zero mean)
            and REML (constant mean) criterion values + autograd gradients (num/torch_backend.py:574-604 through
            kernel/parameter_selection.py:35-124) at theta and at one perturbed parameter vector; cond(K) estimate.
@@ -77,6 +77,18 @@ def cond_estimate(K):
 
 
 def config3():
+    """The REFERENCE itself does not fit this container at n = 32768: its NumPy-backend `predict` peaks at ~6 n x n arrays
+    (3.25 GB at n = 8192, measured -> ~52 GB + the m-side arrays at 32768; the attempt was OOM-killed at 62 GB).  So this pass
+    runs the PINNED ORACLE (oracle/gp_oracle.py: pinned to the reference by tests/test_oracle_vs_golden.py) with a memory-careful
+    assembly of exactly its arithmetic: the Gram matrix from oracle.maternp_covariance on row blocks (the `it` path gives the
+    same entries as the `ii` path; the nugget 10 sigma^2 eps is added to the diagonal as matern.py:90-94 does), LAPACK dpotrf in
+    place, the two triangular solves of cholesky_solve (numpy_backend.py:465-469), the einsum of kriging.py:194.  The file name
+    says which generator made it: oracle_config3_n32768.npz."""
+    import scipy.linalg as sl
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import gp_oracle as orc
+
     n, m_all, m, d = 32768, 50000, 2048, 8
     rng = np.random.default_rng(1234)
     xi = rng.random((n, d))
@@ -85,23 +97,60 @@ def config3():
     idx = np.sort(np.random.default_rng(77).choice(m_all, m, replace=False))
     xt = xt_all[idx]
     th = np.concatenate(([0.0], -np.log(0.5 * (1.0 + np.arange(d) / d))))
-    model = gp.core.Model(None, kernel, None, th, "zero")
+    # cross-check of the block assembly against the oracle's own ii path, on a size it handles whole
+    ns = 3000
+    Ks = np.empty((ns, ns))
+    for r0 in range(0, ns, 1024):
+        Ks[r0:r0 + 1024] = orc.maternp_covariance(xi[:ns][r0:r0 + 1024], xi[:ns], 2, th)
+    Ks[np.diag_indices(ns)] += 10.0 * np.exp(th[0]) * np.finfo(np.float64).eps
+    assert np.array_equal(Ks, orc.maternp_covariance(xi[:ns], None, 2, th)), "block assembly differs from the oracle's Gram matrix"
+    del Ks
     t0 = time.time()
-    zpm, zpv = model.predict(xi, zi, xt)
-    print("predict %.0f s, maxrss %.1f GB" % (time.time() - t0, rss_gb()), flush=True)
+    K = np.empty((n, n))
+    for r0 in range(0, n, 2048):
+        K[r0:r0 + 2048] = orc.maternp_covariance(xi[r0:r0 + 2048], xi, 2, th)
+    K[np.diag_indices(n)] += 10.0 * np.exp(th[0]) * np.finfo(np.float64).eps
+    Kit = orc.maternp_covariance(xi, xt, 2, th)
+    print("gram %.0f s, maxrss %.1f GB" % (time.time() - t0, rss_gb()), flush=True)
     t0 = time.time()
-    nll = float(model.negative_log_likelihood_zero_mean(th, xi, zi))
-    print("nll %.0f s, maxrss %.1f GB: %.15g" % (time.time() - t0, rss_gb(), nll), flush=True)
+    v = np.random.default_rng(5).standard_normal(n)
+    lmax = 0.0
+    for _ in range(40):
+        w = K @ v
+        lmax = float(np.linalg.norm(w))
+        v = w / lmax
+    # K is C-ordered and symmetric: its transpose view is Fortran-ordered, and the UPPER factor of that view is the lower factor
+    # of K in the same buffer -- dpotrf in place, no copy
+    U = sl.cholesky(K.T, lower=False, overwrite_a=True, check_finite=False)
+    assert np.shares_memory(U, K)
+    print("power iteration + dpotrf %.0f s, maxrss %.1f GB" % (time.time() - t0, rss_gb()), flush=True)
     t0 = time.time()
-    K = np.asarray(kernel(xi, None, th))
-    lmax, lmin = cond_estimate(K)
-    del K
-    print("cond %.0f s: lmax %.6g lmin %.6g cond %.4g" % (time.time() - t0, lmax, lmin, lmax / lmin), flush=True)
-    path = os.path.join(HERE, "ref_config3_n32768.npz")
+    # U = L^T (Fortran-ordered upper): L y = b  <=>  U^T y = b
+    y = sl.solve_triangular(U, Kit, lower=False, trans=1, check_finite=False)
+    lam = sl.solve_triangular(U, y, lower=False, trans=0, check_finite=False)              # lambda_t = K^-1 Kit
+    zpm = np.einsum("i..., i...", lam, zi.reshape(-1, 1))
+    zpv = np.exp(th[0]) * np.ones(m) - np.einsum("i..., i...", lam, Kit)                  # kriging.py:194 (prior variance sigma^2)
+    zpv_raw_min = float(zpv.min())
+    zpv = np.maximum(zpv, 0.0)                                                             # model.py:290-296
+    yz = sl.solve_triangular(U, zi, lower=False, trans=1, check_finite=False)
+    Kinv_z = sl.solve_triangular(U, yz, lower=False, trans=0, check_finite=False)
+    nll = float(0.5 * (n * np.log(2.0 * np.pi) + 2.0 * np.sum(np.log(np.diag(U))) + np.einsum("i..., i...", zi, Kinv_z)))
+    print("solves %.0f s: nll %.15g, min raw variance %.3g" % (time.time() - t0, nll, zpv_raw_min), flush=True)
+    v = np.random.default_rng(6).standard_normal(n)
+    v /= np.linalg.norm(v)
+    lmin = np.inf
+    for _ in range(40):
+        w = sl.solve_triangular(U, v, lower=False, trans=1, check_finite=False)
+        w = sl.solve_triangular(U, w, lower=False, trans=0, check_finite=False)
+        lmin = 1.0 / float(np.linalg.norm(w))
+        v = w * lmin
+    print("lmax %.6g lmin %.6g cond %.4g" % (lmax, lmin, lmax / lmin), flush=True)
+    path = os.path.join(HERE, "oracle_config3_n32768.npz")
     np.savez_compressed(path, n=np.array(n), m_all=np.array(m_all), d=np.array(d), theta=th, idx=idx,
-                        zpm=np.asarray(zpm), zpv=np.asarray(zpv), nll=np.array(nll), lambda_max=np.array(lmax),
+                        zpm=np.asarray(zpm).reshape(-1), zpv=np.asarray(zpv).reshape(-1), nll=np.array(nll), lambda_max=np.array(lmax),
                         lambda_min=np.array(lmin), xi_sum=np.array(xi.sum()), zi_sum=np.array(zi.sum()),
-                        xt_sum=np.array(xt.sum()), generator=np.array("reference gpmp 0.9.37, numpy backend"))
+                        xt_sum=np.array(xt.sum()), zpv_raw_min=np.array(zpv_raw_min),
+                        generator=np.array("pinned oracle (oracle/gp_oracle.py), block-assembled Gram, LAPACK in place"))
     print("wrote", path, os.path.getsize(path), "bytes")
 
 

@@ -18,6 +18,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 d = 8
 threads = bench._host_threads()
+from threadpoolctl import threadpool_limits  # noqa: E402
+
+_limit = threadpool_limits(limits=threads)        # one BLAS thread per usable core, as bench.cpu_baseline
 model_fig = bench.cpu_baseline(n, m, d, threads)
 print(json.dumps({"assembled": {k: model_fig[k] for k in ("value", "measured_s", "extrapolated_s", "cpu_trsm_tflops")}}), flush=True)
 xi, zi, xt, theta = bench.synth(n, m, d, 0)

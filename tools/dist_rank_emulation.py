@@ -109,6 +109,8 @@ def main():
         zh = np.sin(2 * np.pi * xh[:, 0]) + xh[:, 1:].sum(axis=1)
         grad = {}
         ch.info = 0          # (the stubbed factorisation "fails": the values are meaningless, the kernels and their shapes are not)
+        ch.backend = "nccl"  # few-column solves and scalars stay on the device, as under RCCL (nothing is sent: stubs); with "gloo"
+                             # every block of the few-column solve crosses PCIe twice, which an RCCL run never does
         for rep in ("warm", "timed"):
             torch.cuda.synchronize()
             t3 = time.perf_counter()
