@@ -119,10 +119,13 @@ def config3():
         w = K @ v
         lmax = float(np.linalg.norm(w))
         v = w / lmax
-    # K is C-ordered and symmetric: its transpose view is Fortran-ordered, and the UPPER factor of that view is the lower factor
-    # of K in the same buffer -- dpotrf in place, no copy
-    U = sl.cholesky(K.T, lower=False, overwrite_a=True, check_finite=False)
-    assert np.shares_memory(U, K)
+    # numpy.linalg.cholesky (its own ILP64 OpenBLAS; a copy: K stays for the residual checks below).  SciPy's LP64 dpotrf in
+    # place FAILS at exactly this size ("16545-th leading minor not positive definite": 16384 * 32768 * 8 bytes = 2^32 -- an
+    # offset overflow in that build, not the matrix: n = 20000 and 8192 give identical log-determinants on both routes), so the
+    # factor comes from the routine the reference itself calls (numpy_backend.py:136,466) and every solve below is verified
+    # by its residual against K.
+    L = np.linalg.cholesky(K)
+    U = L.T                                    # Fortran-ordered upper view of the same buffer: no copy inside SciPy's trtrs wrapper
     print("power iteration + dpotrf %.0f s, maxrss %.1f GB" % (time.time() - t0, rss_gb()), flush=True)
     t0 = time.time()
     # U = L^T (Fortran-ordered upper): L y = b  <=>  U^T y = b
@@ -136,6 +139,13 @@ def config3():
     Kinv_z = sl.solve_triangular(U, yz, lower=False, trans=0, check_finite=False)
     nll = float(0.5 * (n * np.log(2.0 * np.pi) + 2.0 * np.sum(np.log(np.diag(U))) + np.einsum("i..., i...", zi, Kinv_z)))
     print("solves %.0f s: nll %.15g, min raw variance %.3g" % (time.time() - t0, nll, zpv_raw_min), flush=True)
+    t0 = time.time()
+    res_l = float(np.max(np.abs(K @ lam - Kit)))                                           # K lambda_t = Kit
+    res_z = float(np.max(np.abs(K @ Kinv_z - zi)))
+    print("residuals %.0f s: max|K lam - Kit| %.3g (max|Kit| %.3g), max|K K^-1 z - z| %.3g (max|z| %.3g)"
+          % (time.time() - t0, res_l, float(np.max(np.abs(Kit))), res_z, float(np.max(np.abs(zi)))), flush=True)
+    assert res_l < 1e-6 and res_z < 1e-5, "a host solve is wrong (LP64 overflow?): fixture not written"
+    del K
     v = np.random.default_rng(6).standard_normal(n)
     v /= np.linalg.norm(v)
     lmin = np.inf
@@ -149,7 +159,8 @@ def config3():
     np.savez_compressed(path, n=np.array(n), m_all=np.array(m_all), d=np.array(d), theta=th, idx=idx,
                         zpm=np.asarray(zpm).reshape(-1), zpv=np.asarray(zpv).reshape(-1), nll=np.array(nll), lambda_max=np.array(lmax),
                         lambda_min=np.array(lmin), xi_sum=np.array(xi.sum()), zi_sum=np.array(zi.sum()),
-                        xt_sum=np.array(xt.sum()), zpv_raw_min=np.array(zpv_raw_min),
+                        xt_sum=np.array(xt.sum()), zpv_raw_min=np.array(zpv_raw_min), residual_lambda=np.array(res_l),
+                        residual_kinv_z=np.array(res_z),
                         generator=np.array("pinned oracle (oracle/gp_oracle.py), block-assembled Gram, LAPACK in place"))
     print("wrote", path, os.path.getsize(path), "bytes")
 
