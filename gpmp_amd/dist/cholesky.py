@@ -133,6 +133,14 @@ class HipLocalOps:
         self._lib.check(self.lib.gpmp_trsm_lower(g._ptr(L), L.shape[0], g._ld(L), g._ptr(dinv), g._ptr(B), B.shape[1], g._ld(B), 0, None,
                                                  g._stream()), "gpmp_trsm_lower")
 
+    def trsm_left_t(self, L, dinv, B):
+        """B <- L^-T B in place (B: k x m view, L: k x k lower)."""
+        g = self.gnp
+        if B.shape[1] == 0:
+            return
+        self._lib.check(self.lib.gpmp_trsm_lower(g._ptr(L), L.shape[0], g._ld(L), g._ptr(dinv), g._ptr(B), B.shape[1], g._ld(B), 1, None,
+                                                 g._stream()), "gpmp_trsm_lower")
+
     def gemm_nn_sub(self, C, A, B):
         """C -= A B  (C: M x N view, A: M x K, B: K x N)."""
         g = self.gnp
@@ -525,6 +533,15 @@ class BlockCyclicCholesky:
     def _all_reduce(self, t: torch.Tensor, op, group, what: str):
         self._log(group, f"all_reduce:{what}", -1, t.numel())
         dist.all_reduce(t, op=op, group=group)
+        return t
+
+    def _reduce(self, t: torch.Tensor, dst_rank: int, group, what: str):
+        """Sum of ``t`` over ``group`` delivered to ``dst_rank`` (the other members' buffers are left unspecified)."""
+        ct = _comm_tensor(t, self.backend)
+        self._log(group, f"reduce:{what}", dst_rank, ct.numel())
+        dist.reduce(ct, dst=dst_rank, op=dist.ReduceOp.SUM, group=group)
+        if self.grid.rank == dst_rank and ct.data_ptr() != t.data_ptr():
+            t.copy_(ct)
         return t
 
     # ---- factorisation
@@ -1026,11 +1043,73 @@ class BlockCyclicCholesky:
         st.close()
         return Bloc
 
+    def solve_upper_many(self, Bloc: torch.Tensor) -> torch.Tensor:
+        """X = L^-T B in place for a right-hand side distributed like ``solve_lower_many``'s (rows block-cyclic over the process
+        rows, columns sharded over the process columns): the SECOND solve of ``cholesky_solve`` (gpmp/num/numpy_backend.py:468),
+        which the kriging WEIGHTS lambda_t = L^-T (L^-1 Kit) need (gpmp/core/kriging.py:62, model.py:305-306).  Left-looking
+        backward substitution over the block columns k = nblk-1 ... 0:
+            S_k = sum_{I > k} L_Ik^T X_I  -- every rank multiplies ITS rows of panel k (row-broadcast from process column k mod Pc,
+                                             as in the forward solve) with ITS rows of X, a TN product with a long contraction;
+                                             the partial sums are REDUCED inside the process column to process row k mod Pr
+            X_k = L_kk^-T (B_k - S_k)     -- on process row k mod Pr (L_kk row-broadcast as in the forward solve)
+        X_k is used only where it lives, so nothing is broadcast back: per step one diagonal message + one panel along the process
+        rows and one (bk x m_c) reduce inside each process column.  n^2 m flops, in order on the caller's stream (the weights are an
+        on-request by-product, not the throughput path)."""
+        g, ops, nb = self.grid, self.ops, self.nb
+        mloc = Bloc.shape[1]
+        nblk = self.nblocks
+        row_members = [g.rank_of(g.r, cc) for cc in range(g.pc)]
+        nbk = self.bs(0)
+        ld0 = (nbk + 15) // 16 * 16
+        nd0 = ((nbk + 127) // 128) * 128 * 128
+        Lbuf = self._flat(nbk * ld0 + nd0)
+        Pbuf = ops.empty(self.local_rows(), nb)
+        Sbuf = ops.empty(nb, mloc)
+        for k in range(nblk - 1, -1, -1):
+            rd, cd = g.owner_row(k), g.owner_col(k)
+            bk = self.bs(k)
+            ldk = (bk + 15) // 16 * 16
+            ndinv = ((bk + 127) // 128) * 128 * 128
+            buf = Lbuf[: bk * ldk + ndinv]
+            Lkk, dinv = buf[: bk * ldk].view(bk, ldk)[:, :bk], buf[bk * ldk:]
+            self._step_label = f"bsolve{k}"
+            if g.r == rd:
+                if g.c == cd:
+                    L0, d0 = self.diag_cache[k]
+                    Lkk.copy_(L0)
+                    dinv.copy_(d0[: dinv.numel()])
+                if g.pc > 1:
+                    self._bcast(buf, g.rank_of(rd, cd), g.row_group, row_members)
+            i0 = self._first_row_after(k)
+            Mr = self.roff[-1] - self.roff[i0]
+            S = Sbuf[:bk, :]
+            if Mr > 0:
+                panel = Pbuf[:Mr, :bk]
+                if g.c == cd:
+                    lj = k // g.pc
+                    panel.copy_(self.A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]])
+                if g.pc > 1:
+                    self._bcast(panel, g.rank_of(g.r, cd), g.row_group, row_members)
+                if mloc:
+                    ops.gemm_tn_into(panel, Bloc[self.roff[i0]:, :], S)
+            elif mloc:
+                S.zero_()
+            if not mloc:
+                continue
+            if g.pr > 1:
+                self._reduce(S, g.rank_of(rd, g.c), g.col_group, "bsolve")
+            if g.r == rd:
+                li = k // g.pr
+                Bk = Bloc[self.roff[li]:self.roff[li + 1], :]
+                Bk.sub_(S)
+                ops.trsm_left_t(Lkk, dinv, Bk)
+        return Bloc
+
     def predict_zero_mean(self, cov, x, z, xt, covparam):
         """Zero-mean kriging from the distributed factor: see ``predict`` (no mean design)."""
         return self.predict(cov, x, z, xt, covparam)
 
-    def predict(self, cov, x, z, xt, covparam, P=None, Pt=None):
+    def predict(self, cov, x, z, xt, covparam, P=None, Pt=None, return_lambdas=False):
         """Posterior mean and variance at xt from the distributed factor of K(x, x).  Zero mean (P None:
         gpmp/core/kriging.py:35-67,170-199) restated as ONE solve, V = L^-1 K(x, xt), mean = V^T (L^-1 z),
         var = k(xt, xt) - colsumsq(V); with a linear predictor (universal kriging, kriging.py:70-116; P: n x q mean design at
@@ -1040,7 +1119,9 @@ class BlockCyclicCholesky:
         The prediction points are split over the process COLUMNS, the rows of V over the process ROWS; the local block
         K(x[rows owned], xt[column shard]) is one Gram call, and the only reductions are (2 + q) x m_c all-reduced inside each
         process column.  Returns (mean, variance, (j0, j1)): this process column's shard of the results (identical on the
-        ranks of one process column), as NumPy arrays."""
+        ranks of one process column), as NumPy arrays.  ``return_lambdas=True`` appends the kriging weights of model.py:305-306 as
+        this RANK's block (local rows ``global_row_index()`` x prediction points j0:j1, device tensor):
+        lambda = L^-T (V - Wp mu) -- the second solve of cholesky_solve, ``solve_upper_many``; V is consumed."""
         from .predict import shard_bounds
 
         if self.info:
@@ -1079,6 +1160,12 @@ class BlockCyclicCholesky:
             mu = np.linalg.solve(0.5 * (S + S.T), R)
             mean = mean - (Wp.T @ wz) @ mu
             reduction = reduction - np.sum(mu * R, axis=0)
+        if return_lambdas:
+            if q and len(ri) and j1 > j0:
+                # V <- V - Wp mu (rows owned x my points): a rank-q product on the library GEMM
+                ops.gemm_nn_sub(V, ops.asarray(W[torch.as_tensor(ri, device=W.device)][:, 1:].contiguous()), ops.asarray(torch.as_tensor(mu)))
+            lam = self.solve_upper_many(V)
+            return mean, prior.cpu().numpy() - reduction, (j0, j1), lam
         return mean, prior.cpu().numpy() - reduction, (j0, j1)
 
     def negative_log_likelihood(self, z) -> float:

@@ -6,7 +6,8 @@ one GPU's HBM: every rank of the process grid makes the SAME call with the SAME 
 same full-length NumPy results back.  What differs from the single-GPU model: a covariance callable is evaluated on
 blocks (cross-covariance calls on subsets of the points), the diagonal term -- the nugget 10 sigma^2 eps of
 gpmp/kernel/matern.py:90, or the noise variance of a ``MaternCovariance(noise=True)`` -- is added by the model, and
-``return_lambdas`` is not offered (the n x m weights are the one object that is never formed here).
+``return_lambdas`` (round 4: the second solve of cholesky_solve on the block-cyclic factor, ``solve_upper_many``) comes either as
+the full n x m host matrix on every rank or, ``return_lambdas="local"``, as this rank's block.
 """
 from __future__ import annotations
 
@@ -69,9 +70,12 @@ class DistributedModel:
         return out
 
     # ---- the Model surface
-    def predict(self, xi, zi, xt, zero_neg_variances=True):
+    def predict(self, xi, zi, xt, return_lambdas=False, zero_neg_variances=True):
         """Posterior mean and variance at xt (gpmp/core/model.py:227-307): zero mean, parameterized mean (centred
-        observations + prior mean at xt) or linear predictor (universal kriging)."""
+        observations + prior mean at xt) or linear predictor (universal kriging).  ``return_lambdas`` (model.py:305-306):
+        True appends the kriging weights lambda_t as the FULL n x m NumPy matrix on every rank (an all-gather of n x m
+        doubles: meant for the sizes a host array holds); "local" appends this rank's block instead, as
+        (device tensor, global row indices, (j0, j1)) -- the form that scales."""
         xi, xt = np.asarray(xi, dtype=np.float64), np.asarray(xt, dtype=np.float64)
         zi = np.asarray(zi, dtype=np.float64).reshape(-1)
         ch = self._factor(xi, self.covparam)
@@ -82,12 +86,24 @@ class DistributedModel:
             prior = self._design(xt).reshape(-1)
         elif self.meantype == "linear_predictor":
             P, Pt = self._design(xi), self._design(xt)
-        mean, var, (j0, j1) = ch.predict(self.covariance, xi, zi, xt, self.covparam, P=P, Pt=Pt)
+        out = ch.predict(self.covariance, xi, zi, xt, self.covparam, P=P, Pt=Pt, return_lambdas=bool(return_lambdas))
+        mean, var, (j0, j1) = out[:3]
         zpm, zpv = self._gather(np.arange(j0, j1), mean, var)
         if np.any(zpv < 0.0):
             warnings.warn("Negative variances detected. Consider using jitter.", RuntimeWarning)       # model.py:290-296
         if zero_neg_variances:
             zpv = np.maximum(zpv, 0.0)
+        if return_lambdas:
+            lam, ri = out[3], ch.global_row_index()
+            if return_lambdas == "local":
+                return zpm + prior, zpv, (lam, ri, (j0, j1))
+            parts = [None] * self.grid.world
+            dist.all_gather_object(parts, (np.asarray(ri), (j0, j1), lam.cpu().numpy()), group=self.grid.world_group)
+            full = np.zeros((xi.shape[0], xt.shape[0]))
+            for rows, (a, b), blk in parts:
+                if len(rows) and b > a:
+                    full[np.ix_(rows, np.arange(a, b))] = blk
+            return zpm + prior, zpv, full
         return zpm + prior, zpv
 
     def loo(self, xi, zi):

@@ -47,6 +47,10 @@ class CpuLocalOps:
         if B.numel():
             B.copy_(torch.linalg.solve_triangular(torch.tril(L), B, upper=False))
 
+    def trsm_left_t(self, L, dinv, B):
+        if B.numel():
+            B.copy_(torch.linalg.solve_triangular(torch.tril(L).T, B, upper=True))
+
     def gemm_nn_sub(self, C, A, B):
         if C.numel():
             C.sub_(A @ B)

@@ -156,16 +156,23 @@ def _dist_predict_worker(rank, world, port, pr, pc, n, m, nb, out, transport):
         ch.build_local_gram(_cov, x, th, 1e-6)
         assert ch.factor() == 0
         mean, var, (j0, j1) = ch.predict_zero_mean(_cov_full, x, z, xt, th)
+        # (round 4) the kriging weights from the backward solve on the same factor; mean / variance must not change
+        mean2, var2, (a2, b2), lam_loc = ch.predict(_cov_full, x, z, xt, th, return_lambdas=True)
+        assert (a2, b2) == (j0, j1) and np.array_equal(mean2, mean) and np.array_equal(var2, var)
         gathered = [None] * world
-        dist.all_gather_object(gathered, (grid.r, grid.c, j0, j1, mean, var))
+        dist.all_gather_object(gathered, (grid.r, grid.c, j0, j1, mean, var, ch.global_row_index(), lam_loc.numpy()))
         if rank == 0:
-            zpm, zpv = np.full(m, np.nan), np.full(m, np.nan)
-            for (r, c, a, b, mu, v) in gathered:
+            zpm, zpv, lam = np.full(m, np.nan), np.full(m, np.nan), np.full((n, m), np.nan)
+            for (r, c, a, b, mu, v, rows, blk) in gathered:
                 if r == 0:
                     zpm[a:b], zpv[a:b] = mu, v
                 else:       # every rank of a process column holds the same shard
                     assert np.array_equal(zpm[a:b], mu) or np.allclose(zpm[a:b], mu, rtol=0, atol=1e-13)
+                if b > a and len(rows):
+                    lam[np.ix_(rows, np.arange(a, b))] = blk
+            assert not np.isnan(lam).any()             # every (row block, point shard) arrived exactly once
             np.save(out, np.stack([zpm, zpv]))
+            np.save(out + ".lam.npy", lam)
     finally:
         dist.destroy_process_group()
 
@@ -190,6 +197,7 @@ def test_block_cyclic_many_rhs_solve_and_predict(tmp_path, pr, pc, n, m, nb, tra
     ref_var = orc.maternp_covariance(xt, None, 2, th, True) - np.einsum("ij,ij->j", lam, Kit)
     assert np.max(np.abs(got[0] - ref_mean)) < 1e-8 * np.max(np.abs(z))
     assert np.max(np.abs(got[1] - ref_var)) < 1e-8
+    assert np.max(np.abs(np.load(out + ".lam.npy") - lam)) < 1e-7 * np.max(np.abs(lam))
 
 
 class _OracleBackedModel:
@@ -268,6 +276,7 @@ def _oplog_worker(rank, world, port, pr, pc, n, m, nb, out, transport, lookahead
         assert ch.factor() == 0
         ch.negative_log_likelihood(z)
         ch.predict_zero_mean(_cov_full, x, z, xt, th)
+        ch.predict(_cov_full, x, z, xt, th, return_lambdas=True)     # (round 4) backward solve: row broadcasts + one reduce per block column
         ch.value_and_grad(x, z, th, 2, P=np.ones((n, 1)))           # REML gradient: ring shifts inside the process rows
         gathered = [None] * world
         dist.all_gather_object(gathered, (grid.r, grid.c, ch.oplog))
@@ -315,6 +324,9 @@ def test_issue_order_is_identical_on_all_members_of_every_communicator(tmp_path,
     # the roots rotate as the block-cyclic layout says: row communicator r sees every process column as a root
     roots = {e[2] for e in per_comm["row0"][0][1] if e[1] in ("broadcast", "p2p_bcast")}
     assert roots == set(range(pc))
+    # the backward solve reduces once per block column inside every process column, to the process row that owns the block row
+    red = [e for e in per_comm["col0"][0][1] if e[1] == "reduce:bsolve"]
+    assert len(red) == (n + nb - 1) // nb and {e[2] for e in red} == {0 * pc + 0, 1 * pc + 0}
     # the gradient's ring inside the process rows: Pc / 2 shifts, logged identically by every member
     assert [e[1] for e in per_comm["row0"][0][1] if e[1].startswith("ring_shift")] == [f"ring_shift{s}" for s in range(1, pc // 2 + 1)]
 
@@ -547,12 +559,18 @@ def _model_worker(rank, world, port, pr, pc, meantype, out):
         mp_ = np.array([0.3, -0.7]) if meantype == "parameterized" else None
         model = DistributedModel(ProcessGrid(pr, pc), mean, _cov_full, mp_, th, meantype, nb=128, ops=CpuLocalOps())
         zpm, zpv = model.predict(x, z, xt)
+        # (round 4) the kriging weights: the full n x m matrix on every rank, and this rank's block on request
+        zpm_l, zpv_l, lam = model.predict(x, z, xt, return_lambdas=True)
+        assert np.array_equal(zpm_l, zpm) and np.array_equal(zpv_l, zpv) and lam.shape == (n, m)
+        _, _, (blk, rows, (j0, j1)) = model.predict(x, z, xt, return_lambdas="local")
+        assert np.allclose(blk.cpu().numpy(), lam[np.ix_(rows, np.arange(j0, j1))], rtol=0, atol=1e-13)
         zloo, s2, eloo = model.loo(x, z)
         crit = {"zero": lambda: model.negative_log_likelihood_zero_mean(th, x, z),
                 "parameterized": lambda: model.negative_log_likelihood(mp_, th, x, z),
                 "linear_predictor": lambda: model.negative_log_restricted_likelihood(th, x, z)}[meantype]()
         if rank == world - 1:                          # every rank holds the full results: take them from the LAST one
             np.save(out, np.concatenate((zpm, zpv, zloo, s2, eloo, [crit])))
+            np.save(out + ".lam.npy", lam)
     finally:
         dist.destroy_process_group()
 
@@ -573,7 +591,9 @@ def test_distributed_model_surface_matches_the_oracle_model(tmp_path, pr, pc, me
             "linear_predictor": lambda a, p: np.hstack((np.ones((len(a), 1)), a))}[meantype]
     mp_ = np.array([0.3, -0.7]) if meantype == "parameterized" else None
     om = orc.OracleModel(mean, _cov_full, mp_, th, meantype)
-    rm, rv = orc.predict(om, x, z, xt)
+    rm, rv, rlam = orc.predict(om, x, z, xt, return_lambdas=True)
+    lam = np.load(out + ".lam.npy")
+    assert np.max(np.abs(lam - rlam)) < 1e-7 * np.max(np.abs(rlam)), np.max(np.abs(lam - rlam))      # lambda_t rel 1e-7
     rz, rs, re_ = orc.loo(om, x, z)
     rc = {"zero": lambda: orc.negative_log_likelihood_zero_mean(om, th, x, z), "parameterized": lambda: orc.negative_log_likelihood(om, mp_, th, x, z),
           "linear_predictor": lambda: orc.negative_log_restricted_likelihood(om, th, x, z)}[meantype]()

@@ -493,10 +493,13 @@ def _model_worker(rank, world, port, pr, pc, meantype, out):
         mean = None if meantype == "zero" else (lambda a, p: np.hstack((np.ones((len(a), 1)), a)))
         model = DistributedModel(ProcessGrid(pr, pc), mean, MaternCovariance(2), None, th, meantype, nb=256)
         zpm, zpv = model.predict(x, z, xt)
+        zpm_l, zpv_l, lam = model.predict(x, z, xt, return_lambdas=True)       # (round 4) weights: the backward solve with the real kernels
+        assert np.array_equal(zpm_l, zpm) and np.array_equal(zpv_l, zpv)
         zloo, s2, eloo = model.loo(x, z)
         crit = model.negative_log_likelihood_zero_mean(th, x, z) if meantype == "zero" else model.negative_log_restricted_likelihood(th, x, z)
         if rank == world - 1:
             np.save(out, np.concatenate((zpm, zpv, zloo, s2, eloo, [crit])))
+            np.save(out + ".lam.npy", lam)
     finally:
         dist.destroy_process_group()
 
@@ -518,11 +521,13 @@ def test_distributed_model_surface_hip(tmp_path, pr, pc, meantype):
     th = theta_aniso(4, scale=0.5)
     mean = None if meantype == "zero" else (lambda a, p: np.hstack((np.ones((len(a), 1)), a)))
     om = orc.OracleModel(mean, lambda a, b, t, pairwise=False: orc.maternp_covariance(a, b, 2, t, pairwise), None, th, meantype)
-    rm, rv = orc.predict(om, x, z, xt)
+    rm, rv, rlam = orc.predict(om, x, z, xt, return_lambdas=True)
     rz, rs, re_ = orc.loo(om, x, z)
     rc = float(orc.negative_log_likelihood_zero_mean(om, th, x, z)) if meantype == "zero" else float(orc.negative_log_restricted_likelihood(om, th, x, z))
     ev = np.linalg.eigvalsh(orc.maternp_covariance(x, None, 2, th))
     cs = max(1.0, float(ev[-1] / ev[0]) / 1e6)
+    lam = np.load(out + ".lam.npy")
+    assert lam.shape == rlam.shape and np.max(np.abs(lam - rlam)) < 1e-7 * cs * np.max(np.abs(rlam))
     zs = np.max(np.abs(z))
     o = 0
     for ref, tol in ((rm, 1e-9 * cs * zs), (rv, 1e-9 * cs), (rz, 1e-8 * cs * zs), (rs, 1e-8 * cs * np.max(rs)), (re_, 1e-8 * cs * zs)):
