@@ -49,6 +49,7 @@ SIGNATURES = {
     "gpmp_device_release": (c_int, []),
     "gpmp_device_state_count": (c_int, []),
     "gpmp_debug_device_table_selftest": (c_int, [c_int, c_int, c_int]),
+    "gpmp_jacobi_sweep": (c_int, [_P, c_long, _P, c_long, c_int, c_double, _P, _P]),
     "gpmp_coldots_pair": (c_int, [_P, c_long, _P, c_long, c_int, c_int, _P, _P, _P]),
     "gpmp_logdet_chol": (c_int, [_P, c_int, c_long, _P, _P]),
     "gpmp_matern_grad_trace": (c_int, [_P, c_long, _P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, c_long, _P, _P, _P]),

@@ -507,6 +507,11 @@ def solve(A, B, overwrite_a=True, overwrite_b=True, assume_a="gen", sym_pos=Fals
     A, B = asarray(A), asarray(B)
     if assume_a == "pos" or sym_pos:
         return cholesky_factor(A).solve(B)
+    if A.shape[0] <= 256:
+        # the q x q (or (q + 1) x (q + 1)) systems of the mean-space algebra: host LAPACK, like the other q x q steps
+        return asarray(numpy.linalg.solve(to_np(A), to_np(B)))
+    # a LARGE general / symmetric-indefinite system is not something the GP path produces (universal kriging goes through the
+    # Schur complement or the contrast space, core/kriging.py); kept for user code written against the backend namespace
     return torch.linalg.solve(A, B)
 
 
@@ -518,7 +523,45 @@ def qr(A, mode="reduced"):
 
 
 def svd(A, full_matrices=True, hermitian=True):
-    return torch.linalg.svd(asarray(A), full_matrices=full_matrices)
+    """(U, s, Vt) with A = U diag(s) Vt, singular values in decreasing order -- scipy.linalg.svd / torch.linalg.svd of the
+    reference backends, for the SQUARE matrices the path hands it (gpmp/core/sample_paths.py:54-58: a covariance matrix that is
+    only positive semi-definite).  One-sided Jacobi on the library's own kernel (gpmp_jacobi_sweep: rows of G = A rotated until
+    mutually orthogonal, the rotations accumulated in W = U^T); singular vectors of numerically zero singular values are
+    completed from U (``hermitian``: A symmetric, v_i = +-u_i).  Non-square input does not occur on the path: host LAPACK."""
+    lib = _lib.load()
+    A = asarray(A)
+    if A.dim() != 2 or A.shape[0] != A.shape[1]:
+        Uh, sh, Vh = numpy.linalg.svd(to_np(A), full_matrices=full_matrices)
+        return asarray(Uh), asarray(sh), asarray(Vh)
+    n = A.shape[0]
+    if n == 0:
+        return A.clone(), zeros((0,)), A.clone()
+    G = as_matrix(A, copy=True)
+    W = alloc_matrix(n, n)
+    W.zero_()
+    W.diagonal().fill_(1.0)
+    fro = float(torch.sqrt(torch.sum(G[:, :n] * G[:, :n])))
+    tiny = n * eps * fro                 # rows below this are rounding noise of a rank-deficient matrix: they would never settle
+    tol = 8.0 * eps * math.sqrt(n)       # a length-n dot product is exact to about sqrt(n) eps relative
+    conv = torch.zeros(1, dtype=torch.float64, device=_dev())
+    for _ in range(40):
+        _lib.check(lib.gpmp_jacobi_sweep(_ptr(G), _ld(G), _ptr(W), _ld(W), n, tiny, _ptr(conv), _stream()), "gpmp_jacobi_sweep")
+        if float(conv.item()) <= tol:
+            break
+    s = torch.sqrt(torch.sum(G * G, dim=1))
+    order = torch.argsort(s, descending=True)
+    s, G, W = s[order], G[order], W[order]
+    U = W.T.contiguous()
+    ok = s > builtins.max(tiny, n * eps * float(s[0]))
+    if hermitian:
+        # A symmetric: v_i = +-u_i, and the rows of W (a product of plane rotations) are orthonormal to rounding, whereas
+        # g_i / s_i carries the relative noise eps s_0 / s_i of a small singular value
+        sgn = torch.where(torch.sum(G * W, dim=1) < 0.0, -torch.ones_like(s), torch.ones_like(s))
+        Vt = sgn.reshape(-1, 1) * W
+    else:
+        Vt = torch.where(ok.reshape(-1, 1), G / torch.where(ok, s, torch.ones_like(s)).reshape(-1, 1), W)
+    s = torch.where(ok, s, torch.zeros_like(s))
+    return U, s, Vt
 
 
 def matmul(A, B, ta=False, tb=False):

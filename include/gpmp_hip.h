@@ -212,6 +212,15 @@ int gpmp_coldots_ws_rows(int n);
 int gpmp_coldots_pair(const double* A, long lda, const double* B, long ldb, int n, int m, double* out, double* ws,
                       gpmp_stream_t stream);
 
+/* ONE sweep of the one-sided Jacobi SVD of a square matrix (what stands behind gnp.svd: gpmp/num/torch_backend.py:833-834,
+ * scipy.linalg.svd in the NumPy backend; its caller on the path is the "svd" route of gpmp/core/sample_paths.py:54-58, the
+ * symmetric square root of a positive SEMI-definite covariance).  G (n x n row-major, ldg) starts as A and W (n x n, ldw) as
+ * the identity; a sweep rotates every pair of ROWS of G once (n - 1 launches of n / 2 independent pairs) and applies the same
+ * rotations to W.  When the rows of G are mutually orthogonal, A = W^T diag(|g_i|) (g_i / |g_i|).  *conv_dev (device double) =
+ * the largest |g_p . g_q| / (|g_p| |g_q|) met in this sweep; rows with |g| <= tiny_norm count as zero and are left alone.  The
+ * caller repeats sweeps until *conv_dev is at rounding level.  Enqueue only. */
+int gpmp_jacobi_sweep(double* G, long ldg, double* W, long ldw, int n, double tiny_norm, double* conv_dev, gpmp_stream_t stream);
+
 /* *out_dev (device double) = 2 * sum_i log(L[i,i])  (gpmp/core/likelihood.py:50).  Enqueue only. */
 int gpmp_logdet_chol(const double* L, int n, long ldl, double* out_dev, gpmp_stream_t stream);
 

@@ -103,3 +103,31 @@ def test_per_device_state_two_host_threads_and_release(gnp):
     F = gnp.cholesky_factor(gnp.asarray(mats[0]))
     assert np.max(np.abs(torch.tril(F.L).cpu().numpy() - refs[0])) < 1e-10 * np.max(np.abs(refs[0]))
     assert lib.gpmp_device_state_count() == 1
+
+
+@pytest.mark.parametrize("n,kind", [(1, "spd"), (2, "general"), (257, "general"), (300, "psd_rank_deficient"), (1100, "spd")])
+def test_svd_by_one_sided_jacobi_vs_lapack(gnp, n, kind):
+    """gnp.svd on the library's own kernel (gpmp_jacobi_sweep) against LAPACK: singular values, orthogonality, reconstruction;
+    the positive SEMI-definite case is the one the path has (gpmp/core/sample_paths.py:54-58: repeated points)."""
+    rng = np.random.default_rng(n)
+    if kind == "general":
+        A = rng.standard_normal((n, n))
+    else:
+        from oracle import gp_oracle as orc
+
+        x = rng.random((n, 3))
+        if kind == "psd_rank_deficient":
+            x[n // 2:] = x[: n - n // 2]                      # every point twice: rank n / 2
+        A = orc.maternp_covariance_it(x, x, 2, np.array([0.3, 1.0, 0.7, 1.2]))
+    U, s, Vt = (gnp.to_np(t) for t in gnp.svd(gnp.asarray(A), full_matrices=True, hermitian=(kind != "general")))
+    sref = np.linalg.svd(A, compute_uv=False)
+    scale = sref[0]
+    assert U.shape == (n, n) and s.shape == (n,) and Vt.shape == (n, n)
+    assert np.all(np.diff(s) <= 0.0) and np.all(s >= 0.0)
+    assert np.max(np.abs(s - sref)) < 1e-12 * scale * max(1.0, np.sqrt(n))
+    assert np.max(np.abs(U.T @ U - np.eye(n))) < 5e-12 and np.max(np.abs(Vt @ Vt.T - np.eye(n))) < 5e-12    # ~ n x sweeps rotations of eps each
+    assert np.max(np.abs((U * s) @ Vt - A)) < 1e-12 * scale
+    if kind != "general":
+        # the symmetric square root the sample paths use: C = U sqrt(s) Vt, C C^T = A (sample_paths.py:57)
+        C = (U * np.sqrt(s)) @ Vt
+        assert np.max(np.abs(C @ C.T - A)) < 1e-11 * scale
