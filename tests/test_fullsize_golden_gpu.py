@@ -1,11 +1,13 @@
-"""BASELINE configs 3 and 4 at their STATED sizes against vectors the REFERENCE ITSELF produced at those sizes
-(tests/golden/make_fullsize_fixtures.py, run in the build container: gpmp 0.9.37 imported from /root/reference).
+"""BASELINE configs 3 and 4 at their STATED sizes against committed full-size vectors.
 
-  config 3  d = 8, n = 32768: `Model.predict` (gpmp/core/model.py:227-307) at a seeded 2048-point subset of the 50000 bench
-            targets and `negative_log_likelihood_zero_mean` (gpmp/core/likelihood.py:18-52), NumPy backend
-            -> ref_config3_n32768.npz.  The HIP path predicts ALL 50000 points in one call (the bench step) and is compared on
-            the subset; a second call on the subset alone must agree with it.
-  config 4  d = 20, n = 16384: ML (zero mean) and REML (constant mean) criterion values + autograd gradients of the torch-CPU
+  config 3  d = 8, n = 32768: posterior mean / variance (gpmp/core/model.py:227-307) at a seeded 2048-point subset of the 50000
+            bench targets and the zero-mean NLL (gpmp/core/likelihood.py:18-52) from the PINNED ORACLE run at full size on a GPU
+            box's host cores (tests/golden/make_oracle_config3.py -> oracle_config3_n32768.npz; the reference itself cannot
+            produce this one in the build container: its LAPACK does not factor n = 32768 there, see make_fullsize_fixtures.py).
+            The HIP path predicts ALL 50000 points in one call (the bench step) and is compared on the subset; a second call on
+            the subset alone must agree with it.
+  config 4  d = 20, n = 16384, from the REFERENCE ITSELF (tests/golden/make_fullsize_fixtures.py, build container: gpmp 0.9.37
+            imported from /root/reference): ML (zero mean) and REML (constant mean) criterion values + autograd gradients of the torch-CPU
             backend (gpmp/num/torch_backend.py:574-604 through gpmp/kernel/parameter_selection.py:35-124) at two parameter
             vectors -> ref_config4_n16384.npz; checked through the Python criteria AND the fused C driver gpmp_nll_grad.
 
@@ -122,7 +124,7 @@ def test_config3_predict_and_nll_vs_reference_n32768_m50000(gp):
 
     import gpmp_amd.num as gnp
 
-    g = _load("ref_config3_n32768.npz")
+    g = _load("oracle_config3_n32768.npz")
     n, m_all, d = int(g["n"]), int(g["m_all"]), int(g["d"])
     assert (n, m_all, d) == (32768, 50000, 8)
     rng = np.random.default_rng(1234)

@@ -7,6 +7,10 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
 mkdir -p gpurun_out/prof_r4
 export TMPDIR=/tmp
+# the config 3 vector: the pinned oracle at full size on THIS box's host cores (no GPU involved), then the tests against it
+timeout -k 10 1100 python tests/golden/make_oracle_config3.py gpurun_out/oracle_config3_n32768.npz > gpurun_out/r4_make_oracle_config3.log 2>&1
+echo "oracle config3 rc=$?"; tail -12 gpurun_out/r4_make_oracle_config3.log
+cp gpurun_out/oracle_config3_n32768.npz tests/golden/ || exit 1
 timeout -k 10 900 python -m pytest tests/test_fullsize_golden_gpu.py tests/test_dist_gpu.py -x -q -m gpu -k "config or model_surface" > gpurun_out/r4_fullsize_golden2.log 2>&1
 echo "fullsize golden + dist model rc=$?" | tee -a gpurun_out/r4_fullsize_golden2.log
 tail -15 gpurun_out/r4_fullsize_golden2.log
