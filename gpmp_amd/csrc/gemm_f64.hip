@@ -49,6 +49,7 @@ struct GemmParams {
   int pair16;   // v2 epilogue: 16-byte stores after a lane-pair exchange
   int prio;     // small NT kernels: raise the wave priority (GPMP_CHAIN_PRIO)
   int gm;       // plain tile order: tile rows per group (8 = the 64 co-resident workgroups of an XCD cover 8 x 8 tiles)
+  int tri_block;  // lower-triangular tile sets in 8 x 8 super-tiles (round 4) instead of row by row
   long sa, sb, sc;   // element strides of A, B, C per batch index
   long sa2, sb2, sc2;   // ... per outer batch index (blockIdx.z)
 };
@@ -66,12 +67,45 @@ __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& t
   if (p.lower_only) {
     const int tn = p.tiles_n < p.tiles_m ? p.tiles_n : p.tiles_m;
     const int t1 = tn * (tn + 1) / 2;
-    if (v < t1) {
+    if (v < t1 && p.tri_block) {
+      // Round 4: the triangle in SUPER-TILES of 8 x 8 tiles, super-row by super-row, so that the 64 co-resident workgroups of an
+      // XCD (a contiguous run of v) cover an 8 x 8 block of tiles -- 16 panel k-slices per step instead of the 65 of a 1 x 64
+      // strip of the row-by-row order (a quarter of the L2-side traffic of the Cholesky's trailing update).  A full super-row I
+      // holds 64 I + 36 tiles (I off-diagonal squares + the diagonal triangle); 32 I^2 + 4 I tiles come before it.  Only the
+      // last super-row can be ragged (fewer than 8 tile rows).
+      int I = (int)((sqrt(16.0 + 128.0 * (double)v) - 4.0) * (1.0 / 64.0));
+      while (32 * (I + 1) * (I + 1) + 4 * (I + 1) <= v) ++I;
+      while (32 * I * I + 4 * I > v) --I;
+      const int w = v - (32 * I * I + 4 * I);
+      const int rows = (tn - 8 * I) < 8 ? (tn - 8 * I) : 8;
+      const int sq = rows * 8;                       // tiles of one off-diagonal super-tile of this super-row
+      if (w < I * sq) {
+        const int J = w / sq, x = w - J * sq;
+        ti = 8 * I + x % rows;
+        tj = 8 * J + x / rows;
+      } else {
+        const int w2 = w - I * sq;
+        int i = (int)((sqrt(8.0 * (double)w2 + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= w2) ++i;
+        while (i * (i + 1) / 2 > w2) --i;
+        ti = 8 * I + i;
+        tj = 8 * I + (w2 - i * (i + 1) / 2);
+      }
+    } else if (v < t1) {
       int i = (int)((sqrt(8.0 * (double)v + 1.0) - 1.0) * 0.5);
       while ((i + 1) * (i + 2) / 2 <= v) ++i;
       while (i * (i + 1) / 2 > v) --i;
       ti = i;
       tj = v - i * (i + 1) / 2;
+    } else if (p.tri_block) {
+      // the rectangle below the triangle (M > N): groups of 8 tile rows, row fastest inside a group
+      const int rr = v - t1;
+      const int g = rr / (8 * tn);
+      const int first = tn + 8 * g;
+      const int gsize = (p.tiles_m - first) < 8 ? (p.tiles_m - first) : 8;
+      const int w = rr - g * 8 * tn;
+      ti = first + w % gsize;
+      tj = w / gsize;
     } else {
       const int rr = v - t1;
       ti = tn + rr / tn;
@@ -1163,6 +1197,9 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   static int gm = -1;
   if (gm < 0) { const char* e = getenv("GPMP_GEMM_GM"); gm = e ? atoi(e) : 8; if (gm < 1) gm = 8; }
   p.gm = gm;
+  // lower-triangular tile sets of equal-cost tiles in 8 x 8 super-tiles (read at every call: A/B inside one process)
+  { const char* e = getenv("GPMP_GEMM_TRI_BLOCK");
+    p.tri_block = ((e ? atoi(e) : 1) != 0) && !(o.kstart_row | o.kend_row | o.kstart_col | o.kend_col); }
   p.batch = o.batch > 1 ? o.batch : 1;
   p.sa = o.stride_a; p.sb = o.stride_b; p.sc = o.stride_c;
   p.batch2 = o.batch2 > 1 ? o.batch2 : 1;

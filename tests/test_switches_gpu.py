@@ -25,6 +25,7 @@ SETTINGS = [
     {"GPMP_POTRF_BLOCKED_BELOW": "100000"},
     {"GPMP_GEMM_SMALL_ROWS16_BELOW": "0"},
     {"GPMP_GEMM_SMALL_ROWS16_BELOW": "1000000"},
+    {"GPMP_GEMM_TRI_BLOCK": "0"},                     # (round 4) lower-triangular tile sets row by row (the order of rounds 1-3)
     # (round 4) two-level 2048-column panels: binary blocking inside the panel, rank-2048 trailing updates, four look-ahead pieces
     {"GPMP_POTRF_SUPER_ABOVE": "2048", "GPMP_POTRF_WIDE_ABOVE": "2048", "GPMP_POTRF_LA_SPLIT_ABOVE": "1024"},
     {"GPMP_POTRF_SUPER_ABOVE": "2048", "GPMP_POTRF_WIDE_ABOVE": "2048", "GPMP_POTRF_LA_SPLIT": "0"},
