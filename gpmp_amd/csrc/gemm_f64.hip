@@ -50,6 +50,7 @@ struct GemmParams {
   int prio;     // small NT kernels: raise the wave priority (GPMP_CHAIN_PRIO)
   int gm;       // plain tile order: tile rows per group (8 = the 64 co-resident workgroups of an XCD cover 8 x 8 tiles)
   int tri_block;  // lower-triangular tile sets in 8 x 8 super-tiles (round 4) instead of row by row
+  int early;      // v2: request tile kt + 2 right behind the barrier of tile kt (64 MFMAs of cover) instead of at the top of tile kt + 1 (48)
   long sa, sb, sc;   // element strides of A, B, C per batch index
   long sa2, sb2, sc2;   // ... per outer batch index (blockIdx.z)
 };
@@ -544,9 +545,13 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
   };
 
+  // early: tile kt + 2 is requested right behind the barrier of tile kt -- buffer `cur` is free there, every fragment of it was read
+  // before the barrier -- instead of at the top of tile kt + 1: 64 MFMAs of cover for the global -> LDS loads instead of 48.
+  // (Round 4.  A second barrier per k-tile right after the last fragment read would give 96; measured: it loses 4-5 points.)
+  const bool early = p.early != 0;
   auto ktile = [&](int kt, bool more, auto&& inject) {
     const int cur = kt & 1;
-    if (more) issue(kt + 1, cur ^ 1);
+    if (more && !early) issue(kt + 1, cur ^ 1);
     // at most three k-steps of fragments are live at any point (48 VGPRs)
     read_frags(2, cur);
     __builtin_amdgcn_sched_barrier(0);
@@ -558,6 +563,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
     mfma_step(2);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();   // next tile landed (vmcnt(0) of every wave) and buffer `cur` is free for tile kt+2
+    if (early && kt + 2 < nk) issue(kt + 2, cur);
     if (more) {
       read_frags(0, cur ^ 1);
       read_frags(1, cur ^ 1);
@@ -571,6 +577,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
 
   if (nk > 0) {
     issue(0, 0);
+    if (early && nk > 1) issue(1, 1);
     __syncthreads();
     read_frags(0, 0);
     read_frags(1, 0);
@@ -1197,6 +1204,13 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   static int gm = -1;
   if (gm < 0) { const char* e = getenv("GPMP_GEMM_GM"); gm = e ? atoi(e) : 8; if (gm < 1) gm = 8; }
   p.gm = gm;
+  // request distance of the LDS-direct kernel's operand tiles (read at every call): -1 = never early, 0 = early from
+  // GPMP_GEMM_EARLY_MIN_K on (default), 1 = always early
+  { const char* e = getenv("GPMP_GEMM_EARLY_ISSUE");
+    const int mode = e ? atoi(e) : 0;
+    const char* mk = getenv("GPMP_GEMM_EARLY_MIN_K");
+    const int min_k = mk ? atoi(mk) : 2048;
+    p.early = mode > 0 ? 1 : (mode < 0 ? 0 : (K >= min_k ? 1 : 0)); }
   // lower-triangular tile sets of equal-cost tiles in 8 x 8 super-tiles (read at every call: A/B inside one process)
   { const char* e = getenv("GPMP_GEMM_TRI_BLOCK");
     p.tri_block = ((e ? atoi(e) : 1) != 0) && !(o.kstart_row | o.kend_row | o.kstart_col | o.kend_col); }

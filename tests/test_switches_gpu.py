@@ -25,7 +25,9 @@ SETTINGS = [
     {"GPMP_POTRF_BLOCKED_BELOW": "100000"},
     {"GPMP_GEMM_SMALL_ROWS16_BELOW": "0"},
     {"GPMP_GEMM_SMALL_ROWS16_BELOW": "1000000"},
-    {"GPMP_GEMM_TRI_BLOCK": "0"},                     # (round 4) lower-triangular tile sets row by row (the order of rounds 1-3)
+    {"GPMP_GEMM_TRI_BLOCK": "0"},
+    {"GPMP_GEMM_EARLY_ISSUE": "1"},                   # (round 4) operand tiles requested one barrier earlier, at every K
+    {"GPMP_GEMM_EARLY_ISSUE": "-1"},                     # (round 4) lower-triangular tile sets row by row (the order of rounds 1-3)
     # (round 4) two-level 2048-column panels: binary blocking inside the panel, rank-2048 trailing updates, four look-ahead pieces
     {"GPMP_POTRF_SUPER_ABOVE": "2048", "GPMP_POTRF_WIDE_ABOVE": "2048", "GPMP_POTRF_LA_SPLIT_ABOVE": "1024"},
     {"GPMP_POTRF_SUPER_ABOVE": "2048", "GPMP_POTRF_WIDE_ABOVE": "2048", "GPMP_POTRF_LA_SPLIT": "0"},
@@ -43,6 +45,8 @@ SOLVE_SETTINGS = [
     {"GPMP_POTRF_ALONG_RIGHT": "0"},                  # (round 3) left-looking updates in the panel-by-panel solve
     {"GPMP_POTRF_ALONG_RIGHT": "0", "GPMP_POTRF_ALONG_ROWS": "512"},
     {"GPMP_POTRF_SUPER_ABOVE": "2048", "GPMP_POTRF_WIDE_ABOVE": "2048"},      # (round 4) 2048-column panels under the panel-by-panel solve
+    {"GPMP_GEMM_EARLY_ISSUE": "1"},
+    {"GPMP_GEMM_EARLY_ISSUE": "-1"},
 ]
 
 
