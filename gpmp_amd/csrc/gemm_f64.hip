@@ -678,7 +678,7 @@ struct LeafSolveParams {
   int m;            // right-hand sides; the last strip may be narrower than 128
 };
 
-// BNW = columns of a strip: 128 (waves 2 x 2, 64 x 64 each) or 64 (waves 4 x 1, 32 x 64 each).  The narrow form halves the
+// BNW = columns of a strip: 128 (waves 2 x 2, 64 x 64 each) or 112 / 96 / 80 / 64 / 32 / 16 (waves 4 x 1, 32 x BNW each).  The narrow form halves the
 // work of a workgroup and doubles their number: a leaf has only m / BNW workgroups, and at m = 10000 (config 2) 79 of them
 // leave two thirds of the machine idle for the 0.17 ms the four sequential products take.
 template <int BNW>
@@ -1144,6 +1144,12 @@ int launch_trsm_leaf_forward(const double* L, long ldl, const double* dinv_leaf,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_leaf_kernel<16>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_leaf_kernel<112>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_leaf_kernel<96>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_leaf_kernel<80>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     attr_once.done(dev_bit);
   }
   // A leaf has one workgroup per strip, each walking the nb blocks one after the other (MFMA-bound on its compute unit:
@@ -1158,11 +1164,39 @@ int launch_trsm_leaf_forward(const double* L, long ldl, const double* dinv_leaf,
   if (strips128 < narrow_below) {
     bnw = 64;
     while (bnw > 16 && (ncols + bnw - 1) / bnw < min_strips) bnw >>= 1;
+  } else {
+    // Round 4: many strips.  A leaf's workgroups are MFMA-bound on their compute unit, so the leaf lasts as long as the busiest
+    // CU: with L = ceil(strips / CUs) workgroups on it, pairs run two at a time (each at half rate, together ~0.9 of the pipe) and an
+    // odd one alone (~0.8): time ~ width x (2.22 floor(L / 2) + 1.25 (L mod 2)).  m = 50000 in 128-column strips is 391 workgroups
+    // (L = 2): 112 columns (waves 4 x 1 over 32 x 112) make 447 strips of 7 / 8 the work each, m = 40000 goes to 80 columns; m = 30000
+    // (235 strips, one per CU) stays at 128.  Measured: predict n = 32768: m = 50000 950.4 -> 947.8 ms, m = 40000 801.4 -> 795.5 ms.
+    const char* fe = getenv("GPMP_TRSM_LEAF_FIT");
+    if ((fe ? atoi(fe) : 1) != 0) {
+      static int ncu = 0;
+      if (ncu <= 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+        else ncu = 256;
+      }
+      auto cost = [&](int w) {
+        const int sw = (ncols + w - 1) / w;
+        const int L = (sw + ncu - 1) / ncu;
+        return (double)w * (2.22 * (L / 2) + 1.25 * (L % 2));
+      };
+      double best = cost(128);
+      for (int w : {112, 96, 80}) {
+        const double c = cost(w);
+        if (c < 0.97 * best) { best = c; bnw = w; }
+      }
+    }
   }
   LeafSolveParams p{G, ldg, B, ldb, nb, ncols};
   ProfScope ps(PK_GEMM_NN, st, (double)ncols * (double)(nb * BM) * (double)((nb + 1) * BM));   // counted with the small-K NN work it replaces
   const dim3 grid((ncols + bnw - 1) / bnw);
   if (bnw == 128) hipLaunchKernelGGL(trsm_leaf_kernel<128>, grid, dim3(256), lds2, st, p);
+  else if (bnw == 112) hipLaunchKernelGGL(trsm_leaf_kernel<112>, grid, dim3(256), lds2, st, p);
+  else if (bnw == 96) hipLaunchKernelGGL(trsm_leaf_kernel<96>, grid, dim3(256), lds2, st, p);
+  else if (bnw == 80) hipLaunchKernelGGL(trsm_leaf_kernel<80>, grid, dim3(256), lds2, st, p);
   else if (bnw == 64) hipLaunchKernelGGL(trsm_leaf_kernel<64>, grid, dim3(256), lds2, st, p);
   else if (bnw == 32) hipLaunchKernelGGL(trsm_leaf_kernel<32>, grid, dim3(256), lds2, st, p);
   else hipLaunchKernelGGL(trsm_leaf_kernel<16>, grid, dim3(256), lds2, st, p);

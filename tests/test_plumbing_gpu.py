@@ -131,3 +131,28 @@ def test_svd_by_one_sided_jacobi_vs_lapack(gnp, n, kind):
         # the symmetric square root the sample paths use: C = U sqrt(s) Vt, C C^T = A (sample_paths.py:57)
         C = (U * np.sqrt(s)) @ Vt
         assert np.max(np.abs(C @ C.T - A)) < 1e-11 * scale
+
+
+@pytest.mark.parametrize("m,width", [(40000, 80), (50000, 112), (46000, 96)])
+def test_forward_solve_leaves_with_fitted_strip_widths(gnp, m, width, monkeypatch):
+    """Round 4: with many right-hand sides the fused 512-row leaves of the forward solve take 112- / 96- / 80-column strips when
+    that fills the machine better than 128 (gemm_f64.hip: launch_trsm_leaf_forward); the solution must be the one of the
+    128-column strips (GPMP_TRSM_LEAF_FIT=0) to rounding and LAPACK's on sampled columns (gpmp/num/numpy_backend.py:467)."""
+    import scipy.linalg as sla
+    import torch
+
+    from oracle import gp_oracle as orc
+
+    n = 1536                                                    # three leaves of 512 rows + the updates between them
+    rng = np.random.default_rng(m)
+    x = rng.random((n, 3))
+    K = orc.maternp_covariance(x, None, 2, np.array([0.0, 1.0, 0.8, 1.3])) + 1e-6 * np.eye(n)
+    F = gnp.cholesky_factor(gnp.asarray(K))
+    B = torch.randn((n, m), dtype=torch.float64, device=F.L.device, generator=torch.Generator(device=F.L.device).manual_seed(m))
+    X = F.solve_lower(B.clone())
+    monkeypatch.setenv("GPMP_TRSM_LEAF_FIT", "0")
+    X0 = F.solve_lower(B.clone())
+    assert float((X - X0).abs().max()) < 1e-11 * float(X0.abs().max())
+    cols = np.concatenate((np.arange(0, 300), np.arange(m - 300, m), rng.choice(m, 400, replace=False)))
+    ref = sla.solve_triangular(np.tril(gnp.to_np(F.L)), B[:, torch.as_tensor(cols, device=B.device)].cpu().numpy(), lower=True)
+    assert np.max(np.abs(X[:, torch.as_tensor(cols, device=B.device)].cpu().numpy() - ref)) < 1e-10 * np.max(np.abs(ref))
