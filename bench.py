@@ -601,7 +601,9 @@ def gather_ranks_seen(dist_mod, rank, world, backend, have_gpu):
     ident = {(r["host"], r.get("uuid") or r.get("pci_bus_id") or r.get("device_index")) for r in recs}
     return {"backend": backend, "rccl_version": rccl, "world": world, "ranks": recs,
             "distinct_pids": len({(r["host"], r["pid"]) for r in recs}),
-            "distinct_devices": len(ident) if have_gpu else 0}
+            "distinct_devices": len(ident) if have_gpu else 0,
+            # one process AND one device per rank (false in a gloo rehearsal where ranks share a GPU, and in stub runs)
+            "one_device_per_rank": bool(have_gpu and len(ident) == world and len({(r["host"], r["pid"]) for r in recs}) == world)}
 
 
 def time_block_cyclic_strong_scaling(runner, dist_mod, world, rank, reps, tmax):
