@@ -50,6 +50,7 @@ struct GemmParams {
   int prio;     // small NT kernels: raise the wave priority (GPMP_CHAIN_PRIO)
   int gm;       // plain tile order: tile rows per group (8 = the 64 co-resident workgroups of an XCD cover 8 x 8 tiles)
   int tri_block;  // lower-triangular tile sets in 8 x 8 super-tiles (round 4) instead of row by row
+  int bn;         // v2, plain NN launches: tile width 128 / 112 / 96 (launch_t)
   int early;      // v2: request tile kt + 2 right behind the barrier of tile kt (64 MFMAs of cover) instead of at the top of tile kt + 1 (48)
   long sa, sb, sc;   // element strides of A, B, C per batch index
   long sa2, sb2, sc2;   // ... per outer batch index (blockIdx.z)
@@ -401,8 +402,14 @@ __device__ __forceinline__ int v2_frag_addr(int idx, int k) {
   else return k * 128 + 2 * ((idx >> 1) ^ ((k & 1) << 3)) + (idx & 1);
 }
 
-template <bool AKC, bool BKC, bool CACC>
+// BNT = columns of a tile: 128 (waves 2 x 2, 64 x 64 each) or 112 / 96 (waves 4 x 1, 32 x BNT each: the layout of the narrow solve
+// leaves).  Narrower tiles exist for ONE reason: a launch lasts ceil(tiles / (2 CUs)) rounds of the machine, and with N = 50000
+// (391 tile columns of 128) the solve's updates of 512 ... 4096 rows end on a nearly empty round -- 447 columns of 112 fit better
+// (launch_t picks the width that minimises rounds x width).  Everything else -- operand images, request schedule, k loop -- is shared.
+template <bool AKC, bool BKC, bool CACC, int BNT = BN>
 __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
+  constexpr int MI = BNT == BN ? 4 : 2;            // 16-row MFMA tiles per wave
+  constexpr int NJ = BNT == BN ? 4 : BNT / 16;     // 16-column MFMA tiles per wave
   extern __shared__ __attribute__((aligned(16))) double smem[];  // [2 buffers][A image | B image] = 64 KB
   int ti, tj;
   p.A += (long)blockIdx.y * p.sa + (long)blockIdx.z * p.sa2;   // batched launch: one independent product per blockIdx.y
@@ -411,17 +418,17 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
   decode_tile(p, blockIdx.x, ti, tj);
   ti = __builtin_amdgcn_readfirstlane(ti);
   tj = __builtin_amdgcn_readfirstlane(tj);
-  const int row0 = ti * BM, col0 = tj * BN;
+  const int row0 = ti * BM, col0 = tj * BNT;
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = BNT == BN ? (wave >> 1) * 64 : wave * 32, wn = BNT == BN ? (wave & 1) * 64 : 0;
   const int lr = lane & 15, lk = lane >> 4;
   // edge tiles (M, N not multiples of 128; both even): operand rows are clamped / clipped so that nothing is read
   // outside the matrices, the main loop is the same, and only valid rows / columns of C are read and written
   const int rows_v = (p.M - row0) < BM ? (p.M - row0) : BM;
-  const int cols_v = (p.N - col0) < BN ? (p.N - col0) : BN;
-  const bool edge = (rows_v < BM) || (cols_v < BN);
+  const int cols_v = (p.N - col0) < BNT ? (p.N - col0) : BNT;
+  const bool edge = (rows_v < BM) || (cols_v < BNT);
 
   int kbeg = p.kstart_row ? row0 : 0;
   if (p.kstart_col) {
@@ -430,7 +437,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
   }
   int kend = p.K;
   if (p.kend_row && row0 + BM < kend) kend = row0 + BM;
-  if (p.kend_col && col0 + BN < kend) kend = col0 + BN;
+  if (p.kend_col && col0 + BNT < kend) kend = col0 + BNT;
   const int nk = kend > kbeg ? (kend - kbeg) / BK : 0;
 
   // ---- accumulators (start from (beta/alpha) C, see v1)
@@ -438,7 +445,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
   const bool pair_stores = p.pair16 != 0;
   double* __restrict__ cbase = p.C + (long)row0 * p.ldc + col0;
   const unsigned lane_off = (unsigned)((wm + lk) * (int)p.ldc + wn + lr);
-  d4 acc[4][4];
+  d4 acc[MI][NJ];
   // C is read either up front (accumulators start from (beta/alpha) C) or, when the k loop is long
   // enough, one 16x16 MFMA tile per k-tile during the first 16 k-tiles: every workgroup of a round
   // starts its tile at the same time, and 512 simultaneous 128 KB reads are an HBM-rate burst that
@@ -448,29 +455,29 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
     const double sc = beta / alpha;
     if (!edge) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j][r] = sc * rp[lane_off + j * 16];
+          for (int j = 0; j < NJ; ++j) acc[i][j][r] = sc * rp[lane_off + j * 16];
         }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
           const bool rok = wm + i * 16 + 4 * r + lk < rows_v;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j][r] = (rok && wn + j * 16 + lr < cols_v) ? sc * rp[lane_off + j * 16] : 0.0;
+          for (int j = 0; j < NJ; ++j) acc[i][j][r] = (rok && wn + j * 16 + lr < cols_v) ? sc * rp[lane_off + j * 16] : 0.0;
         }
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int j = 0; j < NJ; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
   }
 
   // ---- per-lane source offsets (bytes), one per load instruction.  Rows (k-contiguous operand) or column pairs
@@ -528,20 +535,20 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
     }
   };
 
-  double fa[4][4], fb[4][4];   // [k-step][fragment], statically indexed after unrolling
+  double fa[4][MI], fb[4][NJ];   // [k-step][fragment], statically indexed after unrolling
   auto read_frags = [&](int ks, int buf) {
     const double* sa = smem + buf * 2 * V2_TILE;
     const double* sb = sa + V2_TILE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[ks][i] = sa[v2_frag_addr<AKC>(wm + i * 16 + lr, ks * 4 + lk)];
+    for (int i = 0; i < MI; ++i) fa[ks][i] = sa[v2_frag_addr<AKC>(wm + i * 16 + lr, ks * 4 + lk)];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fb[ks][j] = sb[v2_frag_addr<BKC>(wn + j * 16 + lr, ks * 4 + lk)];
+    for (int j = 0; j < NJ; ++j) fb[ks][j] = sb[v2_frag_addr<BKC>(wn + j * 16 + lr, ks * 4 + lk)];
   };
   auto mfma_step = [&](int ks) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
   };
 
@@ -589,8 +596,8 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
         const int cvoff = (int)lane_off * 8;
         const int ldc8 = (int)p.ldc * 8;
 #pragma unroll
-        for (int T = 0; T < 16; ++T) {
-          const int i = T >> 2, j = T & 3;
+        for (int T = 0; T < MI * NJ; ++T) {
+          const int i = T / NJ, j = T % NJ;
           // the four rows of MFMA tile (i, j) are requested before this k-tile's operand loads and have
           // landed by the k-tile's barrier (vmcnt(0)); they are folded in just before k-step 3
           typedef unsigned int v2u __attribute__((ext_vector_type(2)));
@@ -603,7 +610,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
             for (int r = 0; r < 4; ++r) acc[i][j][r] = fma(sc, __builtin_bit_cast(double, craw[r]), acc[i][j][r]);
           });
         }
-        kt = 16;
+        kt = MI * NJ;
       }
     }
     for (; kt < nk; ++kt) ktile(kt, kt + 1 < nk, nothing);
@@ -616,9 +623,9 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
     const bool odd = lane & 1;
     const unsigned off2 = lane_off - (odd ? 1u : 0u);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const double a0 = alpha * acc[i][j][0], a1 = alpha * acc[i][j][1], a2 = alpha * acc[i][j][2], a3 = alpha * acc[i][j][3];
         const double g0 = swap_lane_xor1(odd ? a0 : a2), g1 = swap_lane_xor1(odd ? a1 : a3);
         const d2 v0 = odd ? (d2){g0, a2} : (d2){a0, g0};
@@ -629,12 +636,12 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
       }
   } else if (!edge) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           double v = alpha * acc[i][j][r];
           if constexpr (!CACC) { if (beta != 0.0) v += beta * rp[lane_off + j * 16]; }
           rp[lane_off + j * 16] = v;
@@ -642,13 +649,13 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
       }
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double* rp = cbase + (long)(i * 16 + 4 * r) * p.ldc;
         const bool rok = wm + i * 16 + 4 * r + lk < rows_v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           if (rok && wn + j * 16 + lr < cols_v) {
             double v = alpha * acc[i][j][r];
             if constexpr (!CACC) { if (beta != 0.0) v += beta * rp[lane_off + j * 16]; }
@@ -1070,6 +1077,10 @@ int launch_t(const GemmParams& p, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_v2<AKC, BKC, CACC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_v2<AKC, BKC, CACC, 112>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    GPMP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_v2<AKC, BKC, CACC, 96>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     attr_once.done(dev_bit);
   }
   static int use_v2 = -1;
@@ -1081,6 +1092,25 @@ int launch_t(const GemmParams& p, hipStream_t st) {
                     (p.lda % 2 == 0) && (p.ldb % 2 == 0) && (p.ldc >= p.N) &&
                     ((long)BM * p.lda * 8 + (long)p.K * 8 < 0x7FFFFFFFL) && ((long)BN * p.ldb * 8 + (long)p.K * 8 < 0x7FFFFFFFL);
   // small NT products on a grid that cannot fill the machine: 64 x 64 tiles (latency kernel above)
+  // tile width of a plain launch on the LDS-direct kernel (round 4): the width among 128 / 112 / 96 that minimises
+  // rounds x width, rounds = ceil(tiles / (2 CUs)); GPMP_GEMM_FIT_N=0 keeps 128 (read at every call)
+  GemmParams pf = p;
+  if (v2ok && p.batch == 1 && p.batch2 == 1 && !p.lower_only && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col) && p.N >= 16 * BN) {
+    const char* fe = getenv("GPMP_GEMM_FIT_N");
+    if ((fe ? atoi(fe) : 1) != 0) {
+      const long slots = 512;
+      auto cost = [&](int w) { const long t = (long)p.tiles_m * ((p.N + w - 1) / w); return ((t + slots - 1) / slots) * (long)w; };
+      long best = cost(BN);
+      for (int w : {112, 96}) {
+        const long c = cost(w);
+        if (c * 100 < best * 97) { best = c; pf.bn = w; }
+      }
+      if (pf.bn != BN) {
+        pf.tiles_n = (p.N + pf.bn - 1) / pf.bn;
+        pf.ntiles = pf.tiles_m * pf.tiles_n;
+      }
+    }
+  }
   static int use_small = -1, small_max = 128;
   if (use_small < 0) {
     const char* e = getenv("GPMP_GEMM_SMALL_NT"); use_small = e ? atoi(e) : 1;
@@ -1097,7 +1127,9 @@ int launch_t(const GemmParams& p, hipStream_t st) {
     // executed flops of this launch (tiles actually visited, k range actually swept)
     const double kavg = (p.kstart_row || p.kend_row || p.kstart_col || p.kend_col) ? 0.5 * p.K : (double)p.K;
     ProfScope ps((AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN)) + ((v2ok && !small_nt) ? 8 : 0), st,
-                 2.0 * (double)p.ntiles * BM * BN * kavg * p.batch * p.batch2);
+                 (!p.lower_only && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col))
+                     ? 2.0 * (double)p.M * (double)p.N * (double)p.K * p.batch * p.batch2      // a plain product: its own flops
+                     : 2.0 * (double)p.ntiles * BM * BN * kavg * p.batch * p.batch2);
     if (lean_nt) hipLaunchKernelGGL(gemm_nt_lean_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
     else if (small_nt) {
       // fewer 32-row tiles than ~compute units: 16-row tiles (read at every call: tests exercise both heights)
@@ -1107,6 +1139,8 @@ int launch_t(const GemmParams& p, hipStream_t st) {
       if (wg32 < below16) hipLaunchKernelGGL(gemm_nt_small_kernel<16>, dim3((p.N + SBN - 1) / SBN, (p.M + 15) / 16), dim3(256), 0, st, p);
       else hipLaunchKernelGGL(gemm_nt_small_kernel<SBM>, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
     }
+    else if (v2ok && pf.bn == 112) hipLaunchKernelGGL((gemm_f64_kernel_v2<AKC, BKC, CACC, 112>), dim3(pf.ntiles, pf.batch, pf.batch2), dim3(256), lds2, st, pf);
+    else if (v2ok && pf.bn == 96) hipLaunchKernelGGL((gemm_f64_kernel_v2<AKC, BKC, CACC, 96>), dim3(pf.ntiles, pf.batch, pf.batch2), dim3(256), lds2, st, pf);
     else if (v2ok) hipLaunchKernelGGL((gemm_f64_kernel_v2<AKC, BKC, CACC>), dim3(p.ntiles, p.batch, p.batch2), dim3(256), lds2, st, p);
     else hipLaunchKernelGGL((gemm_f64_kernel<AKC, BKC, CACC>), dim3(p.ntiles, p.batch, p.batch2), dim3(256), lds, st, p);
   }
@@ -1238,6 +1272,7 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   static int gm = -1;
   if (gm < 0) { const char* e = getenv("GPMP_GEMM_GM"); gm = e ? atoi(e) : 8; if (gm < 1) gm = 8; }
   p.gm = gm;
+  p.bn = BN;
   // request distance of the LDS-direct kernel's operand tiles (read at every call): -1 = never early, 0 = early from
   // GPMP_GEMM_EARLY_MIN_K on (default), 1 = always early
   { const char* e = getenv("GPMP_GEMM_EARLY_ISSUE");

@@ -156,3 +156,22 @@ def test_forward_solve_leaves_with_fitted_strip_widths(gnp, m, width, monkeypatc
     cols = np.concatenate((np.arange(0, 300), np.arange(m - 300, m), rng.choice(m, 400, replace=False)))
     ref = sla.solve_triangular(np.tril(gnp.to_np(F.L)), B[:, torch.as_tensor(cols, device=B.device)].cpu().numpy(), lower=True)
     assert np.max(np.abs(X[:, torch.as_tensor(cols, device=B.device)].cpu().numpy() - ref)) < 1e-10 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 50000, 512), (1024, 50000, 1024), (2048, 30002, 512), (640, 46000, 1024)])
+def test_gemm_with_fitted_tile_width_vs_128_and_numpy(gnp, M, N, K, monkeypatch):
+    """Round 4: plain products on the LDS-direct kernel take 112- or 96-column tiles when that fills the last round of the machine
+    better (gemm_f64.hip: launch_t, GPMP_GEMM_FIT_N).  Same product as with 128-column tiles (same k order per entry: bit-identical)
+    and as NumPy on sampled columns, incl. a ragged last tile."""
+    import torch
+
+    rng = np.random.default_rng(M + N + K)
+    A = gnp.asarray(rng.standard_normal((M, K)))
+    B = gnp.asarray(rng.standard_normal((K, N)))
+    C1 = gnp.matmul(A, B)
+    monkeypatch.setenv("GPMP_GEMM_FIT_N", "0")
+    C0 = gnp.matmul(A, B)
+    assert torch.equal(C1, C0)
+    cols = np.concatenate((np.arange(0, 260), np.arange(N - 260, N), rng.choice(N, 300, replace=False)))
+    ref = gnp.to_np(A) @ gnp.to_np(B)[:, cols]
+    assert np.max(np.abs(C1[:, torch.as_tensor(cols, device=C1.device)].cpu().numpy() - ref)) < 1e-12 * np.sqrt(K) * 10

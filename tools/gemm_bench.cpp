@@ -50,6 +50,7 @@ int main(int argc, char** argv) {
   // the triangular solve's updates of the headline step (B2 -= L21 X1: M = K = R rows, N = 50000) and the Cholesky's trailing
   // updates at rank 1024 / 2048 -- the shapes whose L2-side traffic DESIGN section 4 discusses (run under rocprofv3 --pmc FETCH_SIZE)
   if (which == 50) { for (int R : {16384, 8192, 4096, 2048}) run("solve update NN M=K=R N=50000", 0, 0, R, 50000, R, 0, 1.0, reps); }
+  if (which == 53) { for (int R : {512, 1024, 2048, 4096, 8192}) run("solve update NN M=K=R N=50000", 0, 0, R, 50000, R, 0, 1.0, reps); }
   if (which == 52) run("solve update NN M=K=8192 N=50000", 0, 0, 8192, 50000, 8192, 0, 1.0, reps);
   if (which == 51) { for (int K : {1024, 2048}) run("potrf trailing NT lower M=N=24576", 0, 1, 24576, 24576, K, 1, 1.0, reps); }
   if (which == 20) { for (int K : {128, 256, 512, 1024, 2048, 4096}) { run("NN beta=1 K sweep", 0, 0, 16384, 16384, K, 0, 1.0, reps); run("NN beta=0 K sweep", 0, 0, 16384, 16384, K, 0, 0.0, reps); } }
