@@ -568,7 +568,11 @@ int potrf_lower(double* A, int n, long lda, double* dinv, int* info_dev, hipStre
 // gws: optional scratch of at least (LEAF_TRSM)^2 doubles; enables the fused leaf (gemm_f64.hip: trsm_leaf_kernel)
 int trsm_forward(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int tri,
                  int tri_off, double* gws, hipStream_t st) {
-  if (n <= LEAF_TRSM) {
+  // rows of a fused leaf (read at every call): 512, or 1024 (GPMP_TRSM_LEAF_ROWS) -- eight blocks per strip, k loops up to 1024,
+  // no separate 512-row update between two leaves; the scratch behind the block inverses holds the 1024 x 1024 G
+  const int leaf_rows = (!tri && gws != nullptr && n % NB == 0 && m >= 64 * NB) ? imin(2 * LEAF_TRSM, imax(LEAF_TRSM, env_int("GPMP_TRSM_LEAF_ROWS", LEAF_TRSM)))
+                                                                               : LEAF_TRSM;
+  if (n <= leaf_rows) {
     static int fused = -1;
     if (fused < 0) { const char* e = getenv("GPMP_TRSM_FUSED_LEAF"); fused = e ? atoi(e) : 1; }
     const bool ok = fused && gws != nullptr && !tri && n % NB == 0 && m >= 4 * NB && (m % 2 == 0) && (ldb % 2 == 0) &&

@@ -153,6 +153,9 @@ def test_forward_solve_leaves_with_fitted_strip_widths(gnp, m, width, monkeypatc
     monkeypatch.setenv("GPMP_TRSM_LEAF_FIT", "0")
     X0 = F.solve_lower(B.clone())
     assert float((X - X0).abs().max()) < 1e-11 * float(X0.abs().max())
+    monkeypatch.setenv("GPMP_TRSM_LEAF_ROWS", "1024")          # the measured-neutral alternative: eight blocks per fused leaf
+    X2 = F.solve_lower(B.clone())
+    assert float((X2 - X0).abs().max()) < 1e-11 * float(X0.abs().max())
     cols = np.concatenate((np.arange(0, 300), np.arange(m - 300, m), rng.choice(m, 400, replace=False)))
     ref = sla.solve_triangular(np.tril(gnp.to_np(F.L)), B[:, torch.as_tensor(cols, device=B.device)].cpu().numpy(), lower=True)
     assert np.max(np.abs(X[:, torch.as_tensor(cols, device=B.device)].cpu().numpy() - ref)) < 1e-10 * np.max(np.abs(ref))
