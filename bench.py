@@ -74,10 +74,14 @@ def pmc_traffic_per_launch(kernel_substr):
             return None
         path = found[-1]   # the latest committed pass
         pmc_traffic_per_launch.source = os.path.relpath(os.path.dirname(path), ROOT) + "/" + re.sub(r"_(fetch|write)_", "_{fetch,write}_", os.path.basename(path))
+        kb, disp = 0.0, 0          # the kernel may appear as several template instances (tile widths): all of its launches together
         for row in csv.DictReader(open(path)):
             if kernel_substr in row["kernel"]:
-                tot += factor * 1024.0 * float(row["per_dispatch_KB_raw"])
-                n_disp = int(row["dispatches"])
+                kb += float(row["per_dispatch_KB_raw"]) * int(row["dispatches"])
+                disp += int(row["dispatches"])
+        if disp:
+            tot += factor * 1024.0 * kb / disp
+            n_disp = disp
     return tot if n_disp else None
 
 
@@ -875,6 +879,8 @@ def dist_extra_worker(args):
 # ------------------------------------------------------------------------------------------------------------------
 # the headline worker (one per GPU)
 # ------------------------------------------------------------------------------------------------------------------
+# the dominant kernel as rocprofv3 names it, up to the tile-width template argument (prefix match: every instance)
+DOMINANT_KERNEL = "gemm_f64_kernel_v2<true, false, true"
 METRIC = "fp64 predict+NLL throughput (points/s) and potrf TFLOP/s vs roofline, n=32k"
 
 
@@ -983,11 +989,12 @@ class HipWorkload:
         # Every flop of these launches is algorithmic: they are the plain rectangular products B2 -= L21 X1 of the
         # recursive solve (no triangular waste), so executed == algorithmic for THIS kernel.
         line["roofline"] = {
-            "bound": "mfma", "kernel": "gemm_f64_kernel_v2<true, false, true> (trsm updates B2 -= L21 X1, K >= 512)",
+            "bound": "mfma", "kernel": "gemm_f64_kernel_v2<true, false, true, W> (trsm updates B2 -= L21 X1, K >= 512; W = tile width 128 / 112 / 96: "
+                                       "ONE kernel template, its instances appear as separate rows in a rocprofv3 summary and are counted together here)",
             "achieved": nn_exec / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else None,
             "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": (nn_exec / (nn_ms * 1e-3) / 1e12) / FP64_MFMA_PEAK_TFLOPS if nn_ms > 0 else None,
-            "traffic": pmc_traffic_per_launch("gemm_f64_kernel_v2<true, false, true>") if (n, m) == (32768, 50000) else None,
+            "traffic": pmc_traffic_per_launch(DOMINANT_KERNEL) if (n, m) == (32768, 50000) else None,
             "traffic_note": "NOT measured in this run: bytes per launch at the fabric side of L2 (Infinity-Cache hits included) from the "
                             "latest COMMITTED rocprofv3 --pmc passes of this same command (separate FETCH_SIZE / WRITE_SIZE passes, "
                             "FETCH_SIZE x2 on gfx950 + WRITE_SIZE): " + str(getattr(pmc_traffic_per_launch, "source", None)),
@@ -1016,7 +1023,7 @@ class HipWorkload:
             # latest committed passes stays, and the note says which it is
             self.out = None
             torch.cuda.empty_cache()
-            live, note = pmc_traffic_live("gemm_f64_kernel_v2<true, false, true>", args)
+            live, note = pmc_traffic_live(DOMINANT_KERNEL, args)
             if live is not None:
                 line["roofline"]["traffic_committed_passes"] = line["roofline"]["traffic"]
                 line["roofline"]["traffic"], line["roofline"]["traffic_note"] = live, note
