@@ -273,6 +273,15 @@ def _comm_tensor(t: torch.Tensor, backend: str) -> torch.Tensor:
     return t.detach().to("cpu").contiguous()
 
 
+def _gloo_cuda_guard(t: torch.Tensor, group) -> None:
+    """gloo moves CUDA tensors, but its point-to-point send does not wait for the kernels that produce the tensor
+    (tools/gloo_cuda_p2p_probe.py: the receiver gets stale data); RCCL's operations are stream-ordered.  The device-resident
+    communication path is only ever combined with gloo by tests/test_dist_gpu.py's probe of that path on a shared GPU: there,
+    the producing stream is drained first.  No effect under RCCL or with CPU tensors."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 class _Streams:
     """The stream of the bulk trailing updates ("main") and one high-priority side stream (the panel chain and every
     collective).  With ``reserve_cus`` > 0 the bulk updates run on a CU-masked stream of their own, fenced against the
@@ -492,6 +501,7 @@ class BlockCyclicCholesky:
         moment -- messages of different steps can never be matched with each other."""
         ct = _comm_tensor(t, self.backend)
         me = self.grid.rank
+        _gloo_cuda_guard(ct, group)
         if self.transport == "p2p":
             self._log(group, "p2p_bcast", src_rank, ct.numel())
             if me == src_rank:
@@ -516,6 +526,7 @@ class BlockCyclicCholesky:
         g = self.grid
         dst, src = g.rank_of(g.r, (g.c - shift) % g.pc), g.rank_of(g.r, (g.c + shift) % g.pc)
         ct = _comm_tensor(t, self.backend)
+        _gloo_cuda_guard(ct, g.row_group)
         ncols2 = sum(self.bs(J) for J in g.local_col_blocks(self.nblocks, (g.c + shift) % g.pc))
         buf = torch.empty((ct.shape[0], ncols2), dtype=ct.dtype, device=ct.device)
         self._log(g.row_group, f"ring_shift{shift}", -1, ct.shape[0])     # (rows: the same on every member; the column counts differ by <= 1)

@@ -535,3 +535,22 @@ def test_distributed_model_surface_hip(tmp_path, pr, pc, meantype):
         o += len(ref)
         assert np.max(np.abs(seg - ref)) < tol
     assert abs(got[-1] - rc) < 1e-11 * cs * abs(rc)
+
+
+@pytest.mark.parametrize("pr,pc,transport", [(2, 2, "bcast"), (1, 2, "p2p")])
+def test_device_resident_communication_branches_over_gloo_cuda(pr, pc, transport):
+    """(round 4) The branches that only run under RCCL -- comm tensors, scalars and the few-column solve kept on the DEVICE,
+    collectives called with CUDA tensors from the three streams -- exercised without RCCL: gloo moves CUDA tensors too, so the
+    ranks share the one GPU with ``backend`` forced to the RCCL code path (tools/gloo_cuda_comm_probe.py).  Factorisation, NLL,
+    REML, universal kriging with weights, leave-one-out and the REML gradient against the oracle.  RCCL's own stream / ordering
+    behaviour is not what this can check."""
+    import subprocess
+    import sys
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gloo_cuda_comm_probe.py"), str(pr), str(pc), transport],
+                       env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0 and "DEVICE-COMM PROBE OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
