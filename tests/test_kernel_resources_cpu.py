@@ -14,7 +14,12 @@ CSRC = os.path.join(ROOT, "gpmp_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+_CACHE = {}
+
+
 def _resources(src):
+    if src in _CACHE:                      # one compile per source and test session (gemm_f64.hip: 24 template instances of the GEMM)
+        return _CACHE[src]
     cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
            "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", os.devnull]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
@@ -29,6 +34,7 @@ def _resources(src):
         m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
         if m and name:
             res[name][m.group(1).strip()] = int(m.group(2))
+    _CACHE[src] = res
     return res
 
 
