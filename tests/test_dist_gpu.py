@@ -77,7 +77,8 @@ def test_block_cyclic_cholesky_hip(tmp_path, pr, pc, n, nb, transport, lookahead
 def test_block_cyclic_cholesky_rccl(tmp_path, pr, pc, n, nb, transport, lookahead):
     """The same schedule over RCCL, one GPU per rank: both transports, look-ahead on and off.  Needs pr * pc GPUs --
     skipped on the one-GPU boxes of this pool (only the 1 x 1 grid runs there), so until a multi-GPU node has run it
-    the RCCL path with more than one rank is unproven and bench.py keeps its distributed extra opt-in."""
+    the RCCL path with more than one rank is unproven.  What the 1 x 1 grid CAN prove under RCCL -- every other distributed
+    entry point through ProcessGroupNCCL -- is test_every_distributed_entry_point_under_rccl below (round 5)."""
     if torch.cuda.device_count() < pr * pc:
         pytest.skip(f"needs {pr * pc} GPUs, have {torch.cuda.device_count()}")
     _run_and_check(tmp_path, pr, pc, n, nb, transport, lookahead, "nccl")
@@ -552,5 +553,28 @@ def test_device_resident_communication_branches_over_gloo_cuda(pr, pc, transport
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gloo_cuda_comm_probe.py"), str(pr), str(pc), transport],
+                       env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0 and "DEVICE-COMM PROBE OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("pr,pc,transport", [(1, 1, "bcast"), (1, 1, "p2p"), (1, 2, "bcast"), (2, 2, "p2p")])
+def test_every_distributed_entry_point_under_rccl(pr, pc, transport):
+    """(round 5) Every distributed entry point through ``ProcessGroupNCCL`` itself: factorisation, NLL, REML, universal kriging
+    WITH weights (forward + backward many-right-hand-side solves), leave-one-out, the REML and the noisy-ML value + gradient, the
+    ``DistributedModel`` surface (predict with ``return_lambdas=True``, loo, criterion) and a short ``fit_covparam`` run, against
+    the oracle.  RCCL wants one GPU per rank, so a one-GPU box runs the 1 x 1 grid (both transports) and skips the rest: that
+    covers communicator creation with the high-priority options (gpmp_amd/dist/grid.py:14-45), the four communicator kinds, the
+    device-resident comm tensors (gpmp_amd/dist/cholesky.py:269-284) and the work / stream waits under RCCL's own streams --
+    not an exchange between two ranks."""
+    import subprocess
+    import sys
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if torch.cuda.device_count() < pr * pc:
+        pytest.skip(f"needs {pr * pc} GPUs, have {torch.cuda.device_count()}")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gloo_cuda_comm_probe.py"), str(pr), str(pc), transport, "nccl"],
                        env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0 and "DEVICE-COMM PROBE OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
