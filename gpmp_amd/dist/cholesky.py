@@ -200,6 +200,16 @@ class HipLocalOps:
         self._lib.check(self.lib.gpmp_dgemm(1, 0, M, N, K, 1.0, g._ptr(A), g._ld(A), g._ptr(B), g._ld(B), 0.0, g._ptr(C), g._ld(C), 0,
                                             g._stream()), "gpmp_dgemm")
 
+    def gemm_tn_acc(self, A, B, C):
+        """C += A^T B through the library GEMM (C a strided view of the right shape)."""
+        g = self.gnp
+        K, M = A.shape
+        N = B.shape[1]
+        if M == 0 or N == 0 or K == 0:
+            return
+        self._lib.check(self.lib.gpmp_dgemm(1, 0, M, N, K, 1.0, g._ptr(A), g._ld(A), g._ptr(B), g._ld(B), 1.0, g._ptr(C), g._ld(C), 0,
+                                            g._stream()), "gpmp_dgemm")
+
     def grad_trace_cross(self, M, xr, xc, p, covparam, noise, F, G):
         """[sum M sigma^2 Kc, sum M dK/dlog(1/rho_j) ...] over the rectangular block M (rows: points xr, columns: points xc),
         M <- M - F G^T in registers: gpmp_matern_grad_trace_cross.  Returns a (1 + d,) device vector."""
@@ -1054,66 +1064,138 @@ class BlockCyclicCholesky:
         st.close()
         return Bloc
 
-    def solve_upper_many(self, Bloc: torch.Tensor) -> torch.Tensor:
+    def solve_upper_many(self, Bloc: torch.Tensor, overlap: Optional[bool] = None, profile: Optional[bool] = None) -> torch.Tensor:
         """X = L^-T B in place for a right-hand side distributed like ``solve_lower_many``'s (rows block-cyclic over the process
         rows, columns sharded over the process columns): the SECOND solve of ``cholesky_solve`` (gpmp/num/numpy_backend.py:468),
         which the kriging WEIGHTS lambda_t = L^-T (L^-1 Kit) need (gpmp/core/kriging.py:62, model.py:305-306).  Left-looking
         backward substitution over the block columns k = nblk-1 ... 0:
-            S_k = sum_{I > k} L_Ik^T X_I  -- every rank multiplies ITS rows of panel k (row-broadcast from process column k mod Pc,
-                                             as in the forward solve) with ITS rows of X, a TN product with a long contraction;
-                                             the partial sums are REDUCED inside the process column to process row k mod Pr
-            X_k = L_kk^-T (B_k - S_k)     -- on process row k mod Pr (L_kk row-broadcast as in the forward solve)
-        X_k is used only where it lives, so nothing is broadcast back: per step one diagonal message + one panel along the process
-        rows and one (bk x m_c) reduce inside each process column.  n^2 m flops, in order on the caller's stream (the weights are an
-        on-request by-product, not the throughput path)."""
+            S_k = sum_{I > k} L_Ik^T X_I,   X_k = L_kk^-T (B_k - S_k)
+        every rank multiplies ITS rows of panel k with ITS rows of X (TN products with a long contraction), the partial sums are
+        REDUCED inside the process column to process row k mod Pr, and X_k stays where it lives: nothing is broadcast back.  Per
+        block column k, split like the forward solve so that the bulk never waits for the step before it:
+          P(k)  prefetch: L_kk (+ its diagonal-block inverses) along process row k mod Pr, the panel L_{I>k, k} along every
+                process row                                                            [row communicators; factor data only]
+          U(k)  bulk:     S_k <- sum over the local block rows I >= k+2 of L_Ik^T X_I  [local TN GEMM, n^2 m flops in total]
+                          -- needs X_{k+2}, NOT X_{k+1}
+          C(k)  chain:    the process row that owns block row k+1 adds the ONE missing term L_{k+1,k}^T X_{k+1}; reduce inside
+                the process column; on process row k mod Pr: X_k = L_kk^-T (B_k - S_k)   [column communicators]
+        Schedule (round 5; the forward solve's pattern on the same three streams): U(k-1) runs on the caller's stream and
+        P(k-1) on the prefetch stream WHILE C(k) -- small product, reduce, 1024-row triangular solve -- runs on the side stream;
+        two buffers per message kind and per partial sum.  Row communicators are used from the prefetch stream only, column
+        communicators from the side stream only, in decreasing k on every member.  ``overlap=False`` (GPMP_DIST_SOLVE_OVERLAP=0)
+        issues the same operations in the same order on the caller's stream alone."""
         g, ops, nb = self.grid, self.ops, self.nb
+        if overlap is None:
+            overlap = os.environ.get("GPMP_DIST_SOLVE_OVERLAP", "1") != "0"
+        if profile is not None:
+            self.profile = profile
         mloc = Bloc.shape[1]
         nblk = self.nblocks
         row_members = [g.rank_of(g.r, cc) for cc in range(g.pc)]
         nbk = self.bs(0)
         ld0 = (nbk + 15) // 16 * 16
         nd0 = ((nbk + 127) // 128) * 128 * 128
-        Lbuf = self._flat(nbk * ld0 + nd0)
-        Pbuf = ops.empty(self.local_rows(), nb)
-        Sbuf = ops.empty(nb, mloc)
-        for k in range(nblk - 1, -1, -1):
-            rd, cd = g.owner_row(k), g.owner_col(k)
+        Lbuf = [self._flat(nbk * ld0 + nd0) for _ in range(2)]
+        Pbuf = [ops.empty(self.local_rows(), nb) for _ in range(2)]
+        Sbuf = [ops.empty(nb, mloc) for _ in range(2)]
+        self._marks = []
+        st = self._st = _Streams(getattr(ops, "device", None) if overlap else None, 0, getattr(ops, "lib", None))
+        pre_ctx, side_ctx = st.diag_ctx, st.side_ctx          # the "diagonal" stream of the factorisation carries the prefetch here
+        start = st.record(False)
+        l_ready, p_ready, x_done, u_done = {}, {}, {}, {}
+
+        def views(k):
             bk = self.bs(k)
             ldk = (bk + 15) // 16 * 16
             ndinv = ((bk + 127) // 128) * 128 * 128
-            buf = Lbuf[: bk * ldk + ndinv]
-            Lkk, dinv = buf[: bk * ldk].view(bk, ldk)[:, :bk], buf[bk * ldk:]
-            self._step_label = f"bsolve{k}"
-            if g.r == rd:
-                if g.c == cd:
-                    L0, d0 = self.diag_cache[k]
-                    Lkk.copy_(L0)
-                    dinv.copy_(d0[: dinv.numel()])
-                if g.pc > 1:
-                    self._bcast(buf, g.rank_of(rd, cd), g.row_group, row_members)
+            buf = Lbuf[k % 2][: bk * ldk + ndinv]
+            return bk, buf, buf[: bk * ldk].view(bk, ldk)[:, :bk], buf[bk * ldk:]
+
+        def prefetch(k):
+            rd, cd = g.owner_row(k), g.owner_col(k)
+            bk, buf, Lkk, dinv = views(k)
+            self._step_label = f"bsolve_pre{k}"
+            with pre_ctx():
+                st.wait_diag(start)
+                st.wait_diag(x_done.get(k + 2))      # C(k+2) has used L buffer and panel buffer (k+2) % 2
+                st.wait_diag(u_done.get(k + 2))      # U(k+2) has read panel k+2
+                with self._phase("bsolve_prefetch"):
+                    if g.r == rd:
+                        if g.c == cd:
+                            L0, d0 = self.diag_cache[k]
+                            Lkk.copy_(L0)
+                            dinv.copy_(d0[: dinv.numel()])
+                        if g.pc > 1:
+                            self._bcast(buf, g.rank_of(rd, cd), g.row_group, row_members)
+                    l_ready[k] = st.record_diag()
+                    i0 = self._first_row_after(k)
+                    Mr = self.roff[-1] - self.roff[i0]
+                    if Mr > 0:
+                        panel = Pbuf[k % 2][:Mr, :bk]
+                        if g.c == cd:
+                            lj = k // g.pc
+                            panel.copy_(self.A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]])
+                        if g.pc > 1:
+                            self._bcast(panel, g.rank_of(g.r, cd), g.row_group, row_members)
+                    p_ready[k] = st.record_diag()
+
+        def bulk(k):
+            """S_k <- the block rows I >= k+2 of this rank (zero when it has none): everything of S_k that X_{k+1} is not part of"""
+            bk = self.bs(k)
             i0 = self._first_row_after(k)
-            Mr = self.roff[-1] - self.roff[i0]
-            S = Sbuf[:bk, :]
-            if Mr > 0:
-                panel = Pbuf[:Mr, :bk]
-                if g.c == cd:
-                    lj = k // g.pc
-                    panel.copy_(self.A[self.roff[i0]:, self.coff[lj]:self.coff[lj + 1]])
-                if g.pc > 1:
-                    self._bcast(panel, g.rank_of(g.r, cd), g.row_group, row_members)
+            i2 = self._first_row_after(k + 1)
+            self._step_label = f"bsolve_bulk{k}"
+            st.wait(False, p_ready.get(k))
+            st.wait(False, x_done.get(k + 2))        # X_{k+2} is final; C(k+2) has finished with partial-sum buffer k % 2
+            with st.main_ctx(), self._phase("bsolve_bulk"):
                 if mloc:
-                    ops.gemm_tn_into(panel, Bloc[self.roff[i0]:, :], S)
-            elif mloc:
-                S.zero_()
-            if not mloc:
-                continue
-            if g.pr > 1:
-                self._reduce(S, g.rank_of(rd, g.c), g.col_group, "bsolve")
-            if g.r == rd:
-                li = k // g.pr
-                Bk = Bloc[self.roff[li]:self.roff[li + 1], :]
-                Bk.sub_(S)
-                ops.trsm_left_t(Lkk, dinv, Bk)
+                    S = Sbuf[k % 2][:bk, :]
+                    if self.roff[-1] - self.roff[i2] > 0:
+                        off = self.roff[i2] - self.roff[i0]
+                        ops.gemm_tn_into(Pbuf[k % 2][off: self.roff[-1] - self.roff[i0], :bk], Bloc[self.roff[i2]:, :], S)
+                    else:
+                        S.zero_()
+            u_done[k] = st.record(False)
+
+        def chain(k):
+            rd = g.owner_row(k)
+            bk, buf, Lkk, dinv = views(k)
+            self._step_label = f"bsolve{k}"
+            with side_ctx():
+                st.wait(True, start)
+                st.wait(True, l_ready.get(k))
+                st.wait(True, p_ready.get(k))
+                st.wait(True, u_done.get(k))
+                st.wait(True, x_done.get(k + 1))
+                with self._phase("bsolve_chain"):
+                    if mloc:
+                        S = Sbuf[k % 2][:bk, :]
+                        if k + 1 < nblk and g.r == g.owner_row(k + 1):
+                            # the one term the bulk product left out: block row k+1, the FIRST rows of this rank's panel k
+                            li1 = (k + 1) // g.pr
+                            b1 = self.bs(k + 1)
+                            ops.gemm_tn_acc(Pbuf[k % 2][:b1, :bk], Bloc[self.roff[li1]:self.roff[li1 + 1], :], S)
+                        if g.pr > 1:
+                            self._reduce(S, g.rank_of(rd, g.c), g.col_group, "bsolve")
+                        if g.r == rd:
+                            li = k // g.pr
+                            Bk = Bloc[self.roff[li]:self.roff[li + 1], :]
+                            Bk.sub_(S)
+                            ops.trsm_left_t(Lkk, dinv, Bk)
+                x_done[k] = st.record(True)
+
+        prefetch(nblk - 1)
+        bulk(nblk - 1)
+        for k in range(nblk - 1, -1, -1):
+            if k >= 1:
+                prefetch(k - 1)
+                bulk(k - 1)                           # independent of C(k): runs beside it
+            chain(k)
+            for evs in (l_ready, p_ready, x_done, u_done):      # keep three steps of events
+                evs.pop(k + 3, None)
+        st.wait(False, x_done.get(0))
+        st.wait(False, p_ready.get(0))
+        st.close()
         return Bloc
 
     def predict_zero_mean(self, cov, x, z, xt, covparam):

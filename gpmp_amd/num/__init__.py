@@ -526,8 +526,8 @@ def svd(A, full_matrices=True, hermitian=True):
     """(U, s, Vt) with A = U diag(s) Vt, singular values in decreasing order -- scipy.linalg.svd / torch.linalg.svd of the
     reference backends, for the SQUARE matrices the path hands it (gpmp/core/sample_paths.py:54-58: a covariance matrix that is
     only positive semi-definite).  One-sided Jacobi on the library's own kernel (gpmp_jacobi_sweep: rows of G = A rotated until
-    mutually orthogonal, the rotations accumulated in W = U^T); singular vectors of numerically zero singular values are
-    completed from U (``hermitian``: A symmetric, v_i = +-u_i).  Non-square input does not occur on the path: host LAPACK."""
+    mutually orthogonal, the rotations accumulated in W = U^T).  ``hermitian`` is ignored, as in the reference backends: symmetry
+    and definiteness are detected, never assumed.  Non-square input does not occur on the path: host LAPACK."""
     lib = _lib.load()
     A = asarray(A)
     if A.dim() != 2 or A.shape[0] != A.shape[1]:
@@ -553,13 +553,32 @@ def svd(A, full_matrices=True, hermitian=True):
     s, G, W = s[order], G[order], W[order]
     U = W.T.contiguous()
     ok = s > builtins.max(tiny, n * eps * float(s[0]))
-    if hermitian:
-        # A symmetric: v_i = +-u_i, and the rows of W (a product of plane rotations) are orthonormal to rounding, whereas
-        # g_i / s_i carries the relative noise eps s_0 / s_i of a small singular value
-        sgn = torch.where(torch.sum(G * W, dim=1) < 0.0, -torch.ones_like(s), torch.ones_like(s))
-        Vt = sgn.reshape(-1, 1) * W
+    # ``hermitian`` is accepted and NOT trusted: the reference backends ignore it and compute a general SVD
+    # (gpmp/num/torch_backend.py:833-834).  The shortcut v_i = u_i is taken only where it is verified: A symmetric to rounding
+    # and every kept singular pair with u_i . v_i > 0 (a positive semi-definite matrix -- the covariance matrices of
+    # gpmp/core/sample_paths.py:54-58); there the rows of W (a product of plane rotations) are orthonormal to rounding, whereas
+    # g_i / s_i carries the relative noise eps s_0 / s_i of a small singular value.  Everything else gets Vt = G / s row by row --
+    # exact by construction (G = diag(s) Vt), also for a symmetric INDEFINITE matrix with a +-lambda pair, whose singular
+    # subspace is two-dimensional (v_i != +-u_i in general).
+    amax = float(A.abs().max())
+    symmetric = bool(float((A - A.T).abs().max()) <= 8.0 * eps * amax)
+    dots = torch.sum(G * W, dim=1)
+    if symmetric and bool(torch.all(torch.where(ok, dots > 0.5 * s, torch.ones_like(ok)))):
+        Vt = W.clone()
     else:
         Vt = torch.where(ok.reshape(-1, 1), G / torch.where(ok, s, torch.ones_like(s)).reshape(-1, 1), W)
+        nbad = int((~ok).sum())
+        if nbad and not symmetric:
+            # numerically zero singular values of a NON-symmetric matrix: the matching rows of W are left null vectors; the
+            # right ones are the orthogonal complement of the kept rows of Vt (Householder reflectors, never on the GP path)
+            r = n - nbad
+            if r == 0:
+                Vt = torch.eye(n, dtype=torch.float64, device=_dev())
+            else:
+                from .householder import HouseholderQR
+
+                h = HouseholderQR(Vt[:r].T.contiguous())
+                Vt = torch.cat((Vt[:r], h.columns(r, n).T), dim=0)
     s = torch.where(ok, s, torch.zeros_like(s))
     return U, s, Vt
 

@@ -16,7 +16,10 @@ def _gnp():
 
 
 class HouseholderQR:
-    def __init__(self, P):
+    def __init__(self, P, check_rank=True):
+        """``check_rank``: the kriging callers (contrast matrices, contrast-space predictor) need a full-rank mean design and get
+        a LinAlgError otherwise; the generic ``gnp.qr`` proceeds like LAPACK's geqrf -- a column that is already zero below the
+        diagonal gets tau = 0 (H_k = I) and a zero R_kk."""
         gnp = _gnp()
         A = gnp.asarray(P).clone()
         if A.dim() != 2:
@@ -30,7 +33,14 @@ class HouseholderQR:
             x = A[k:, k]
             nx = float(torch.sqrt(torch.sum(x * x)))
             if not nx > n * gnp.eps * scale[k]:
-                raise numpy.linalg.LinAlgError("singular mean design: P is rank deficient")
+                if check_rank:
+                    raise numpy.linalg.LinAlgError("singular mean design: P is rank deficient")
+                if nx == 0.0:                                  # geqrf: nothing to annihilate, H_k = I
+                    v = gnp.zeros((n,))
+                    v[k] = 1.0
+                    self.v.append(v)
+                    self.tau.append(0.0)
+                    continue
             alpha = -nx if float(x[0]) >= 0.0 else nx
             v = gnp.zeros((n,))
             v[k:] = x
@@ -90,8 +100,8 @@ def qr(A, mode="reduced"):
     if q >= n or q == 0:
         # square / wide / empty inputs do not occur on the GP path (a mean design has q < n columns): host LAPACK
         Qh, Rh = numpy.linalg.qr(gnp.to_np(A), mode="complete" if mode == "complete" else "reduced")
-        return gnp.asarray(Qh), gnp.asarray(Rh)
-    h = HouseholderQR(A)
+        return gnp.asarray(Rh) if mode == "r" else (gnp.asarray(Qh), gnp.asarray(Rh))
+    h = HouseholderQR(A, check_rank=False)
     if mode == "r":
         return h.R
     if mode == "complete":

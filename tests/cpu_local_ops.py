@@ -73,6 +73,10 @@ class CpuLocalOps:
     def gemm_tn_into(self, A, B, C):
         C.copy_(A.T @ B)
 
+    def gemm_tn_acc(self, A, B, C):
+        if C.numel():
+            C.add_(A.T @ B)
+
     def grad_trace_cross(self, M, xr, xc, p, covparam, noise, F, G):
         """NumPy restatement of gpmp_matern_grad_trace_cross (oracle formulas: oracle/gp_oracle.py covariance_gradient_traces)"""
         import math

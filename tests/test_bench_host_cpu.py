@@ -33,3 +33,33 @@ def test_latest_pmc_pass_is_chosen_numerically(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     got = bench.pmc_traffic_per_launch("k<true, false, true>")
     assert got == (2.0 * 7.0 + 7.0) * 1024.0       # v10: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, in bytes
+
+
+def test_cpu_baseline_is_a_same_run_measurement_with_a_bounded_child(monkeypatch):
+    """(round 5) `cpu_baseline.value` = ONE full-size oracle step measured in a child process of this run (cores stated, not
+    assembled); a child that exceeds its limit costs only itself: the assembled model takes over and says so."""
+    import bench
+
+    monkeypatch.setenv("GPMP_BENCH_CPU_FULL", "1")
+    out = bench.cpu_baseline_for_line(1536, 700, 8, bench._host_threads(), 256)
+    assert out["assembled"] is False and out["kind"] == "port" and out["cores"] == bench._host_threads()
+    assert out["full_size_run"]["note"] == "measured in THIS run"
+    assert abs(out["value"] - 700 / out["full_size_run"]["s_per_step"]) < 1e-9 * out["value"]
+    assert out["host_potrf"]["tflops"] > 0 and np.isfinite(out["full_size_run"]["nll"])
+    monkeypatch.setenv("GPMP_BENCH_CPU_FULL_TIMEOUT", "0.05")
+    out = bench.cpu_baseline_for_line(1536, 700, 8, bench._host_threads(), 256)
+    assert out["assembled"] is True and out["sample"].startswith("FALL-BACK") and "exceeded its limit" in out["measured_step_failed"]
+
+
+def test_latest_committed_cpu_log_is_chosen_by_round_number(tmp_path, monkeypatch):
+    import json
+
+    import bench
+
+    for rnd, s in ((4, 175.0), (10, 150.0), (9, 160.0)):
+        d = tmp_path / "profiles" / f"r{rnd}"
+        d.mkdir(parents=True)
+        (d / "cpu_fullsize_step.log").write_text(json.dumps({"tool": "cpu_fullsize_step", "n": 8, "m": 4, "d": 2, "full_step_s": s,
+                                                             "points_per_s": 4 / s, "threads": 16}) + "\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench._latest_cpu_fullsize_log(8, 4, 2)["s_per_step"] == 150.0        # r10 is later than r9 and r4

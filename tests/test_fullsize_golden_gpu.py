@@ -119,7 +119,7 @@ def test_config4_fused_c_driver_vs_reference_autograd_n16384_d20(gp, name):
 
 
 # ---------------------------------------------------------------------------------------------- config 3
-def test_config3_predict_and_nll_vs_reference_n32768_m50000(gp):
+def test_config3_predict_and_nll_vs_pinned_oracle_n32768_m50000(gp):
     import torch
 
     import gpmp_amd.num as gnp

@@ -356,8 +356,8 @@ def main():
     ap.add_argument("--transport", default="bcast")
     ap.add_argument("--device-comm", action="store_true")
     ap.add_argument("--limit", type=float, default=1500.0, help="seconds allowed to the distributed side before its workers are killed")
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "config5_single.npz"))
-    ap.add_argument("--dist-out", default=os.path.join(ROOT, "gpurun_out", "config5_dist.npz"))
+    ap.add_argument("--out", default="/tmp/config5_single.npz")
+    ap.add_argument("--dist-out", default="/tmp/config5_dist.npz")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     if a.what == "single":

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--step-m", type=int, default=0, help="also time one emulated HEADLINE STEP on the block-cyclic factor: (Gram + factor + "
                     "zero-mean prediction at this many points) + (Gram + factor + NLL), what extra.strong_scaling_block_cyclic of bench.py "
                     "runs on the real grid; compute only (collectives stubbed)")
+    ap.add_argument("--lambdas", action="store_true", help="with --solve-m: also time the BACKWARD many-right-hand-side solve (the kriging "
+                    "weights of return_lambdas=True), with and without the prefetch / bulk / chain overlap")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -66,6 +68,9 @@ def main():
             return t
 
         def _world_bcast(self, t, src_rank):
+            return t
+
+        def _reduce(self, t, dst_rank, group, what):          # (the backward solve's partial sums stay where they are)
             return t
 
     n, d = a.n, 8
@@ -103,6 +108,19 @@ def main():
             solve["overlap" if overlap else "in_order"] = {"s": dt, "rank_share_tflops": solve["rank_share_flops"] / dt / 1e12,
                                                            "phases_ms": {k: round(v, 2) for k, v in ch.phase_times().items()}}
             del B
+        if a.lambdas:
+            solve["backward"] = {}
+            for overlap in (True, False, True):
+                B = gnp.alloc_matrix(ch.local_rows(), mc)
+                B.copy_(torch.randn(ch.local_rows(), mc, dtype=torch.float64, device=B.device) * 1e-3)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                ch.solve_upper_many(B, overlap=overlap, profile=True)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t3
+                solve["backward"]["overlap" if overlap else "in_order"] = {"s": dt, "rank_share_tflops": solve["rank_share_flops"] / dt / 1e12,
+                                                                           "phases_ms": {k: round(v, 2) for k, v in ch.phase_times().items()}}
+                del B
     grad = None
     if a.grad:
         xh = np.asarray(rng.random((n, d)))
