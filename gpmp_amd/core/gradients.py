@@ -100,8 +100,8 @@ class REMLAnalytic:
 
 
 # ---- many small problems in one call ------------------------------------------------------------------
-BATCH_MAX_N = 2048      # GPMP_BATCH_MAX_N
-BATCH_MAX_Q = 7
+BATCH_MAX_N = 4096      # GPMP_BATCH_MAX_N (include/gpmp_hip.h)
+BATCH_MAX_Q = 16        # GPMP_BATCH_MAX_Q
 
 
 def batch_qualifies(model, use_mean=False):
@@ -113,7 +113,7 @@ def batch_qualifies(model, use_mean=False):
 def batch_piece_limit(nmax, d, q, want_grad, device=None):
     """Largest number of problems of up to ``nmax`` points whose workspace fits the budget of ONE library call (a quarter
     of the free device memory, at most 32 GiB; GPMP_BATCH_WS_BUDGET_MB overrides): two nmax x nmax matrices per problem
-    with gradients, 70 MB at 2048 points.  0: the shape is outside the batched kernel's limits."""
+    with gradients, 70 MB at 2048 points, 270 MB at 4096.  0: the shape is outside the batched kernel's limits."""
     lib = _lib.load()
     per_problem = 8 * int(lib.gpmp_batch_ws_elems(int(nmax), int(d), int(q), 1, 1 if want_grad else 0))
     if per_problem == 0:
@@ -132,9 +132,9 @@ def batch_values_and_gradients(model, covparams, batches, want_grad=True, use_me
     (gpmp/num/torch_backend.py:607-718) and multi-parameter log_prob evaluations (gpmp/mcmc/param_posterior.py:229-278).
 
     ``batches``: list of (x_b, z_b) device arrays; ``covparams``: one parameter vector (shared) or a (B, ntheta) array.
-    ``use_mean``: REML with ``model.mean`` as the linear predictor (q <= 7 columns), else the zero-mean NLL.
+    ``use_mean``: REML with ``model.mean`` as the linear predictor (q <= 16 columns), else the zero-mean NLL.
     Returns ``(values, grads)`` as NumPy arrays ((B,), (B, ntheta) or None), or ``None`` when the batch does not
-    qualify (not a declared Matern covariance, a batch above 2048 points, more than 7 mean columns): the caller then
+    qualify (not a declared Matern covariance, a batch above 4096 points, more than 16 mean columns): the caller then
     evaluates the batches one after the other.  A failed factorisation raises ``HipLinAlgError`` like the array path."""
     cov = model.covariance
     if not isinstance(cov, MaternCovariance) or len(batches) == 0:
@@ -229,7 +229,7 @@ MLZeroMeanAnalytic.batch_piece_limit = REMLAnalytic.batch_piece_limit = staticme
 
 def _many(self, P, xi, zi, want_grad=False):
     """the criterion at every row of ``P`` on the same data: one batched call with per-problem parameters (the data are
-    replicated per row: at most 2048 x d doubles each).  None when the batched driver does not apply."""
+    replicated per row: at most 4096 x d doubles each).  None when the batched driver does not apply."""
     P = numpy.atleast_2d(numpy.asarray(P, dtype=numpy.float64))
     xi, zi = gnp.asarray(xi), gnp.asarray(zi)
     return self.batch_values_and_gradients(P, [(xi, zi)] * P.shape[0], want_grad)

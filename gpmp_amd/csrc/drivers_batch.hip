@@ -1,11 +1,11 @@
-// Many small GP problems at once: B independent criteria (zero-mean NLL, or REML with a mean design of q <= 7 columns)
+// Many small GP problems at once: B independent criteria (zero-mean NLL, or REML with a mean design of q <= 16 columns)
 // with their analytic gradients, every step ONE launch over all problems.  This is the throughput caller of SURVEY 8(f).4:
 //   * mini-batch selection criteria -- the weighted mean over the batches of a loader of the per-batch NLL / REML and its
 //     gradient (gpmp/num/torch_backend.py:607-718, gpmp/dataloader.py:484-513): B batches, ONE parameter vector;
 //   * posterior samplers / multi-chain optimisers -- log_prob = -criterion at many parameter vectors on the same data
 //     (gpmp/mcmc/param_posterior.py:229-278): ONE data set, B parameter vectors.
 // Per problem the reference runs cdist -> Matern -> cholesky -> 2 solve_triangular (-> autograd backward); on the GPU
-// a problem of n <= 2048 points is far too small to fill the machine (0.2 - 2 ms each, latency-bound), so problems
+// a problem of n <= 4096 points is too small to fill the machine (0.2 - 3 ms each, latency-bound), so problems
 // are stacked: one padded n_max x n_max slot each (identity padding: log-det and quadratic form unchanged), and
 //   Gram build          B small launches of the fused distance + Matern kernel (lower tiles, own parameters / own points)
 //   Cholesky            the blocked right-looking factorisation with every kernel batched over the problems
@@ -21,10 +21,11 @@
 namespace gpmp {
 namespace {
 
-constexpr int BQ = 7;              // mean-design columns supported in the batched path (round 2: 3; a linear mean in d <= 6 fits now)
-constexpr int BR = BQ + 1;         // right-hand sides per problem: [z, P]; the kernels exist for 4 (q <= 3) and 8 of them
-constexpr int BSM = 80;            // doubles of per-problem scalars: [0] logdet K, [1] quad, [2] ln|S|, [3] ln|PtP|, [4] fail,
-                                   // [8 + a] c = S^-1 b, [16 + BQ a + b] S^-1
+constexpr int BQ = 16;             // mean-design columns supported in the batched path (round 2: 3, then 7; round 5: 16 = what the
+                                   // single-problem drivers' mean-space workgroup carries: a linear mean in d <= 15)
+constexpr int BR = BQ + 1;         // right-hand sides per problem: [z, P]; the kernels exist for 4 (q <= 3), 8 (q <= 7) and 17 of them
+constexpr int BSM = 288;           // doubles of per-problem scalars: [0] logdet K, [1] quad, [2] ln|S|, [3] ln|PtP|, [4] fail,
+                                   // [8 + a] c = S^-1 b, [24 + BQ a + b] S^-1
 inline long pad16(long v) { return (v + 15) / 16 * 16; }
 
 // identity in the padding of one slot: rows / columns n .. nmax - 1 (lower triangle + diagonal are what the factorisation reads)
@@ -140,9 +141,82 @@ __global__ void __launch_bounds__(256) batch_trsv_kernel(const double* __restric
 //   q = 0:  value = 1/2 (n ln 2 pi + ln|K| + w^T w)
 //   q > 0:  value = 1/2 ((n - q) ln 2 pi + ln|K| + ln|S| - ln|P^T P| + w^T w - b^T S^-1 b),  S = Wp^T Wp, b = Wp^T w
 // small (BSM doubles per problem) keeps S^-1 and c = S^-1 b for the gradient; info[b] += n + pivot on a singular mean design.
-// QT: mean-design columns the instantiation carries (3 or 7); sums: [0] log L_ii, then the upper triangles of W^T W
-// ((QT + 1) x (QT + 1)) and of P^T P (QT x QT) -- 17 sums for QT = 3, 65 for QT = 7; reduced by wave shuffles, then across the
-// four waves through LDS (a 256 x 65 LDS image would not fit)
+// The sums: [0] log L_ii, then the upper triangles of W^T W ((QT + 1) x (QT + 1)) and of P^T P (QT x QT), QT = the mean-design
+// columns the instantiation carries.  `batch_value_finish` (one thread) turns their totals into the value.
+template <int QT>
+__device__ void batch_value_finish(const double* tot, int q, int n, int b, double* __restrict__ small, int* __restrict__ info,
+                                   double* __restrict__ values) {
+  constexpr int RT = QT + 1;
+  double G[RT][RT], PtP[QT][QT];
+  {
+    int k = 1;
+    for (int c = 0; c < RT; ++c)
+      for (int e = c; e < RT; ++e) { G[c][e] = G[e][c] = tot[k]; ++k; }
+    for (int c = 0; c < QT; ++c)
+      for (int e = c; e < QT; ++e) { PtP[c][e] = PtP[e][c] = tot[k]; ++k; }
+  }
+  const double logdetK = 2.0 * tot[0];
+  double* sm = small + (long)b * BSM;
+  int fail = 0;
+  double ldS = 0.0, ldP = 0.0, quad = G[0][0];
+  if (q > 0) {
+    // Cholesky of a q x q matrix (q <= QT) with the relative pivot test of the single-problem driver
+    auto chol = [&](double (*M)[QT], double& logdet) {
+      double d0[QT];
+      for (int k = 0; k < q; ++k) d0[k] = M[k][k];
+      logdet = 0.0;
+      for (int k = 0; k < q; ++k) {
+        double dkk = M[k][k];
+        for (int l = 0; l < k; ++l) dkk -= M[k][l] * M[k][l];
+        if (!(dkk > (double)q * 2.220446049250313e-16 * d0[k])) { if (fail == 0) fail = k + 1; dkk = 1.0; }
+        const double rkk = sqrt(dkk);
+        M[k][k] = rkk;
+        logdet += 2.0 * log(rkk);
+        for (int i = k + 1; i < q; ++i) {
+          double v = M[i][k];
+          for (int l = 0; l < k; ++l) v -= M[i][l] * M[k][l];
+          M[i][k] = v / rkk;
+        }
+      }
+    };
+    double S[QT][QT], Pm[QT][QT], bvec[QT];
+    for (int c = 0; c < q; ++c) {
+      bvec[c] = G[1 + c][0];
+      for (int e = 0; e < q; ++e) { S[c][e] = G[1 + c][1 + e]; Pm[c][e] = PtP[c][e]; }
+    }
+    chol(Pm, ldP);
+    chol(S, ldS);
+    // R^-1 (lower), S^-1 = R^-T R^-1, c = S^-1 b
+    double Ri[QT][QT];
+    for (int j = 0; j < q; ++j)
+      for (int i = 0; i < q; ++i) {
+        double s = (i == j) ? 1.0 : 0.0;
+        for (int l = j; l < i; ++l) s -= S[i][l] * Ri[l][j];
+        Ri[i][j] = (i < j) ? 0.0 : s / S[i][i];
+      }
+    double bsb = 0.0;
+    for (int i = 0; i < q; ++i) {
+      double ci = 0.0;
+      for (int j = 0; j < q; ++j) {
+        double s = 0.0;
+        for (int l = (i > j ? i : j); l < q; ++l) s += Ri[l][i] * Ri[l][j];
+        sm[24 + BQ * i + j] = s;
+        ci += s * bvec[j];
+      }
+      sm[8 + i] = ci;
+      bsb += bvec[i] * ci;
+    }
+    quad -= bsb;
+  }
+  sm[0] = logdetK; sm[1] = quad; sm[2] = ldS; sm[3] = ldP; sm[4] = (double)fail;
+  if (fail != 0) atomicCAS(info + b, 0, n + fail);
+  double v = 0.5 * ((double)(n - q) * 1.8378770664093454835606594728112 + logdetK + ldS - ldP + quad);
+  if (info[b] != 0 || !(v == v) || v > DBL_MAX || v < -DBL_MAX) v = __builtin_huge_val();
+  values[b] = v;
+}
+
+// QT = 3 or 7: every thread keeps all sums in registers (17 / 65 of them) over its rows; reduced by wave shuffles, then across
+// the four waves through LDS (a 256 x 65 LDS image would not fit)
 template <int QT>
 __global__ void __launch_bounds__(256) batch_value_kernel(const double* __restrict__ Lall, long ldl, long sl, const double* __restrict__ Wall,
                                                           long ldw, long sw, const double* __restrict__ P, long ldp, long sp, int q,
@@ -183,74 +257,73 @@ __global__ void __launch_bounds__(256) batch_value_kernel(const double* __restri
     if ((t & 63) == 0) red[t >> 6][k] = v;
   }
   __syncthreads();
-  if (t != 0) return;
-  double G[BR][BR], PtP[BQ][BQ];
-  {
-    int k = 1;
-    for (int c = 0; c < RT; ++c)
-      for (int e = c; e < RT; ++e) { G[c][e] = G[e][c] = red[0][k] + red[1][k] + red[2][k] + red[3][k]; ++k; }
-    for (int c = 0; c < QT; ++c)
-      for (int e = c; e < QT; ++e) { PtP[c][e] = PtP[e][c] = red[0][k] + red[1][k] + red[2][k] + red[3][k]; ++k; }
-  }
-  const double sumlog = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-  const double logdetK = 2.0 * sumlog;
-  double* sm = small + (long)b * BSM;
-  int fail = 0;
-  double ldS = 0.0, ldP = 0.0, quad = G[0][0];
-  if (q > 0) {
-    // Cholesky of a q x q matrix (q <= BQ) with the relative pivot test of the single-problem driver
-    auto chol = [&](double (*M)[BQ], double& logdet) {
-      double d0[BQ];
-      for (int k = 0; k < q; ++k) d0[k] = M[k][k];
-      logdet = 0.0;
-      for (int k = 0; k < q; ++k) {
-        double dkk = M[k][k];
-        for (int l = 0; l < k; ++l) dkk -= M[k][l] * M[k][l];
-        if (!(dkk > (double)q * 2.220446049250313e-16 * d0[k])) { if (fail == 0) fail = k + 1; dkk = 1.0; }
-        const double rkk = sqrt(dkk);
-        M[k][k] = rkk;
-        logdet += 2.0 * log(rkk);
-        for (int i = k + 1; i < q; ++i) {
-          double v = M[i][k];
-          for (int l = 0; l < k; ++l) v -= M[i][l] * M[k][l];
-          M[i][k] = v / rkk;
-        }
-      }
-    };
-    double S[BQ][BQ], Pm[BQ][BQ], bvec[BQ];
-    for (int c = 0; c < q; ++c) {
-      bvec[c] = G[1 + c][0];
-      for (int e = 0; e < q; ++e) { S[c][e] = G[1 + c][1 + e]; Pm[c][e] = PtP[c][e]; }
+  for (int k = t; k < NS; k += 256) red[0][k] += red[1][k] + red[2][k] + red[3][k];
+  __syncthreads();
+  if (t == 0) batch_value_finish<QT>(red[0], q, n, b, small, info, values);
+}
+
+// QT = 16 (7 < q <= 16, round 5): 290 sums do not fit a thread's registers, so the roles turn: rows go through LDS 64 at a time and
+// every thread owns at most two (column, column) PAIRS of W^T W / P^T P over ALL rows; the log-diagonal sum rides on one wave.
+__global__ void __launch_bounds__(256) batch_value_wide_kernel(const double* __restrict__ Lall, long ldl, long sl, const double* __restrict__ Wall,
+                                                               long ldw, long sw, const double* __restrict__ P, long ldp, long sp, int q,
+                                                               const int* __restrict__ ns, int nmax, double* __restrict__ small,
+                                                               int* __restrict__ info, double* __restrict__ values) {
+  constexpr int QT = BQ, RT = QT + 1, CH = 64;
+  constexpr int NW = RT * (RT + 1) / 2, NP = QT * (QT + 1) / 2, NS = 1 + NW + NP;
+  __shared__ double rows[CH][RT + QT + 1];            // [w_0 .. w_q | p_0 .. p_{q-1}] of 64 rows (odd stride: no bank pattern)
+  __shared__ double tot[NS];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const double* L = Lall + (long)b * sl;
+  const double* W = Wall + (long)b * sw;
+  const int n = ns[b];
+  // the pairs of this thread: k = t and k = t + 256 in the order of the totals (W pairs first, then P pairs), as LDS columns
+  int ca[2], cb[2];
+  for (int s = 0; s < 2; ++s) {
+    int k = t + 256 * s;
+    ca[s] = cb[s] = -1;
+    if (k < NW) {
+      int c = 0;
+      while (k >= RT - c) { k -= RT - c; ++c; }
+      ca[s] = c; cb[s] = c + k;
+    } else if (k < NW + NP) {
+      k -= NW;
+      int c = 0;
+      while (k >= QT - c) { k -= QT - c; ++c; }
+      ca[s] = RT + c; cb[s] = RT + c + k;
     }
-    chol(Pm, ldP);
-    chol(S, ldS);
-    // R^-1 (lower), S^-1 = R^-T R^-1, c = S^-1 b
-    double Ri[BQ][BQ];
-    for (int j = 0; j < q; ++j)
-      for (int i = 0; i < q; ++i) {
-        double s = (i == j) ? 1.0 : 0.0;
-        for (int l = j; l < i; ++l) s -= S[i][l] * Ri[l][j];
-        Ri[i][j] = (i < j) ? 0.0 : s / S[i][i];
-      }
-    double bsb = 0.0;
-    for (int i = 0; i < q; ++i) {
-      double ci = 0.0;
-      for (int j = 0; j < q; ++j) {
-        double s = 0.0;
-        for (int l = (i > j ? i : j); l < q; ++l) s += Ri[l][i] * Ri[l][j];
-        sm[16 + BQ * i + j] = s;
-        ci += s * bvec[j];
-      }
-      sm[8 + i] = ci;
-      bsb += bvec[i] * ci;
-    }
-    quad -= bsb;
   }
-  sm[0] = logdetK; sm[1] = quad; sm[2] = ldS; sm[3] = ldP; sm[4] = (double)fail;
-  if (fail != 0) atomicCAS(info + b, 0, n + fail);
-  double v = 0.5 * ((double)(n - q) * 1.8378770664093454835606594728112 + logdetK + ldS - ldP + quad);
-  if (info[b] != 0 || !(v == v) || v > DBL_MAX || v < -DBL_MAX) v = __builtin_huge_val();
-  values[b] = v;
+  double a0 = 0.0, a1 = 0.0, lg = 0.0;
+  for (int i0 = 0; i0 < nmax; i0 += CH) {
+    for (int idx = t; idx < CH * (RT + QT); idx += 256) {
+      const int l = idx / (RT + QT), c = idx % (RT + QT), i = i0 + l;
+      double v = 0.0;
+      if (i < nmax) {
+        if (c < RT) { if (c <= q) v = W[(long)i * ldw + c]; }
+        else if (c - RT < q && i < n) v = P[(long)b * sp + (long)i * ldp + (c - RT)];
+      }
+      rows[l][c] = v;
+    }
+    if (t < CH && i0 + t < nmax) lg += log(L[(long)(i0 + t) * ldl + i0 + t]);
+    __syncthreads();
+    if (ca[0] >= 0) {
+#pragma unroll 8
+      for (int l = 0; l < CH; ++l) a0 = fma(rows[l][ca[0]], rows[l][cb[0]], a0);
+    }
+    if (ca[1] >= 0) {
+#pragma unroll 8
+      for (int l = 0; l < CH; ++l) a1 = fma(rows[l][ca[1]], rows[l][cb[1]], a1);
+    }
+    __syncthreads();
+  }
+  if (t < 64) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
+    if (t == 0) tot[0] = lg;
+  }
+  if (ca[0] >= 0) tot[1 + t] = a0;
+  if (ca[1] >= 0) tot[1 + t + 256] = a1;
+  __syncthreads();
+  if (t == 0) batch_value_finish<QT>(tot, q, n, b, small, info, values);
 }
 
 // rows of the low-rank part of the gradient trace: F[i] = [U_i S^-1, beta_i], G[i] = [U_i, beta_i], beta = alpha - U c
@@ -267,7 +340,7 @@ __global__ void batch_rows_kernel(const double* __restrict__ Xall, long ldx, lon
   for (int a = 0; a < q; ++a) beta -= xr[1 + a] * sm[8 + a];
   for (int a = 0; a < q; ++a) {
     double s = 0.0;
-    for (int l = 0; l < q; ++l) s += xr[1 + l] * sm[16 + BQ * l + a];
+    for (int l = 0; l < q; ++l) s += xr[1 + l] * sm[24 + BQ * l + a];
     F[a] = s;
     G[a] = xr[1 + a];
   }
@@ -334,7 +407,7 @@ extern "C" int gpmp_nll_grad_batch(const double* x, long stride_x, const double*
                                    double* grads_dev, int* info_dev, gpmp_stream_t stream) {
   GPMP_ARG(x != nullptr, 1, "x is NULL");
   GPMP_ARG(z != nullptr, 3, "z is NULL");
-  GPMP_ARG(q >= 0 && q <= BQ, 8, "q outside [0, 7] (the batched path carries at most 7 mean-design columns)");
+  GPMP_ARG(q >= 0 && q <= BQ, 8, "q outside [0, 16] (the batched path carries at most 16 mean-design columns)");
   GPMP_ARG(q == 0 || (P != nullptr && ldp >= q), 5, "P is NULL or ldp < q");
   GPMP_ARG(nmax >= 1 && nmax <= GPMP_BATCH_MAX_N, 10, "nmax outside [1, GPMP_BATCH_MAX_N]");
   GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 11, "d outside [1, GPMP_MAX_DIM]");
@@ -406,18 +479,24 @@ extern "C" int gpmp_nll_grad_batch(const double* x, long stride_x, const double*
   hipLaunchKernelGGL(batch_pack_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, st, z, stride_z, P, ldp, stride_p, q, ns, nmax, Y,
                      l.ldq, (long)l.sY);
   GPMP_HIP_TRY(hipGetLastError());
-  // (two instantiations: 4 right-hand sides for q <= 3 -- every reference example -- and 8 for q <= 7)
+  // (three instantiations: 4 right-hand sides for q <= 3 -- every reference example --, 8 for q <= 7, 17 for q <= 16)
   if (q <= 3) {
     hipLaunchKernelGGL((batch_trsv_kernel<false, 4>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, Y, l.ldq, (long)l.sY,
                        nmax, 1 + q);
     GPMP_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(batch_value_kernel<3>, dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, Y, l.ldq, (long)l.sY, P, ldp, stride_p, q, ns,
                        nmax, ws + l.small, info_dev, values_dev);
-  } else {
+  } else if (q <= 7) {
     hipLaunchKernelGGL((batch_trsv_kernel<false, 8>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, Y, l.ldq, (long)l.sY,
                        nmax, 1 + q);
     GPMP_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(batch_value_kernel<7>, dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, Y, l.ldq, (long)l.sY, P, ldp, stride_p, q, ns,
+                       nmax, ws + l.small, info_dev, values_dev);
+  } else {
+    hipLaunchKernelGGL((batch_trsv_kernel<false, BR>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, Y, l.ldq, (long)l.sY,
+                       nmax, 1 + q);
+    GPMP_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(batch_value_wide_kernel, dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, Y, l.ldq, (long)l.sY, P, ldp, stride_p, q, ns,
                        nmax, ws + l.small, info_dev, values_dev);
   }
   GPMP_HIP_TRY(hipGetLastError());
@@ -428,8 +507,11 @@ extern "C" int gpmp_nll_grad_batch(const double* x, long stride_x, const double*
   if (q <= 3)
     hipLaunchKernelGGL((batch_trsv_kernel<true, 4>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, X, l.ldq, (long)l.sY,
                        nmax, 1 + q);
-  else
+  else if (q <= 7)
     hipLaunchKernelGGL((batch_trsv_kernel<true, 8>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, X, l.ldq, (long)l.sY,
+                       nmax, 1 + q);
+  else
+    hipLaunchKernelGGL((batch_trsv_kernel<true, BR>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, X, l.ldq, (long)l.sY,
                        nmax, 1 + q);
   GPMP_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(batch_rows_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, st, X, l.ldq, (long)l.sY, ws + l.small, q, ns,

@@ -63,7 +63,7 @@ class DifferentiableSelectionCriterion:
     def evaluate_many(self, P, want_grad=False):
         """Criterion at MANY parameter vectors (rows of ``P``) on the same data -- what a multi-chain sampler asks for at
         every step (the reference evaluates ``selection_criterion(p)`` chain after chain, gpmp/mcmc/param_posterior.py:229-278,
-        mcmc/metropolis_hastings.py).  With an analytic ML / REML criterion and at most 2048 observations all rows go through
+        mcmc/metropolis_hastings.py).  With an analytic ML / REML criterion and at most 4096 observations all rows go through
         ONE batched library call (gpmp_nll_grad_batch with per-problem parameters); otherwise they are evaluated one after the
         other.  A row whose factorisation fails gets +inf (and a zero gradient), as ``evaluate_no_grad`` does.
         Returns ``values`` (C,) or ``(values, grads)`` with ``grads`` (C, len(p))."""
@@ -158,7 +158,7 @@ class BatchDifferentiableSelectionCriterion:
     def _accumulate(self, p_arr, want_grad, p_call=None):
         """Sum of (batch value x batch size), points seen and -- with ``want_grad`` -- the sum of (batch gradient x batch size)
         over the batches of this evaluation, STREAMING the loader: whether the batched kernel applies is decided first (a
-        declared Matern covariance: model level, no data touched) and per batch from its size on the host (<= 2048 points);
+        declared Matern covariance: model level, no data touched) and per batch from its size on the host (<= 4096 points);
         qualifying batches are collected into pieces of at most one library call's workspace budget
         (``batch_piece_limit``) and go through gpmp_nll_grad_batch piece by piece, every other batch is evaluated on its own
         and dropped -- at no time more than one piece of the loader is resident on the device.  ``p_call`` is what a

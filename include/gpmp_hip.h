@@ -47,7 +47,8 @@ typedef void* gpmp_stream_t;
 #define GPMP_MAX_DIM 64      /* largest input dimension d handled by the Gram kernels */
 #define GPMP_MAX_P 16        /* largest Matern half-integer index p (nu = p + 1/2) */
 #define GPMP_MAX_RANK 72     /* largest low-rank correction width in gpmp_matern_grad_trace */
-#define GPMP_BATCH_MAX_N 2048 /* largest (padded) problem size of the batched small-problem driver */
+#define GPMP_BATCH_MAX_N 4096 /* largest (padded) problem size of the batched small-problem driver */
+#define GPMP_BATCH_MAX_Q 16   /* largest number of mean-design columns of the batched small-problem driver */
 
 int gpmp_hip_abi_version(void);
 /* Last error text of the calling thread (HIP error string or argument message). */
@@ -323,7 +324,7 @@ int gpmp_predict_mean(const double* xi, const double* zi, const double* Pi, long
 
 /* ---- many small problems at once (mini-batch criteria, posterior samplers) ------------------------------------- */
 
-/* B independent criteria -- the zero-mean NLL (q = 0) or REML with a mean design of q <= 7 columns -- and, when
+/* B independent criteria -- the zero-mean NLL (q = 0) or REML with a mean design of q <= GPMP_BATCH_MAX_Q columns -- and, when
  * grads_dev != NULL, their gradients with respect to the covariance parameters, every step ONE launch over all
  * problems (problem = blockIdx.y / .z of the diagonal-block, GEMM and solve kernels).  Callers: the weighted mean over
  * the batches of a loader (gpmp/num/torch_backend.py:607-718, gpmp/dataloader.py:484-513: B batches, one parameter

@@ -2,7 +2,8 @@
 SURVEY 8(f).4, the throughput caller behind gnp.BatchDifferentiableSelectionCriterion (gpmp/num/torch_backend.py:607-718)
 and multi-parameter log_prob evaluations (gpmp/mcmc/param_posterior.py:229-278).  Checked problem by problem against the
 single-problem driver gpmp_nll_grad (itself pinned on the reference's fixtures in tests/test_c_abi_mean_drivers_gpu.py),
-on ragged sizes across the diagonal-block / panel boundaries, shared and per-problem parameters, q = 0 ... 3."""
+on ragged sizes across the diagonal-block / panel boundaries, shared and per-problem parameters, q = 0 ... 16 mean columns,
+slots up to 4096 points (round 5: the limits were q <= 7, n <= 2048)."""
 import ctypes
 import math
 
@@ -68,6 +69,12 @@ def _batch(env, xs, zs, Ps, thetas, shared, p=2, noise=0, want_grad=True):
     return vals.cpu().numpy(), (grads.cpu().numpy() if want_grad else None), info.cpu().numpy()
 
 
+def _design(x, q):
+    """mean design with up to 1 + 6 d columns: [1, x, x^2] (the first 1 + 2 d, as before round 5), then cos(k pi x), k = 1 .. 4"""
+    cols = [np.ones((len(x), 1)), x, x * x] + [np.cos(k * np.pi * x) for k in range(1, 5)]
+    return np.hstack(cols)[:, :q]
+
+
 def _data(n, d, seed):
     rng = np.random.default_rng(seed)
     x = rng.random((n, d))
@@ -102,25 +109,28 @@ def _cond_scale(K):
 
 
 @pytest.mark.parametrize("noise", [0, 1])
-@pytest.mark.parametrize("q", [0, 1, 3, 4, 7])
-@pytest.mark.parametrize("sizes", [(2048, 1300, 1537), (300, 128, 77, 257)])
+@pytest.mark.parametrize("q", [0, 1, 3, 4, 7, 8, 16])
+@pytest.mark.parametrize("sizes", [(4096, 3000), (2048, 1300, 1537), (300, 128, 77, 257)])
 def test_batch_driver_against_the_oracle_at_its_edges(env, sizes, q, noise):
-    """the batched kernel against the CPU ORACLE (not against another HIP driver): ragged slots up to the 2048-point limit,
-    q = 0 (ML: likelihood.py:18-52) and q = 1, 3 (REML: likelihood.py:92-129), values and analytic gradients, with the
-    SURVEY 8(c) tolerances (value rel 1e-12, gradient rel 1e-8) scaled by the MEASURED cond(K) / 1e6 of each problem;
-    noise = 1 adds a 1e-4 noise variance (cond ~ 5e6), noise = 0 is the bare kernel (cond up to 5e8 at n = 2048)"""
+    """the batched kernel against the CPU ORACLE (not against another HIP driver): ragged slots up to the 4096-point limit,
+    q = 0 (ML: likelihood.py:18-52) and q = 1 ... 16 (REML: likelihood.py:92-129; q = 8, 16: the wide mean-space kernel of round 5),
+    values and analytic gradients, with the SURVEY 8(c) tolerances (value rel 1e-12, gradient rel 1e-8) scaled by the MEASURED
+    cond(K) / 1e6 of each problem; noise = 1 adds a 1e-4 noise variance (cond ~ 5e6), noise = 0 is the bare kernel (cond up to
+    5e8 at n = 2048)"""
     from oracle import gp_oracle as orc
 
-    if max(sizes) > 1024 and q in (3, 4):
-        pytest.skip("the 2048-point set runs q = 0, 1, 7 (host eigenvalues + inverse per problem: 3 s a case)")
+    if max(sizes) == 2048 and q in (3, 4, 8):
+        pytest.skip("the 2048-point set runs q = 0, 1, 7, 16 (host eigenvalues + inverse per problem: 3 s a case)")
+    if max(sizes) > 2048 and (q not in (0, 16) or noise == 0):
+        pytest.skip("the 4096-point set runs q = 0 and q = 16 with the noise term (host eigenvalues + inverse per problem: 20 s a case)")
     d = 3
     th = np.concatenate(([0.2], -np.log(0.3 + 0.2 * np.arange(d))))
     if noise:
         th = np.concatenate(([th[0], math.log(1e-4)], th[1:]))
     data = [_data(n, d, 100 + n + k) for k, n in enumerate(sizes)]
     xs, zs = [a for a, _ in data], [b for _, b in data]
-    # mean design: columns of [1, x, x^2] (q = 4: the linear mean of d = 3; q = 7: the widest the batched path carries)
-    Ps = None if q == 0 else [np.hstack((np.ones((len(x), 1)), x, x * x))[:, :q] for x in xs]
+    # mean design: columns of [1, x, x^2, cos(k pi x)] (q = 4: the linear mean of d = 3; q = 16: the widest the batched path carries)
+    Ps = None if q == 0 else [_design(x, q) for x in xs]
     vals, grads, info = _batch(env, xs, zs, Ps, th, shared=True, noise=noise)
     assert np.all(info == 0)
     cov = orc.noisy_maternp_covariance if noise else orc.maternp_covariance
@@ -172,7 +182,8 @@ def test_batch_driver_failure_is_per_problem(env, golden):
         v, gr, _ = _single(env, xs[b], zs[b], None, thetas[b])
         assert abs(vals[b] - v) < 1e-8 * abs(v) and rel_err(grads[b], gr) < 1e-6      # (ill-conditioned at these length scales)
     torch, gnp, _lib, lib = env
-    assert lib.gpmp_batch_ws_elems(2049, 3, 0, 4, 1) == 0 and lib.gpmp_batch_ws_elems(512, 3, 8, 4, 1) == 0 and lib.gpmp_batch_ws_elems(512, 3, 7, 4, 1) > 0
+    assert lib.gpmp_batch_ws_elems(4097, 3, 0, 4, 1) == 0 and lib.gpmp_batch_ws_elems(512, 3, 17, 4, 1) == 0
+    assert lib.gpmp_batch_ws_elems(512, 3, 16, 4, 1) > 0 and lib.gpmp_batch_ws_elems(4096, 3, 16, 2, 1) > 0
 
 
 def test_batch_criterion_fast_path_equals_one_at_a_time(env, golden):
@@ -233,19 +244,21 @@ def test_criterion_at_many_parameter_vectors_sampler_pattern(env, golden):
         assert np.allclose(v_bad[ok], vals[ok], rtol=1e-11) and (not np.isfinite(v_bad[4]) or abs(v_bad[4]) > 1e10)
 
 
-@pytest.mark.parametrize("B,n,d,q", [(1, 5, 1, 0), (1, 129, 2, 1), (3, 4, 1, 3), (2, 1024, 6, 2), (17, 130, 3, 0), (2, 2048, 6, 1)])
+@pytest.mark.parametrize("B,n,d,q", [(1, 5, 1, 0), (1, 129, 2, 1), (3, 4, 1, 3), (2, 1024, 6, 2), (17, 130, 3, 0), (2, 2048, 6, 1),
+                                     (2, 4096, 6, 1), (3, 700, 4, 16), (2, 3000, 3, 9), (5, 40, 3, 12)])
 def test_batch_driver_edge_shapes(env, B, n, d, q):
     """one problem, tiny problems (n just above q), one-dimensional inputs, the largest slot size, a block boundary + 2"""
     th = np.concatenate(([0.1], -np.log(0.3 + 0.25 * np.arange(d))))
     data = [_data(n, d, 900 + 7 * b + n) for b in range(B)]
     xs, zs = [a for a, _ in data], [b_ for _, b_ in data]
-    Ps = None if q == 0 else [np.hstack((np.ones((n, 1)), x, x ** 2))[:, :q] for x in xs]
+    Ps = None if q == 0 else [_design(x, q) for x in xs]
     vals, grads, info = _batch(env, xs, zs, Ps, th, shared=True)
     assert np.all(info == 0)
+    tol_v, tol_g = (1e-10, 1e-8) if n <= 2048 else (1e-8, 1e-6)      # (above 2048 the two drivers block differently: see the ragged-size test)
     for b in range(B):
         v, g, i = _single(env, xs[b], zs[b], None if q == 0 else Ps[b], th)
-        assert i == 0 and abs(vals[b] - v) < 1e-10 * max(1.0, abs(v)), (b, vals[b], v)
-        assert rel_err(grads[b], g) < 1e-8, (b, grads[b], g)
+        assert i == 0 and abs(vals[b] - v) < tol_v * max(1.0, abs(v)), (b, vals[b], v)
+        assert rel_err(grads[b], g) < tol_g, (b, grads[b], g)
 
 
 def test_batched_call_cut_into_pieces_by_workspace_budget(env, monkeypatch):

@@ -1,9 +1,10 @@
 """BASELINE config 5 (n = 131072, 2-D block-cyclic Cholesky) with VALUES on the one GPU of this pool: tools/config5_full.py runs the
 single-GPU product path and the real ``BlockCyclicCholesky`` (ranks sharing the GPU over gloo: the schedule, streams and kernels of
 the 8-GPU run) on the same inputs and compares log-determinant, NLL, sampled entries of the factor, posterior mean / variance,
-kriging weights and the ML value + gradient.  The default suite runs it at n = 32768 on the 2 x 3 grid (the pool's process guard
-allows six processes on the card, not the eight of a 2 x 4 grid); ``GPMP_TEST_CONFIG5_FULL=1`` runs it at n = 131072
-(K = 137 GB on the single-GPU side, 6 x 22.9 GB on the distributed side; ~10 minutes; log: profiles/r5/config5_full_n131072.log).
+kriging weights and the ML value + gradient.  The pool's process guard allows SIX processes on the card and the test runner is
+one of them (it has used the GPU in earlier tests), so inside the suite the grid is 2 x 2: n = 32768 by default,
+``GPMP_TEST_CONFIG5_FULL=1`` for n = 131072 (K = 137 GB on the single-GPU side, 4 x 34 GB on the distributed side; ~10 minutes).
+Run on its own (``python tools/config5_full.py all``) the tool takes the 2 x 3 grid: profiles/r5/config5_full_n131072_grid2x3_shared_gpu.log.
 What is compared is what gpmp/num/numpy_backend.py:465-469 and gpmp/core/likelihood.py:18-52 compute."""
 import os
 import subprocess
@@ -27,8 +28,8 @@ def _run(args, limit):
     return r.stdout
 
 
-def test_config5_schedule_with_values_at_n32768_on_the_2x3_grid(tmp_path):
-    _run(["--size-n", "32768", "--grad-n", "16384", "--m", "2048", "--limit", "300", "--out", str(tmp_path / "s.npz"),
+def test_config5_schedule_with_values_at_n32768_on_the_2x2_grid(tmp_path):
+    _run(["--grid", "2x2", "--size-n", "32768", "--grad-n", "16384", "--m", "2048", "--limit", "300", "--out", str(tmp_path / "s.npz"),
           "--dist-out", str(tmp_path / "d.npz")], 700)
 
 
@@ -38,4 +39,4 @@ def test_config5_at_its_own_size_n131072(tmp_path):
 
     if torch.cuda.is_available() and torch.cuda.get_device_properties(0).total_memory < 250e9:
         pytest.skip("needs 250 GB of HBM")
-    _run(["--limit", "1500", "--out", str(tmp_path / "s.npz"), "--dist-out", str(tmp_path / "d.npz")], 3300)
+    _run(["--grid", "2x2", "--limit", "1500", "--out", str(tmp_path / "s.npz"), "--dist-out", str(tmp_path / "d.npz")], 3300)

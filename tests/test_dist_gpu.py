@@ -166,6 +166,8 @@ def _predict_worker(rank, world, port, pr, pc, n, m, nb, out, transport, overlap
         assert ch.factor() == 0
         os.environ["GPMP_DIST_SOLVE_OVERLAP"] = "1" if overlap else "0"
         mean, var, (j0, j1) = ch.predict_zero_mean(cov, x, z, xt, th)
+        mean_l, var_l, _, lam = ch.predict(cov, x, z, xt, th, return_lambdas=True)     # (round 5) + the overlapped BACKWARD solve
+        assert np.array_equal(mean_l, mean) and np.array_equal(var_l, var)
         # every communicator is driven from ONE stream per phase (what keeps RCCL's per-communicator streams independent):
         # factorisation: row / column communicators from the side stream, the diagonal-block communicator from the diagonal
         # stream; many-right-hand-side solve: row communicators from the prefetch (= diagonal) stream, column from the side
@@ -176,14 +178,21 @@ def _predict_worker(rank, world, port, pr, pc, n, m, nb, out, transport, overlap
                 assert tag.startswith("row") and role == ("diag" if overlap else "host"), (tag, step, role)
             elif step.startswith("solve_chain"):
                 assert tag.startswith("col") and role == ("side" if overlap else "host"), (tag, step, role)
+            elif step.startswith("bsolve_pre"):          # backward solve: factor data along the process rows, prefetch stream
+                assert tag.startswith("row") and role == ("diag" if overlap else "host"), (tag, step, role)
+            elif step.startswith("bsolve"):              # its chain: ONE reduce per block column inside the process column, side stream
+                assert tag.startswith("col") and op == "reduce:bsolve" and role == ("side" if overlap else "host"), (tag, step, role)
         gathered = [None] * world
-        dist.all_gather_object(gathered, (grid.r, j0, j1, mean, var))
+        dist.all_gather_object(gathered, (grid.r, j0, j1, mean, var, ch.global_row_index(), lam.cpu().numpy()))
         if rank == 0:
-            zpm, zpv = np.full(m, np.nan), np.full(m, np.nan)
-            for (r, a, b, mu, v) in gathered:
+            zpm, zpv, full = np.full(m, np.nan), np.full(m, np.nan), np.full((n, m), np.nan)
+            for (r, a, b, mu, v, rows, blk) in gathered:
                 if r == 0:
                     zpm[a:b], zpv[a:b] = mu, v
+                if len(rows) and b > a:
+                    full[np.ix_(rows, np.arange(a, b))] = blk
             np.save(out, np.stack([zpm, zpv]))
+            np.save(out + ".lam.npy", full)
     finally:
         dist.destroy_process_group()
 
@@ -207,9 +216,12 @@ def test_block_cyclic_predict_hip(tmp_path, pr, pc, n, m, nb, transport, overlap
     xt, _ = make_xz(m, 4, 12)
     th = theta_aniso(4, scale=0.5)
     om = orc.OracleModel(None, lambda a, b, t, pairwise=False: orc.maternp_covariance(a, b, 2, t, pairwise), None, th, "zero")
-    rm, rv = orc.predict(om, x, z, xt, zero_neg_variances=False)
+    rm, rv, rlam = orc.predict(om, x, z, xt, return_lambdas=True, zero_neg_variances=False)
     assert np.max(np.abs(got[0] - rm)) < 1e-8 * np.max(np.abs(z))
     assert np.max(np.abs(got[1] - rv)) < 1e-8
+    lam = np.load(out + ".lam.npy")
+    ev = np.linalg.eigvalsh(orc.maternp_covariance(x, None, 2, th))
+    assert np.max(np.abs(lam - rlam)) < 1e-7 * max(1.0, float(ev[-1] / ev[0]) / 1e6) * np.max(np.abs(rlam))
 
 
 @pytest.mark.parametrize("n,nb", [(4096, 512), (3000, 256), (2048, 1024)])
