@@ -20,6 +20,16 @@ int hip_fail(hipError_t e, const char* what) {
   set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
   return -1000 - (int)e;
 }
+int device_cu_count() {
+  static std::atomic<int> cache[64];           // per device ordinal; 0 = not asked yet (two threads racing both ask: same answer)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = cache[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  cache[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
 }  // namespace gpmp
 
 namespace gpmp {

@@ -31,6 +31,10 @@ int hip_fail(hipError_t e, const char* what);
 
 inline hipStream_t as_stream(gpmp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// compute units of the CURRENT device (cached per device ordinal; 256 when the query fails): launch shapes that are fitted to the
+// machine (tile widths, strip widths, persistent grids) ask here, so a host thread per GPU sees its own device's count
+int device_cu_count();
+
 // Per-device one-time setup (kernel attributes belong to the device that was current when they were set): one bit per device
 // ordinal in a function-local mask.  `done` is set by the caller AFTER the setup succeeded; two host threads racing on the same
 // device both run the (idempotent) setup.  A thread-per-GPU host drives every device of the node through one copy of the library.
@@ -71,8 +75,7 @@ struct GemmOpts {
   int lower_only = 0;
   int kstart_row = 0;
   int kend_row = 0;
-  int kstart_col = 0;       // B(l, j) = 0 for l < j - kstart_col_off (B lower triangular after an offset)
-  int kstart_col_off = 0;
+  int kstart_col = 0;       // B(l, j) = 0 for l < j (B lower triangular): tile column j starts its k loop at col0(j)
   int kend_col = 0;         // B(l, j) = 0 for l > j (B upper triangular as K x N, e.g. the transpose of a lower T given as N x K): tile
                             // column j only needs l < col0(j) + 128
   int batch = 1;            // independent products of one shape: operand / result pointers advance by the strides below
@@ -108,7 +111,6 @@ int trsv_few(const double* L, int n, long ldl, const double* dinv, double* B, in
 // ---- misc kernels (reduce.hip) -----------------------------------------------------------------
 int launch_tril(double* A, int n, long lda, hipStream_t st, int nprob = 1, long prob_stride = 0);
 int launch_symmetrize(double* A, int n, long lda, hipStream_t st);
-int launch_set_identity_lower(double* T, int n, long ldt, hipStream_t st);
 int launch_diag_blocks(double* T, int n, long ldt, const double* dinv, hipStream_t st, int nprob = 1, long prob_stride_t = 0,
                        long prob_stride_dinv = 0);
 

@@ -39,16 +39,12 @@ struct GemmParams {
   int M, N, K;
   double alpha, beta;
   int lower_only, kstart_row, kend_row, kend_col;
-  int kstart_col, kstart_col_off;   // k loop of tile column j starts at max(0, col0(j) - off)
+  int kstart_col;   // k loop of tile column j starts at col0(j) (B lower triangular: B(l, j) = 0 for l < j)
   int tiles_m, tiles_n, ntiles;
   int aligned;  // 16-byte loads allowed on A and B
-  int cspread;  // v2: read C inside the first 16 k-tiles instead of up front
   int lean;     // NT, K <= 512: small-footprint kernel (see gemm_nt_lean_kernel)
   int batch;    // gridDim.y independent products
   int batch2;   // gridDim.z independent problems (outer batch)
-  int pair16;   // v2 epilogue: 16-byte stores after a lane-pair exchange
-  int prio;     // small NT kernels: raise the wave priority (GPMP_CHAIN_PRIO)
-  int gm;       // plain tile order: tile rows per group (8 = the 64 co-resident workgroups of an XCD cover 8 x 8 tiles)
   int tri_block;  // lower-triangular tile sets in 8 x 8 super-tiles (round 4) instead of row by row
   int bn;         // v2, plain NN launches: tile width 128 / 112 / 96 (launch_t)
   int early;      // v2: request tile kt + 2 right behind the barrier of tile kt (64 MFMAs of cover) instead of at the top of tile kt + 1 (48)
@@ -125,7 +121,7 @@ __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& t
       tj = v - r * p.tiles_n;
     }
   } else {
-    const int GM = p.gm;
+    constexpr int GM = 8;      // tile rows per group: the 64 co-resident workgroups of an XCD cover an 8 x 8 block of tiles
     const int per_group = GM * p.tiles_n;
     const int g = v / per_group;
     const int first = g * GM;
@@ -238,7 +234,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmParams p) {
 
   int kbeg = p.kstart_row ? row0 : 0;
   if (p.kstart_col) {
-    const int kb = (col0 - p.kstart_col_off) & ~(BK - 1);
+    const int kb = col0 & ~(BK - 1);
     if (kb > kbeg) kbeg = kb;
   }
   int kend = p.K;
@@ -432,7 +428,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
 
   int kbeg = p.kstart_row ? row0 : 0;
   if (p.kstart_col) {
-    const int kb = (col0 - p.kstart_col_off) & ~(BK - 1);
+    const int kb = col0 & ~(BK - 1);
     if (kb > kbeg) kbeg = kb;
   }
   int kend = p.K;
@@ -442,7 +438,6 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
 
   // ---- accumulators (start from (beta/alpha) C, see v1)
   const double alpha = p.alpha, beta = p.beta;
-  const bool pair_stores = p.pair16 != 0;
   double* __restrict__ cbase = p.C + (long)row0 * p.ldc + col0;
   const unsigned lane_off = (unsigned)((wm + lk) * (int)p.ldc + wn + lr);
   d4 acc[MI][NJ];
@@ -450,7 +445,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
   // enough, one 16x16 MFMA tile per k-tile during the first 16 k-tiles: every workgroup of a round
   // starts its tile at the same time, and 512 simultaneous 128 KB reads are an HBM-rate burst that
   // nothing hides (measured: the up-front read costs exactly C / HBM bandwidth at K = 512).
-  const bool spread = CACC && p.cspread && nk >= 18 && !edge;
+  const bool spread = CACC && nk >= 18 && !edge;
   if (CACC && !spread) {
     const double sc = beta / alpha;
     if (!edge) {
@@ -616,7 +611,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
     for (; kt < nk; ++kt) ktile(kt, kt + 1 < nk, nothing);
   }
 
-  if (!edge && (CACC || beta == 0.0) && pair_stores) {
+  if (!edge && (CACC || beta == 0.0)) {
     // Pure store of a full tile with 16-byte stores: in the MFMA layout a lane holds ONE column of four rows (4 apart), so
     // neighbouring lanes (columns c, c + 1) swap half of their registers (DPP quad_perm [1,0,3,2]): the even lane then owns
     // rows r = 0, 1 of both columns, the odd lane rows r = 2, 3 -- 32 store instructions per thread instead of 64.
@@ -878,7 +873,7 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmParams p) {
   if (p.lower_only && col0 > row0 + SBMT - 1) return;
   // these kernels carry the panel chain of the Cholesky: their waves go first where they share a SIMD with the trailing
   // update's (whose 64-cycle MFMAs otherwise take turns with them one for one)
-  if (p.prio) __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(3);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wn = wave * 32;
@@ -989,7 +984,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(10, 10
   if (p.lower_only && col0 > row0 + SBM - 1) return;
   // these kernels carry the panel chain of the Cholesky: their waves go first where they share a SIMD with the trailing
   // update's (whose 64-cycle MFMAs otherwise take turns with them one for one)
-  if (p.prio) __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(3);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wn = wave * 32;
@@ -1091,37 +1086,29 @@ int launch_t(const GemmParams& p, hipStream_t st) {
                     ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && (p.ldc % 2 == 0) &&
                     (p.lda % 2 == 0) && (p.ldb % 2 == 0) && (p.ldc >= p.N) &&
                     ((long)BM * p.lda * 8 + (long)p.K * 8 < 0x7FFFFFFFL) && ((long)BN * p.ldb * 8 + (long)p.K * 8 < 0x7FFFFFFFL);
-  // small NT products on a grid that cannot fill the machine: 64 x 64 tiles (latency kernel above)
   // tile width of a plain launch on the LDS-direct kernel (round 4): the width among 128 / 112 / 96 that minimises
-  // rounds x width, rounds = ceil(tiles / (2 CUs)); GPMP_GEMM_FIT_N=0 keeps 128 (read at every call)
+  // rounds x width, rounds = ceil(tiles / (2 workgroups x CUs))
   GemmParams pf = p;
   if (v2ok && p.batch == 1 && p.batch2 == 1 && !p.lower_only && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col) && p.N >= 16 * BN) {
-    const char* fe = getenv("GPMP_GEMM_FIT_N");
-    if ((fe ? atoi(fe) : 1) != 0) {
-      const long slots = 512;
-      auto cost = [&](int w) { const long t = (long)p.tiles_m * ((p.N + w - 1) / w); return ((t + slots - 1) / slots) * (long)w; };
-      long best = cost(BN);
-      for (int w : {112, 96}) {
-        const long c = cost(w);
-        if (c * 100 < best * 97) { best = c; pf.bn = w; }
-      }
-      if (pf.bn != BN) {
-        pf.tiles_n = (p.N + pf.bn - 1) / pf.bn;
-        pf.ntiles = pf.tiles_m * pf.tiles_n;
-      }
+    const long slots = 2L * device_cu_count();
+    auto cost = [&](int w) { const long t = (long)p.tiles_m * ((p.N + w - 1) / w); return ((t + slots - 1) / slots) * (long)w; };
+    long best = cost(BN);
+    for (int w : {112, 96}) {
+      const long c = cost(w);
+      if (c * 100 < best * 97) { best = c; pf.bn = w; }
+    }
+    if (pf.bn != BN) {
+      pf.tiles_n = (p.N + pf.bn - 1) / pf.bn;
+      pf.ntiles = pf.tiles_m * pf.tiles_n;
     }
   }
-  static int use_small = -1, small_max = 128;
-  if (use_small < 0) {
-    const char* e = getenv("GPMP_GEMM_SMALL_NT"); use_small = e ? atoi(e) : 1;
-    const char* m = getenv("GPMP_GEMM_SMALL_NT_MAX"); if (m) small_max = atoi(m);
-  }
-  static int use_lean = -1;
-  if (use_lean < 0) { const char* e = getenv("GPMP_GEMM_LEAN"); use_lean = e ? atoi(e) : 1; }
-  const bool lean_nt = p.batch == 1 && p.batch2 == 1 && AKC && BKC && p.lean && use_lean && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
+  // small NT products (K <= 512): the small-footprint kernel beside a machine-filling update (p.lean), the latency kernel on a grid
+  // below one round of the machine (at most `small_max` 128 x 128 tiles at K < 512)
+  constexpr int small_max = 128;
+  const bool lean_nt = p.batch == 1 && p.batch2 == 1 && AKC && BKC && p.lean && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
                        !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col) && ((long)SBN * p.ldb * 8 + (long)p.K * 8 < 0x7FFFFFFFL) &&
                        ((long)SBM * p.lda * 8 + (long)p.K * 8 < 0x7FFFFFFFL);
-  const bool small_nt = !lean_nt && p.batch == 1 && p.batch2 == 1 && AKC && BKC && use_small && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
+  const bool small_nt = !lean_nt && p.batch == 1 && p.batch2 == 1 && AKC && BKC && p.aligned && (p.K % BK == 0) && p.K >= BK && p.K <= 512 &&
                         p.ntiles <= (p.K >= 512 ? 384 : small_max) && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col);
   {
     // executed flops of this launch (tiles actually visited, k range actually swept)
@@ -1132,9 +1119,8 @@ int launch_t(const GemmParams& p, hipStream_t st) {
                      : 2.0 * (double)p.ntiles * BM * BN * kavg * p.batch * p.batch2);
     if (lean_nt) hipLaunchKernelGGL(gemm_nt_lean_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
     else if (small_nt) {
-      // fewer 32-row tiles than ~compute units: 16-row tiles (read at every call: tests exercise both heights)
-      const char* h16 = getenv("GPMP_GEMM_SMALL_ROWS16_BELOW");
-      const long below16 = h16 ? atol(h16) : 160;
+      // fewer 32-row tiles than ~compute units: 16-row tiles
+      constexpr long below16 = 160;
       const long wg32 = (long)((p.N + SBN - 1) / SBN) * ((p.M + SBM - 1) / SBM);
       if (wg32 < below16) hipLaunchKernelGGL(gemm_nt_small_kernel<16>, dim3((p.N + SBN - 1) / SBN, (p.M + 15) / 16), dim3(256), 0, st, p);
       else hipLaunchKernelGGL(gemm_nt_small_kernel<SBM>, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
@@ -1187,12 +1173,9 @@ int launch_trsm_leaf_forward(const double* L, long ldl, const double* dinv_leaf,
     attr_once.done(dev_bit);
   }
   // A leaf has one workgroup per strip, each walking the nb blocks one after the other (MFMA-bound on its compute unit:
-  // 68 us for a 64-column strip of a 512-row leaf): the strips are narrowed until there are about GPMP_TRSM_LEAF_MIN_STRIPS of
-  // them.  (GPMP_TRSM_LEAF_NARROW_BELOW, the older switch: 128-column strips from this many up; both read at every call.)
-  const char* nbe = getenv("GPMP_TRSM_LEAF_NARROW_BELOW");
-  const int narrow_below = nbe ? atoi(nbe) : 192;
-  const char* mse = getenv("GPMP_TRSM_LEAF_MIN_STRIPS");
-  const int min_strips = mse ? atoi(mse) : 256;
+  // 68 us for a 64-column strip of a 512-row leaf): with fewer than `narrow_below` strips of 128 columns the strips are narrowed
+  // until there are about `min_strips` of them (config 2: 79 strips of 128 left two thirds of the machine idle).
+  constexpr int narrow_below = 192, min_strips = 256;
   const int strips128 = (ncols + BN - 1) / BN;
   int bnw = 128;
   if (strips128 < narrow_below) {
@@ -1204,24 +1187,16 @@ int launch_trsm_leaf_forward(const double* L, long ldl, const double* dinv_leaf,
     // odd one alone (~0.8): time ~ width x (2.22 floor(L / 2) + 1.25 (L mod 2)).  m = 50000 in 128-column strips is 391 workgroups
     // (L = 2): 112 columns (waves 4 x 1 over 32 x 112) make 447 strips of 7 / 8 the work each, m = 40000 goes to 80 columns; m = 30000
     // (235 strips, one per CU) stays at 128.  Measured: predict n = 32768: m = 50000 950.4 -> 947.8 ms, m = 40000 801.4 -> 795.5 ms.
-    const char* fe = getenv("GPMP_TRSM_LEAF_FIT");
-    if ((fe ? atoi(fe) : 1) != 0) {
-      static int ncu = 0;
-      if (ncu <= 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
-        else ncu = 256;
-      }
-      auto cost = [&](int w) {
-        const int sw = (ncols + w - 1) / w;
-        const int L = (sw + ncu - 1) / ncu;
-        return (double)w * (2.22 * (L / 2) + 1.25 * (L % 2));
-      };
-      double best = cost(128);
-      for (int w : {112, 96, 80}) {
-        const double c = cost(w);
-        if (c < 0.97 * best) { best = c; bnw = w; }
-      }
+    const int ncu = device_cu_count();
+    auto cost = [&](int w) {
+      const int sw = (ncols + w - 1) / w;
+      const int L = (sw + ncu - 1) / ncu;
+      return (double)w * (2.22 * (L / 2) + 1.25 * (L % 2));
+    };
+    double best = cost(128);
+    for (int w : {112, 96, 80}) {
+      const double c = cost(w);
+      if (c < 0.97 * best) { best = c; bnw = w; }
     }
   }
   LeafSolveParams p{G, ldg, B, ldb, nb, ncols};
@@ -1248,7 +1223,7 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   p.M = M; p.N = N; p.K = K;
   p.alpha = alpha; p.beta = beta;
   p.lower_only = o.lower_only; p.kstart_row = o.kstart_row; p.kend_row = o.kend_row; p.kend_col = o.kend_col;
-  p.kstart_col = o.kstart_col; p.kstart_col_off = o.kstart_col_off;
+  p.kstart_col = o.kstart_col;
   p.tiles_m = (M + BM - 1) / BM;
   p.tiles_n = (N + BN - 1) / BN;
   if (o.lower_only) {
@@ -1257,32 +1232,13 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   } else {
     p.ntiles = p.tiles_m * p.tiles_n;
   }
-  static int cspread = -1;
-  if (cspread < 0) { const char* e = getenv("GPMP_GEMM_CSPREAD"); cspread = e ? atoi(e) : 1; }
-  p.cspread = cspread;
-  static int pair16 = -1;
-  if (pair16 < 0) { const char* e = getenv("GPMP_GEMM_PAIR16"); pair16 = e ? atoi(e) : 1; }
-  p.pair16 = pair16;
   p.lean = o.lean | g_machine_busy;
-  static int chain_prio = -1;
-  if (chain_prio < 0) { const char* e = getenv("GPMP_CHAIN_PRIO"); chain_prio = e ? atoi(e) : 1; }
-  p.prio = chain_prio;
-  // (GPMP_GEMM_GM, read once: 8 is the measured optimum -- with 64 co-resident 128 x 128 tiles per XCD the L2-side traffic per
-  //  tile is (A panel) / columns + (B panel) / rows of the co-resident block, smallest for the square 8 x 8)
-  static int gm = -1;
-  if (gm < 0) { const char* e = getenv("GPMP_GEMM_GM"); gm = e ? atoi(e) : 8; if (gm < 1) gm = 8; }
-  p.gm = gm;
   p.bn = BN;
-  // request distance of the LDS-direct kernel's operand tiles (read at every call): -1 = never early, 0 = early from
-  // GPMP_GEMM_EARLY_MIN_K on (default), 1 = always early
-  { const char* e = getenv("GPMP_GEMM_EARLY_ISSUE");
-    const int mode = e ? atoi(e) : 0;
-    const char* mk = getenv("GPMP_GEMM_EARLY_MIN_K");
-    const int min_k = mk ? atoi(mk) : 2048;
-    p.early = mode > 0 ? 1 : (mode < 0 ? 0 : (K >= min_k ? 1 : 0)); }
-  // lower-triangular tile sets of equal-cost tiles in 8 x 8 super-tiles (read at every call: A/B inside one process)
-  { const char* e = getenv("GPMP_GEMM_TRI_BLOCK");
-    p.tri_block = ((e ? atoi(e) : 1) != 0) && !(o.kstart_row | o.kend_row | o.kstart_col | o.kend_col); }
+  // request distance of the LDS-direct kernel's operand tiles: one barrier earlier for long k loops (K >= 2048: solve updates
+  // 92.2 -> 93.1 % of peak; neutral at 1024, -0.3 at 512: profiles/r4/gemm_early_issue_ab.log)
+  p.early = K >= 2048 ? 1 : 0;
+  // lower-triangular tile sets of equal-cost tiles in 8 x 8 super-tiles (fabric-side fetch of the Cholesky's trailing update / 2.24)
+  p.tri_block = !(o.kstart_row | o.kend_row | o.kstart_col | o.kend_col);
   p.batch = o.batch > 1 ? o.batch : 1;
   p.sa = o.stride_a; p.sb = o.stride_b; p.sc = o.stride_c;
   p.batch2 = o.batch2 > 1 ? o.batch2 : 1;

@@ -23,7 +23,6 @@ namespace {
 inline int imin(int a, int b) { return a < b ? a : b; }
 inline int imax(int a, int b) { return a > b ? a : b; }
 // switch from the environment, read at every call (A/B runs inside one process, tests that exercise both settings)
-inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 // Blocked (two-level) leaf of the recursive factorisation; row0 = global index of A[0][0] (for info).
 int potrf_blocked(double* A, int n, long lda, double* dinv, int* info_dev, int row0, hipStream_t st,
@@ -81,10 +80,8 @@ int potrf_blocked(double* A, int n, long lda, double* dinv, int* info_dev, int r
   return 0;
 }
 
-// L X = B (forward), blocked leaf.  tri != 0: B starts as (a row slice of) the identity and only the
-// lower triangle of X = L^-1 is non-zero: block row c only touches its first tri_off + (c+1)*NB columns.
-int trsm_forward_blocked(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb,
-                         int tri, int tri_off, hipStream_t st) {
+// L X = B (forward), blocked leaf.
+int trsm_forward_blocked(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, hipStream_t st) {
   const int nblk = (n + NB - 1) / NB;
   GemmOpts plain;
   for (int ob = 0; ob < nblk; ob += OUTER_BLOCKS) {
@@ -95,7 +92,7 @@ int trsm_forward_blocked(const double* L, int n, long ldl, const double* dinv, d
       const int jb = imin(NB, n - c0);
       const double* dc = dinv + (size_t)c * NB * NB;
       double* Bc = B + (long)c0 * ldb;
-      const int ncol = tri ? imin(m, tri_off + c0 + jb) : m;
+      const int ncol = m;
       int rc = launch_gemm(true, false, jb, ncol, jb, 1.0, dc, NB, Bc, ldb, 0.0, Bc, ldb, plain, st);
       if (rc) return rc;
       const int r1 = c0 + jb;
@@ -109,7 +106,7 @@ int trsm_forward_blocked(const double* L, int n, long ldl, const double* dinv, d
     const int mrem = n - out_end;
     if (mrem > 0) {
       const int kw = out_end - ob * NB;
-      const int ncol = tri ? imin(m, tri_off + out_end) : m;
+      const int ncol = m;
       int rc = launch_gemm(true, false, mrem, ncol, kw, -1.0, L + (long)out_end * ldl + (long)ob * NB, ldl,
                            B + (long)ob * NB * ldb, ldb, 1.0, B + (long)out_end * ldb, ldb, plain, st);
       if (rc) return rc;
@@ -229,12 +226,14 @@ struct DeviceState {
   std::mutex mu;
 };
 std::mutex g_dev_table_mu;
-std::map<int, std::unique_ptr<DeviceState>> g_dev_table;
-DeviceState* device_state(int dev) {
+std::map<int, std::shared_ptr<DeviceState>> g_dev_table;
+// (shared ownership: a thread that has looked its device's state up keeps it alive across a concurrent gpmp_device_release on
+//  another thread -- the release then only drops the table's reference and waits at the state's mutex)
+std::shared_ptr<DeviceState> device_state(int dev) {
   std::lock_guard<std::mutex> lk(g_dev_table_mu);
   auto it = g_dev_table.find(dev);
-  if (it == g_dev_table.end()) it = g_dev_table.emplace(dev, std::make_unique<DeviceState>()).first;
-  return it->second.get();
+  if (it == g_dev_table.end()) it = g_dev_table.emplace(dev, std::make_shared<DeviceState>()).first;
+  return it->second;
 }
 
 // Factor the panel of columns [p0, p1) (p0, p1 multiples of NB; rows p0 .. n): diagonal blocks in LDS,
@@ -302,55 +301,37 @@ int factor_panel(double* A, int n, long lda, double* dinv, int* info_dev, int p0
   return need_cols(p1 + 1);                    // (every piece is waited for: the panel event stands for the whole panel)
 }
 
-int trsm_forward(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int tri,
-                 int tri_off, double* gws, hipStream_t st);
+int trsm_forward(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, double* gws, hipStream_t st);
 
-// Optional overlap (predict): B (n x m) <- L^-1 B.  The leading half of the forward solve needs only the columns of L
-// left of n1; it is enqueued on a third stream as soon as the panel ending at n1 is factored and runs while the trailing
-// half of the factorisation -- 1/8 of its flops, but bound by the panel chain -- proceeds (at n = 32768 that half takes
-// 47 ms for 21 ms of MFMA work).  The rest of the solve follows on the caller's stream.
+// Solve along (chain-bound sizes, n <= 8192: the factorisation leaves most of the machine idle): B (n x m) <- L^-1 B with the rows
+// of every piece of panels solved as soon as those panels are factored, on a third stream -- a block solve
+// B_p <- L_pp^-1 (B_p - L_p,<p X_<p) with RIGHT-looking updates (behind the solve of a piece ALL later rows receive its
+// contribution at once), so that when the factorisation ends only the last piece's diagonal solve is left.
 struct SolveAlong {
   double* B = nullptr;
   int m = 0;
   long ldb = 0;
   double* gws = nullptr;
-  // every_panel: chain-bound sizes (n <= 8192: the factorisation leaves most of the machine idle).  The rows of every
-  // panel are solved as soon as that panel is factored -- a left-looking block solve B_p <- L_pp^-1 (B_p - L_p,<p X_<p) on
-  // the solve stream -- so only the last panel's rows are left when the factorisation ends.
-  int every_panel = 0;
 };
+
+// Schedule constants of the look-ahead factorisation, each the outcome of an A/B in one process (logs: profiles/r1 ... r4,
+// HISTORY section 4 "Switches"; rounds 1-4 kept them as environment switches):
+constexpr int LA_WIDE_ABOVE = 4096;          // 1024-column panels while more rows than this are left (rank-1024 updates: ~89 % of peak), 256-column panels below: in the chain-bound tail the in-panel updates then ride in the trailing update
+constexpr int LA_LEAN_ABOVE = 4096;          // panel products take the small-footprint kernel while the trailing update is at least this large
+constexpr int LA_SPLIT_ABOVE = 8192;         // look-ahead update of a 1024-column panel in three column pieces while more rows than this are left
+constexpr int LA_MAIN_AFTER_LA_BELOW = 4096; // at or below: a step's trailing update starts only after the next panel's look-ahead update
 
 int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hipStream_t s0, const SolveAlong* sa = nullptr) {
   int dev = 0;
   GPMP_HIP_TRY(hipGetDevice(&dev));
-  DeviceState* ds = device_state(dev);
+  const std::shared_ptr<DeviceState> ds = device_state(dev);
   std::lock_guard<std::mutex> la_lock(ds->mu);
   LookAhead& g_la = ds->la;
   hipStream_t& g_solve_stream = ds->solve_stream;
-  // panel boundaries: 1024-wide panels while the trailing matrix is large (rank-1024 updates run at
-  // ~89 % of the MFMA peak against ~84 % for rank-512, and the longer panel still hides behind them),
-  // 512-wide afterwards (shorter latency-bound tail)
-  const int wide_thresh = env_int("GPMP_POTRF_WIDE_ABOVE", 4096), lean_above = env_int("GPMP_POTRF_LEAN_ABOVE", 4096);
-  const int along_lean = env_int("GPMP_POTRF_ALONG_LEAN", 0);
-  // ... and narrower still once the trailing matrix is so small that the panel chain is all that is left: with 256- or
-  // 128-column panels the in-panel rank-128 updates and most of the look-ahead update move from the chain (helper stream)
-  // to the trailing update on the caller's stream, which has the machine to itself there
-  const int w256_below = env_int("GPMP_POTRF_W256_BELOW", 4096), w128_below = env_int("GPMP_POTRF_W128_BELOW", 0);
-  // (option, off: the last columns as ONE panel -- its look-ahead update is then the whole trailing update and the panel is
-  //  the blocked factorisation of what is left, all on the chain stream.  On its own the blocked route wins up to 2048
-  //  columns (potrf_lower), as the tail of this one it changes nothing: n = 4096: 2.19 vs 2.20 ms, 8192: 6.75 vs 6.75.)
-  const int tail_blocked = (sa != nullptr && sa->every_panel) ? 0 : env_int("GPMP_POTRF_TAIL_BLOCKED_BELOW", 0);
-  // Two-level panels (round 4): 2048 columns at a time while more than `super_above` rows are left -- the trailing update then
-  // has rank 2048 (the LDS-direct GEMM is 92 % MFMA-busy there against 88 % at rank 1024), and inside the panel the second half
-  // receives the first in ONE rank-1024 update (factor_panel's binary blocking).  0 = off.
-  const int super_above = env_int("GPMP_POTRF_SUPER_ABOVE", 0) > 0 ? imax(env_int("GPMP_POTRF_SUPER_ABOVE", 0), wide_thresh) : (1 << 30);
   std::vector<int> pb;
   for (int p = 0; p < n;) {
     pb.push_back(p);
-    const int rest = n - p;
-    if (p > 0 && rest <= tail_blocked) break;
-    p += rest > super_above ? 4 * OUTER_BLOCKS * NB
-                            : (rest > wide_thresh ? 2 * OUTER_BLOCKS * NB : (rest <= w128_below ? NB : (rest <= w256_below ? 2 * NB : OUTER_BLOCKS * NB)));
+    p += (n - p) > LA_WIDE_ABOVE ? 2 * OUTER_BLOCKS * NB : 2 * NB;
   }
   pb.push_back(n);
   const int np = (int)pb.size() - 1;
@@ -373,55 +354,40 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   hipEvent_t e_f = g_la.next();                 // panel k factored (on s1)
   GPMP_HIP_TRY(hipEventRecord(e_f, s1));
   hipEvent_t e_u2 = nullptr;                    // trailing update k-1 finished (on s0)
-  bool half_launched = false;
   int n1_solved = 0;
-  hipEvent_t e_half = nullptr;
   if (sa != nullptr && g_solve_stream == nullptr) GPMP_HIP_TRY(hipStreamCreateWithFlags(&g_solve_stream, hipStreamNonBlocking));
   if (sa != nullptr) {   // the solve stream starts after everything already queued by the caller (B is built there)
     hipEvent_t eb = g_la.next();
     GPMP_HIP_TRY(hipEventRecord(eb, s0));
     GPMP_HIP_TRY(hipStreamWaitEvent(g_solve_stream, eb, 0));
   }
-  hipEvent_t e_rows = nullptr;                  // last piece of the panel-by-panel solve (on g_solve_stream)
-  // panel-by-panel solve: the rows of B are solved in pieces of >= along_rows rows (whole panels).  A piece [r0, r1) needs
-  //   (a) B[r0:r1] -= L[r0:r1, 0:r0] X[0:r0]: every operand is final as soon as the piece before it is solved, and
+  // solve along: the rows of B are solved in pieces of >= along_rows rows (whole panels).  A piece [r0, r1) needs
+  //   (a) its share of the updates with the rows solved before: issued right behind the previous piece's solve, for ALL later rows
+  //       at once, B[r0:n] -= L[r0:n, s0:r0] X[s0:r0] (K = one piece), BEFORE the wait for this piece's panels, and
   //   (b) the triangular solve with L[r0:r1, r0:r1]: once the panels up to r1 are factored.
-  // (a) is issued right behind the previous piece's (b), BEFORE the wait for this piece's panels, so that when the
-  // factorisation ends only the last piece's (b) is left (round 1 issued (a) and (b) together behind the piece's last panel:
-  // kernel trace at n = 4096, m = 10000: 1.75 ms of solve after the last panel, of which 0.83 ms was that piece's (a)).
-  int along_rows = 0, upd_end = 0;              // rows < upd_end have received (a)
+  // (round 1 issued (a) and (b) together behind the piece's last panel: kernel trace at n = 4096, m = 10000: 1.75 ms of solve
+  //  after the last panel, of which 0.83 ms was that piece's (a).)
+  int along_rows = 0, upd_end = 0;              // rows < upd_end belong to the piece whose (b) comes next
   auto piece_end = [&](int r0) {
     for (size_t j = 0; j < pb.size(); ++j)
       if (pb[j] > r0 && pb[j] - r0 >= along_rows) return pb[j];
     return n;
   };
-  // GPMP_POTRF_ALONG_RIGHT (read at every call): 1 = RIGHT-looking updates -- behind the solve of the piece [s0, r0) ALL later
-  // rows receive its contribution at once, B[r0:n] -= L[r0:n, s0:r0] X[s0:r0] (K = one piece), so that when the factorisation ends
-  // the last piece only waits for its own diagonal solve; 0 = left-looking: the next piece alone receives everything solved so
-  // far (K = r0: one long update, the last of which -- K = 3n/4 -- starts only when the third quarter is solved).
-  const int along_right = env_int("GPMP_POTRF_ALONG_RIGHT", 1);
   int solved_from = 0;                           // start of the piece solved last
-  auto early_update = [&](int r0) -> int {       // (a) for the piece that starts at r0 = n1_solved
+  auto early_update = [&](int r0) -> int {       // (a) behind the piece that ends at r0 = n1_solved
     if (r0 >= n) return 0;
-    const int r1 = piece_end(r0);
     GemmOpts plain;
-    int rcu;
-    if (along_right)
-      rcu = launch_gemm(true, false, n - r0, sa->m, r0 - solved_from, -1.0, A + (long)r0 * lda + solved_from, lda,
-                        sa->B + (long)solved_from * sa->ldb, sa->ldb, 1.0, sa->B + (long)r0 * sa->ldb, sa->ldb, plain, g_solve_stream);
-    else
-      rcu = launch_gemm(true, false, r1 - r0, sa->m, r0, -1.0, A + (long)r0 * lda, lda, sa->B, sa->ldb, 1.0,
-                        sa->B + (long)r0 * sa->ldb, sa->ldb, plain, g_solve_stream);
+    const int rcu = launch_gemm(true, false, n - r0, sa->m, r0 - solved_from, -1.0, A + (long)r0 * lda + solved_from, lda,
+                                sa->B + (long)solved_from * sa->ldb, sa->ldb, 1.0, sa->B + (long)r0 * sa->ldb, sa->ldb, plain, g_solve_stream);
     solved_from = r0;
-    upd_end = r1;
+    upd_end = piece_end(r0);
     return rcu;
   };
-  if (sa != nullptr && sa->every_panel) {
-    const int along_env = env_int("GPMP_POTRF_ALONG_ROWS", 0);
+  if (sa != nullptr) {
     // (a quarter of the matrix at a time measured best: 2048 -> 512, 4096 -> 1024, 8192 -> 2048 rows per piece)
-    along_rows = along_env > 0 ? along_env : imax(OUTER_BLOCKS * NB, (n / 4) / (OUTER_BLOCKS * NB) * (OUTER_BLOCKS * NB));
+    along_rows = imax(OUTER_BLOCKS * NB, (n / 4) / (OUTER_BLOCKS * NB) * (OUTER_BLOCKS * NB));
     GPMP_HIP_TRY(hipStreamWaitEvent(g_solve_stream, e_f, 0));
-    rc = trsm_forward(A, pb[1], lda, dinv, sa->B, sa->m, sa->ldb, 0, 0, sa->gws, g_solve_stream);
+    rc = trsm_forward(A, pb[1], lda, dinv, sa->B, sa->m, sa->ldb, sa->gws, g_solve_stream);
     if (rc) return rc;
     n1_solved = pb[1];
     rc = early_update(n1_solved);
@@ -433,29 +399,25 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     hipStream_t sside = g_la.side;
     // -- helper: update next panel's columns with P_k, then factor it
     if (e_u2) GPMP_HIP_TRY(hipStreamWaitEvent(s1, e_u2, 0));
-    const int lean_panel = (n - p2 >= lean_above || (sa != nullptr && sa->every_panel && along_lean)) ? 1 : 0;
+    const int lean_panel = (n - p2 >= LA_LEAN_ABOVE) ? 1 : 0;
     hipEvent_t e_main_go = e_f;
     // Wide panels: the look-ahead update is cut in three column pieces.  The chain stream does the first 128 columns and
     // starts the diagonal block at once; the other two ([128, 512) and [512, 1024), the second sub-panel) follow on a side
     // stream while the first diagonal blocks are factored, and factor_panel waits for each just before it touches those
     // columns.  (At n = 16384 the panel, not the trailing update, is the longer of the two in EVERY step -- kernel trace: a
     // 1024-column panel = 0.8-1.0 ms of look-ahead update + 8 x 0.3 ms -- so the 0.8 ms in front of the first potf2 were
-    // on the critical path.)
-    const int la_split = env_int("GPMP_POTRF_LA_SPLIT", 1);
-    const int la_split_above = env_int("GPMP_POTRF_LA_SPLIT_ABOVE", 8192);   // (below, the pieces are too small to be worth two more events: n = 8192 loses 2 %)
-    ColsReady ready[3];
+    // on the critical path.  Below LA_SPLIT_ABOVE rows the pieces are too small to be worth two more events: n = 8192 loses 2 %.)
+    ColsReady ready[2];
     int nready = 0;
-    if (la_split && (p2 - p1 == 2 * OUTER_BLOCKS * NB || p2 - p1 == 4 * OUTER_BLOCKS * NB) && p2 <= n && n - p1 > la_split_above) {
-      const int ncuts = p2 - p1 == 4 * OUTER_BLOCKS * NB ? 4 : 3;
-      const int cuts[5] = {p1, p1 + NB, p1 + OUTER_BLOCKS * NB, ncuts == 4 ? p1 + 2 * OUTER_BLOCKS * NB : p2, p2};
+    if (p2 - p1 == 2 * OUTER_BLOCKS * NB && p2 <= n && n - p1 > LA_SPLIT_ABOVE) {
+      const int cuts[4] = {p1, p1 + NB, p1 + OUTER_BLOCKS * NB, p2};
       // the side stream reads panel k: it waits for an event recorded HERE, behind that panel on the chain stream (e_f is
-      // only renewed where somebody else waits for it -- need_ef below -- and may be an older panel's; found by
-      // tests/test_switches_gpu.py with the split enabled below 4096 rows, where the shipped thresholds never combine the two)
+      // only renewed where somebody else waits for it -- need_ef below -- and may be an older panel's)
       hipEvent_t e_panel = g_la.next();
       GPMP_HIP_TRY(hipEventRecord(e_panel, s1));
       GPMP_HIP_TRY(hipStreamWaitEvent(sside, e_panel, 0));
       if (e_u2) GPMP_HIP_TRY(hipStreamWaitEvent(sside, e_u2, 0));
-      for (int q = 0; q < ncuts; ++q) {
+      for (int q = 0; q < 3; ++q) {
         const int ca = cuts[q], cb = cuts[q + 1];
         hipStream_t sq = q == 0 ? s1 : sside;
         rc = launch_gemm(true, true, n - ca, cb - ca, w, -1.0, A + (long)ca * lda + p0, lda, A + (long)ca * lda + p0, lda,
@@ -476,48 +438,35 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     // chain-bound tail: the trailing update of this step starts only when the look-ahead update above has finished, so
     // that the latter -- on the critical chain -- does not share the machine with it (kernel trace, n = 4096: 12 us alone,
     // 37 us when both start together); the trailing update has slack there
-    const int main_after_la_below = env_int("GPMP_POTRF_MAIN_AFTER_LA_BELOW", 4096);
-    if (n - p1 <= main_after_la_below) {
+    if (n - p1 <= LA_MAIN_AFTER_LA_BELOW) {
       e_main_go = g_la.next();
       GPMP_HIP_TRY(hipEventRecord(e_main_go, s1));
     }
     // (the main stream's update of this iteration covers (n - p2)^2 / 2: with at least two rounds of tiles it holds every
-    //  workgroup slot of the machine while this panel is factored)
-    // (with the panel-by-panel solve the solve stream's GEMMs hold the slots instead)
+    //  workgroup slot of the machine while this panel is factored; with the solve along, the solve stream's GEMMs hold the slots)
     rc = factor_panel(A, n, lda, dinv, info_dev, p1, p2, s1, lean_panel, ready, nready);
     if (rc) return rc;
     // "panel k+1 factored": only recorded where somebody waits for it -- the trailing update of the next step (unless that
     // one starts behind its look-ahead update anyway), the solve stream, the final join.  An event between two kernels of
     // the chain stream costs ~5 us of packet processing (kernel trace: 9-11 us gaps around the look-ahead update against
     // 0-1 us between kernels that follow each other directly).
-    const bool need_ef = sa != nullptr || k + 2 >= np || (n - p2 > main_after_la_below);
+    const bool need_ef = sa != nullptr || k + 2 >= np || (n - p2 > LA_MAIN_AFTER_LA_BELOW);
     hipEvent_t e_f_next = e_f;
     if (need_ef) {
       e_f_next = g_la.next();
       GPMP_HIP_TRY(hipEventRecord(e_f_next, s1));
     }
-    if (sa != nullptr && sa->every_panel) {
+    if (sa != nullptr && p2 == upd_end) {
       // rows [r0, p2) of B: their update with the rows solved before was issued early (above); the diagonal part goes
-      // behind the factorisation of the last of these panels, followed at once by the next piece's update
+      // behind the factorisation of the last of these panels, followed at once by the update of everything below
       const int r0 = n1_solved;
-      if (p2 == upd_end) {
-        GPMP_HIP_TRY(hipStreamWaitEvent(g_solve_stream, e_f_next, 0));
-        rc = trsm_forward(A + (long)r0 * lda + r0, p2 - r0, lda, dinv + (size_t)(r0 / NB) * NB * NB, sa->B + (long)r0 * sa->ldb,
-                          sa->m, sa->ldb, 0, 0, sa->gws, g_solve_stream);
-        if (rc) return rc;
-        n1_solved = p2;
-        rc = early_update(n1_solved);
-        if (rc) return rc;
-      }
-    } else if (sa != nullptr && !half_launched && p2 >= n / 2 && p2 < n && p2 % (OUTER_BLOCKS * NB) == 0) {
-      // columns [0, p2) of L are final once e_f_next has fired: solve the first p2 rows of B behind it
-      half_launched = true;
-      n1_solved = p2;
       GPMP_HIP_TRY(hipStreamWaitEvent(g_solve_stream, e_f_next, 0));
-      rc = trsm_forward(A, p2, lda, dinv, sa->B, sa->m, sa->ldb, 0, 0, sa->gws, g_solve_stream);
+      rc = trsm_forward(A + (long)r0 * lda + r0, p2 - r0, lda, dinv + (size_t)(r0 / NB) * NB * NB, sa->B + (long)r0 * sa->ldb,
+                        sa->m, sa->ldb, sa->gws, g_solve_stream);
       if (rc) return rc;
-      e_half = g_la.next();
-      GPMP_HIP_TRY(hipEventRecord(e_half, g_solve_stream));
+      n1_solved = p2;
+      rc = early_update(n1_solved);
+      if (rc) return rc;
     }
     // -- main: rank-w update of the rest of the trailing matrix with P_k
     GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_main_go, 0));
@@ -531,23 +480,10 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     e_f = e_f_next;
   }
   GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_f, 0));  // join: everything visible to the caller's stream
-  if (sa != nullptr && sa->every_panel) {
-    e_rows = g_la.next();
+  if (sa != nullptr) {                           // n1_solved == n: every piece's rows were solved behind its panels
+    hipEvent_t e_rows = g_la.next();
     GPMP_HIP_TRY(hipEventRecord(e_rows, g_solve_stream));
     GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_rows, 0));
-    return 0;                                      // n1_solved == n: every panel's rows were solved behind its factorisation
-  }
-  if (sa != nullptr) {
-    if (!half_launched) return trsm_forward(A, n, lda, dinv, sa->B, sa->m, sa->ldb, 0, 0, sa->gws, s0);
-    // B2 -= L21 X1, then the trailing rows, on the caller's stream
-    GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_half, 0));
-    GemmOpts plain;
-    const int n1 = n1_solved;
-    rc = launch_gemm(true, false, n - n1, sa->m, n1, -1.0, A + (long)n1 * lda, lda, sa->B, sa->ldb, 1.0, sa->B + (long)n1 * sa->ldb,
-                     sa->ldb, plain, s0);
-    if (rc) return rc;
-    return trsm_forward(A + (long)n1 * lda + n1, n - n1, lda, dinv + (size_t)(n1 / NB) * NB * NB, sa->B + (long)n1 * sa->ldb, sa->m,
-                        sa->ldb, 0, 0, sa->gws, s0);
   }
   return 0;
 }
@@ -555,44 +491,30 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
 // One stream, no look-ahead, up to 2048 columns: nothing runs beside the chain's kernels there, and the look-ahead's second
 // stream only adds event packets and a trailing update that slows the chain (measured in one process, both routes:
 // n = 1536: 0.69 vs 0.77 ms, 2048: 0.96 vs 1.01, 3072: 1.68 vs 1.57, 4096: 2.47 vs 2.17).
-inline int potrf_one_stream_max() {
-  return env_int("GPMP_POTRF_BLOCKED_BELOW", 4 * OUTER_BLOCKS * NB);
-}
+constexpr int POTRF_ONE_STREAM_MAX = 4 * OUTER_BLOCKS * NB;
 
 int potrf_lower(double* A, int n, long lda, double* dinv, int* info_dev, hipStream_t st) {
   GPMP_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
-  if (n <= potrf_one_stream_max()) return potrf_blocked(A, n, lda, dinv, info_dev, 0, st);
+  if (n <= POTRF_ONE_STREAM_MAX) return potrf_blocked(A, n, lda, dinv, info_dev, 0, st);
   return potrf_lookahead(A, n, lda, dinv, info_dev, st);
 }
 
 // gws: optional scratch of at least (LEAF_TRSM)^2 doubles; enables the fused leaf (gemm_f64.hip: trsm_leaf_kernel)
-int trsm_forward(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int tri,
-                 int tri_off, double* gws, hipStream_t st) {
-  // rows of a fused leaf (read at every call): 512, or 1024 (GPMP_TRSM_LEAF_ROWS) -- eight blocks per strip, k loops up to 1024,
-  // no separate 512-row update between two leaves; the scratch behind the block inverses holds the 1024 x 1024 G
-  const int leaf_rows = (!tri && gws != nullptr && n % NB == 0 && m >= 64 * NB) ? imin(2 * LEAF_TRSM, imax(LEAF_TRSM, env_int("GPMP_TRSM_LEAF_ROWS", LEAF_TRSM)))
-                                                                               : LEAF_TRSM;
-  if (n <= leaf_rows) {
-    static int fused = -1;
-    if (fused < 0) { const char* e = getenv("GPMP_TRSM_FUSED_LEAF"); fused = e ? atoi(e) : 1; }
-    const bool ok = fused && gws != nullptr && !tri && n % NB == 0 && m >= 4 * NB && (m % 2 == 0) && (ldb % 2 == 0) &&
+int trsm_forward(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, double* gws, hipStream_t st) {
+  if (n <= LEAF_TRSM) {
+    const bool ok = gws != nullptr && n % NB == 0 && m >= 4 * NB && (m % 2 == 0) && (ldb % 2 == 0) &&
                     ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((long)n * ldb * 8 < 0x7FFFFFFFL);
     if (ok) return launch_trsm_leaf_forward(L, ldl, dinv, n / NB, B, ldb, m, gws, st);
-    return trsm_forward_blocked(L, n, ldl, dinv, B, m, ldb, tri, tri_off, st);
+    return trsm_forward_blocked(L, n, ldl, dinv, B, m, ldb, st);
   }
   const int n1 = split_point(n);
-  int rc = trsm_forward(L, n1, ldl, dinv, B, m, ldb, tri, tri_off, gws, st);
+  int rc = trsm_forward(L, n1, ldl, dinv, B, m, ldb, gws, st);
   if (rc) return rc;
   GemmOpts plain;
-  // B2 -= L21 * X1 ; with tri, X1 is non-zero only in its first tri_off + n1 columns and X1[l][c] = 0 for
-  // l < c - tri_off (lower triangular after the dense tri_off columns): column tiles skip those k.
-  const int ncol = tri ? imin(m, tri_off + n1) : m;
-  if (tri) { plain.kstart_col = 1; plain.kstart_col_off = tri_off; }
-  rc = launch_gemm(true, false, n - n1, ncol, n1, -1.0, L + (long)n1 * ldl, ldl, B, ldb, 1.0, B + (long)n1 * ldb, ldb,
-                   plain, st);
+  // B2 -= L21 * X1
+  rc = launch_gemm(true, false, n - n1, m, n1, -1.0, L + (long)n1 * ldl, ldl, B, ldb, 1.0, B + (long)n1 * ldb, ldb, plain, st);
   if (rc) return rc;
-  return trsm_forward(L + (long)n1 * ldl + n1, n - n1, ldl, dinv + (size_t)(n1 / NB) * NB * NB, B + (long)n1 * ldb, m, ldb,
-                      tri, tri_off + n1, gws, st);
+  return trsm_forward(L + (long)n1 * ldl + n1, n - n1, ldl, dinv + (size_t)(n1 / NB) * NB * NB, B + (long)n1 * ldb, m, ldb, gws, st);
 }
 
 int trsm_backward(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, hipStream_t st) {
@@ -621,7 +543,6 @@ int trtri_doubling(const double* L, int n, long ldl, const double* dinv, double*
   const long sl = pb != nullptr ? pb->stride_a : 0;
   int rc = launch_diag_blocks(T, n, ldt, dinv, st, nprob, stride_t, pb != nullptr ? pb->stride_dinv : 0);
   if (rc) return rc;
-  const int trtri_nn = env_int("GPMP_TRTRI_NN", 1);          // (read at every call: tests and A/Bs compare both forms)
   for (long s = NB; s < n; s *= 2) {
     const int npairs = (int)(n / (2 * s));                  // pairs with two full halves
     const long tail0 = (long)npairs * 2 * s;                // a ragged pair starts here if tail0 + s < n
@@ -635,7 +556,7 @@ int trtri_doubling(const double* L, int n, long ldl, const double* dinv, double*
       double* Wt = T + o * ldt + (o + s);                    // s x len2, W^T = T11^T L21^T
       double* T21 = T + (o + s) * ldt + o;
       const double* T22 = T + (o + s) * ldt + (o + s);
-      if (part == 0 && trtri_nn) {
+      if (part == 0) {
         // full pairs (len2 == s): W = L21 T11 kept UNtransposed in the T12 block, so that both products are of the NN kind --
         // the LDS-direct kernel's best operand layout (k-contiguous left operand, n-contiguous right operand: 91-92 % of peak
         // at K >= 2048 against 82 % for the transposed-left kind the W^T form needs for its first product)
@@ -698,7 +619,7 @@ using namespace gpmp;
 namespace gpmp {
 namespace {
 int release_device_state(int dev) {
-  std::unique_ptr<DeviceState> ds;
+  std::shared_ptr<DeviceState> ds;
   {
     std::lock_guard<std::mutex> lk(g_dev_table_mu);
     auto it = g_dev_table.find(dev);
@@ -707,14 +628,20 @@ int release_device_state(int dev) {
     g_dev_table.erase(it);
   }
   std::lock_guard<std::mutex> lk(ds->mu);          // an enqueue section still running on another thread finishes first
-  // (streams are synchronised before they go: their kernels may still be running)
-  for (hipStream_t st : {ds->la.helper, ds->la.side, ds->solve_stream})
-    if (st != nullptr) {
-      GPMP_HIP_TRY(hipStreamSynchronize(st));
-      GPMP_HIP_TRY(hipStreamDestroy(st));
+  // (streams are synchronised before they go: their kernels may still be running.)  Every handle is released whatever the
+  // earlier ones answered; the first error is what the caller gets.
+  hipError_t first = hipSuccess;
+  auto note = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
+  for (hipStream_t* st : {&ds->la.helper, &ds->la.side, &ds->solve_stream})
+    if (*st != nullptr) {
+      note(hipStreamSynchronize(*st));
+      note(hipStreamDestroy(*st));
+      *st = nullptr;
     }
-  for (hipEvent_t e : ds->la.pool) GPMP_HIP_TRY(hipEventDestroy(e));
-  return 0;
+  for (hipEvent_t e : ds->la.pool) note(hipEventDestroy(e));
+  ds->la.pool.clear();
+  ds->la.used = 0;
+  return first == hipSuccess ? 0 : hip_fail(first, "gpmp_device_release");
 }
 }  // namespace
 }  // namespace gpmp
@@ -744,12 +671,12 @@ extern "C" int gpmp_debug_device_table_selftest(int threads, int ordinals, int i
     pool.emplace_back([&, t] {
       for (int it = 0; it < iters; ++it)
         for (int o = 0; o < ordinals; ++o) {
-          DeviceState* ds = device_state(1000 + (o + t) % ordinals);
+          const std::shared_ptr<DeviceState> ds = device_state(1000 + (o + t) % ordinals);
           std::lock_guard<std::mutex> lk(ds->mu);           // what an enqueue section does
           ds->la.used = 0;
           DeviceState*& slot = seen[t][(o + t) % ordinals];
-          if (slot == nullptr) slot = ds;
-          else if (slot != ds) bad.fetch_add(1);
+          if (slot == nullptr) slot = ds.get();
+          else if (slot != ds.get()) bad.fetch_add(1);
         }
     });
   for (auto& th : pool) th.join();
@@ -793,31 +720,20 @@ extern "C" int gpmp_potrf_trsm_lower_async(double* A, int n, long lda, double* d
   hipStream_t st = as_stream(stream);
   GPMP_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
   double* gws = (n > 2 * OUTER_BLOCKS * NB) ? dinv + (size_t)((n + NB - 1) / NB) * NB * NB : nullptr;
-  // Overlap of the leading half of the solve with the trailing half of the factorisation: off by default.  It gains
-  // 5-7 ms of a 950 ms call (the two GEMM streams lose ~7 % to each other) and makes per-kernel timings of the solve
-  // depend on what the factorisation is doing; read at every call so that tests can exercise both schedules.
-  const char* ov = getenv("GPMP_POTRF_SOLVE_OVERLAP");
-  const int overlap = ov ? atoi(ov) : 0;
   // Chain-bound sizes: the factorisation of n <= 8192 leaves most of the machine idle (3.2 ms for 0.33 ms of MFMA work at
-  // n = 4096), so the rows of every panel are solved behind that panel's factorisation on a third stream.
-  const char* al = getenv("GPMP_POTRF_SOLVE_ALONG_BELOW");
-  const int along_below = al ? atoi(al) : 8192;
-  const char* aa = getenv("GPMP_POTRF_SOLVE_ALONG_ABOVE");
-  const int along_above = aa ? atoi(aa) : 2 * OUTER_BLOCKS * NB;
+  // n = 4096), so the rows of every piece of panels are solved behind those panels' factorisation on a third stream (SolveAlong).
+  // Above that the solve follows the factorisation on the caller's stream: overlapping its leading half with the trailing half of
+  // the factorisation gained 5-7 ms of a 950 ms call (two GEMM streams lose ~7 % to each other) and was dropped.
+  constexpr int along_above = 2 * OUTER_BLOCKS * NB, along_below = 8192;
   if (m > TRSV_FEW_MAX && n > along_above && n <= along_below) {
     SolveAlong sa;
-    sa.B = B; sa.m = m; sa.ldb = ldb; sa.gws = gws; sa.every_panel = 1;
+    sa.B = B; sa.m = m; sa.ldb = ldb; sa.gws = gws;
     return potrf_lookahead(A, n, lda, dinv, info_dev, st, &sa);
   }
-  if (!overlap || m <= TRSV_FEW_MAX || n <= 8 * OUTER_BLOCKS * NB) {
-    int rc = (n <= potrf_one_stream_max()) ? potrf_blocked(A, n, lda, dinv, info_dev, 0, st) : potrf_lookahead(A, n, lda, dinv, info_dev, st);
-    if (rc || m == 0) return rc;
-    if (m <= TRSV_FEW_MAX) return trsv_few(A, n, lda, dinv, B, m, ldb, 0, st);
-    return trsm_forward(A, n, lda, dinv, B, m, ldb, 0, 0, gws, st);
-  }
-  SolveAlong sa;
-  sa.B = B; sa.m = m; sa.ldb = ldb; sa.gws = gws;
-  return potrf_lookahead(A, n, lda, dinv, info_dev, st, &sa);
+  int rc = (n <= POTRF_ONE_STREAM_MAX) ? potrf_blocked(A, n, lda, dinv, info_dev, 0, st) : potrf_lookahead(A, n, lda, dinv, info_dev, st);
+  if (rc || m == 0) return rc;
+  if (m <= TRSV_FEW_MAX) return trsv_few(A, n, lda, dinv, B, m, ldb, 0, st);
+  return trsm_forward(A, n, lda, dinv, B, m, ldb, gws, st);
 }
 
 extern "C" int gpmp_trtri_diag_blocks(const double* L, int n, long ldl, double* dinv, gpmp_stream_t stream) {
@@ -845,7 +761,7 @@ extern "C" int gpmp_trsm_lower(const double* L, int n, long ldl, const double* d
   if (m <= TRSV_FEW_MAX) return trsv_few(L, n, ldl, dinv, B, m, ldb, trans, st);   // HBM-bound fused sweep
   // the panel scratch behind the block inverses (n > 1024, see gpmp_dinv_elems) of `scratch` enables the fused leaf
   double* gws = (scratch != nullptr && n > 2 * OUTER_BLOCKS * NB) ? scratch + (size_t)((n + NB - 1) / NB) * NB * NB : nullptr;
-  return trans ? trsm_backward(L, n, ldl, dinv, B, m, ldb, st) : trsm_forward(L, n, ldl, dinv, B, m, ldb, 0, 0, gws, st);
+  return trans ? trsm_backward(L, n, ldl, dinv, B, m, ldb, st) : trsm_forward(L, n, ldl, dinv, B, m, ldb, gws, st);
 }
 
 extern "C" int gpmp_trsm_right_lower(const double* L, int k, long ldl, const double* dinv, double* B, int M, long ldb,
@@ -865,12 +781,7 @@ extern "C" int gpmp_trtri_lower(const double* L, int n, long ldl, const double* 
   GPMP_ARG(dinv != nullptr, 4, "dinv is NULL");
   GPMP_ARG(T != nullptr && ldt >= n, 5, "T is NULL or ldt < n");
   if (n <= 0) return 0;
-  hipStream_t st = as_stream(stream);
-  const char* e = getenv("GPMP_TRTRI_DOUBLING");        // read at every call (tests compare both routes)
-  if (e == nullptr || atoi(e) != 0) return trtri_doubling(L, n, ldl, dinv, T, ldt, st);
-  int rc = launch_set_identity_lower(T, n, ldt, st);
-  if (rc) return rc;
-  return trsm_forward(L, n, ldl, dinv, T, n, ldt, 1, 0, nullptr, st);
+  return trtri_doubling(L, n, ldl, dinv, T, ldt, as_stream(stream));
 }
 
 extern "C" int gpmp_lauum_lower(const double* T, int n, long ldt, double* Kinv, long ldk, gpmp_stream_t stream) {

@@ -140,12 +140,6 @@ __global__ void diag_blocks_kernel(double* __restrict__ T, int n, long ldt, cons
   }
 }
 
-__global__ void identity_kernel(double* __restrict__ T, int n, long ldt) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  for (int i = blockIdx.y; i < n; i += gridDim.y) T[(long)i * ldt + j] = (i == j) ? 1.0 : 0.0;
-}
-
 }  // namespace
 
 int launch_tril(double* A, int n, long lda, hipStream_t st, int nprob, long prob_stride) {
@@ -166,12 +160,6 @@ int launch_diag_blocks(double* T, int n, long ldt, const double* dinv, hipStream
   if (n <= 0) return 0;
   hipLaunchKernelGGL(diag_blocks_kernel, dim3((n + NB - 1) / NB, nprob), dim3(256), 0, st, T, n, ldt, dinv, prob_stride_t,
                      prob_stride_dinv);
-  GPMP_HIP_TRY(hipGetLastError());
-  return 0;
-}
-int launch_set_identity_lower(double* T, int n, long ldt, hipStream_t st) {
-  if (n <= 0) return 0;
-  hipLaunchKernelGGL(identity_kernel, dim3((n + 255) / 256, n < 16384 ? n : 16384), dim3(256), 0, st, T, n, ldt);
   GPMP_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -334,7 +334,6 @@ __global__ void __launch_bounds__(256) trsv_persist_kernel(TrsvP p) {
 struct StreamState { unsigned int* words; unsigned int* sticky; };
 std::mutex g_state_mu;
 std::map<std::pair<int, hipStream_t>, StreamState> g_states;
-std::map<int, int> g_ncu;
 
 int state_for(hipStream_t st, StreamState& out, int& ncu) {
   int dev = 0;
@@ -351,14 +350,8 @@ int state_for(hipStream_t st, StreamState& out, int& ncu) {
     ns.sticky = ns.words + TRSV_STATE_WORDS;
     it = g_states.emplace(std::make_pair(dev, st), ns).first;
   }
-  auto nit = g_ncu.find(dev);
-  if (nit == g_ncu.end()) {
-    int v = 0;
-    GPMP_HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-    nit = g_ncu.emplace(dev, v).first;
-  }
   out = it->second;
-  ncu = nit->second;
+  ncu = device_cu_count();
   return 0;
 }
 
@@ -418,9 +411,7 @@ int run(const double* L, int n, long ldl, const double* dinv, double* B, int m, 
 // as 128 (predict with a linear mean at n = 4096 / m = 10000: 9.3 -> 6.8 ms).
 int trsv_few(const double* L, int n, long ldl, const double* dinv, double* B, int m, long ldb, int trans,
              hipStream_t st) {
-  // one persistent launch from a few blocks up (GPMP_TRSV_PERSIST=0: the launch-per-block chain)
-  const char* pe = getenv("GPMP_TRSV_PERSIST");     // read at every call (tests compare both routes)
-  const int persist = pe ? atoi(pe) : 1;
+  // one persistent launch from three blocks up to TRSV_MAXBLK; the launch-per-block chain outside that range
   const int nblk = (n + NB - 1) / NB;
   if (m > TRSV_FEW_MAX) { set_error("trsv_few: %d right-hand sides (at most %d)", m, TRSV_FEW_MAX); return -1; }
   // more than 8 columns: passes of 8 (and a last one of 1 / 2 / 4 / 8).  Each pass reads L again, but the sweep's inner loop
@@ -431,7 +422,7 @@ int trsv_few(const double* L, int n, long ldl, const double* dinv, double* B, in
     if (rc) return rc;
     return trsv_few(L, n, ldl, dinv, B + 8, m - 8, ldb, trans, st);
   }
-  if (persist && nblk >= 3 && nblk <= TRSV_MAXBLK) {
+  if (nblk >= 3 && nblk <= TRSV_MAXBLK) {
     if (m <= 1) return run_persist<1>(L, n, ldl, dinv, B, m, ldb, trans, st);
     if (m <= 2) return run_persist<2>(L, n, ldl, dinv, B, m, ldb, trans, st);
     if (m <= 4) return run_persist<4>(L, n, ldl, dinv, B, m, ldb, trans, st);

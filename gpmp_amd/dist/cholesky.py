@@ -390,10 +390,13 @@ class BlockCyclicCholesky:
     the summed milliseconds per phase on this rank -- diag (factor + column broadcast), trsm, row_bcast, col_exchange
     and lookahead_update on the side stream, update on the caller's stream.
     ``reserve_cus``: run the bulk updates on a stream that leaves this many CUs (one per XCD first) to the panel chain
-    (default GPMP_DIST_RESERVE_CUS, else 0)."""
+    (default GPMP_DIST_RESERVE_CUS, else 0).
+    ``step_abi`` / ``panel_via_inverse``: test hooks -- False runs a step's local arithmetic through the tensor-level code
+    instead of the C ABI's ``gpmp_dist_*`` / the panel solves by substitution instead of ONE product with inv(L_kk)."""
 
     def __init__(self, grid: ProcessGrid, n: int, nb: int = 1024, ops=None, transport: Optional[str] = None,
-                 lookahead: bool = True, profile: bool = False, reserve_cus: Optional[int] = None):
+                 lookahead: bool = True, profile: bool = False, reserve_cus: Optional[int] = None, step_abi: bool = True,
+                 panel_via_inverse: bool = True):
         if nb % 128 != 0:
             raise ValueError("block size must be a multiple of 128 (the GEMM tile)")
         self.grid, self.n, self.nb = grid, n, nb
@@ -403,7 +406,7 @@ class BlockCyclicCholesky:
         if self.transport not in ("bcast", "p2p"):
             raise ValueError("transport must be 'bcast' or 'p2p'")
         self.lookahead = lookahead
-        self.panel_via_inverse = os.environ.get("GPMP_DIST_PANEL_INVERSE", "1") != "0"
+        self.panel_via_inverse = bool(panel_via_inverse)     # False: panel solves by substitution (tests compare both)
         self.reserve_cus = int(os.environ.get("GPMP_DIST_RESERVE_CUS", "0")) if reserve_cus is None else int(reserve_cus)
         self.profile = profile       # record per-phase HIP events in factor(); read them with phase_times()
         self._marks = []             # (phase, start event, end event)
@@ -424,7 +427,8 @@ class BlockCyclicCholesky:
         self._step_label = None
         self._lay = (n, nb, grid.pr, grid.pc, grid.r, grid.c)
         # local arithmetic of a step through the C ABI's gpmp_dist_* (HipLocalOps) or through the tensor-level code below
-        self._abi = bool(getattr(self.ops, "step_abi", False)) and nb <= 1024 and os.environ.get("GPMP_DIST_STEP_ABI", "1") != "0"
+        # (``step_abi=False``: the tensor-level code with the real kernels -- tests compare the two bit for bit)
+        self._abi = bool(getattr(self.ops, "step_abi", False)) and nb <= 1024 and bool(step_abi)
 
     # ---- index helpers
     def bs(self, I: int) -> int:

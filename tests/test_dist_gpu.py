@@ -24,8 +24,6 @@ def _free_port():
 def _worker(rank, world, port, pr, pc, n, nb, out, transport, lookahead, backend="gloo", step_abi="1"):
     import torch.distributed as dist
 
-    os.environ["GPMP_DIST_STEP_ABI"] = step_abi
-
     # gloo: every rank on the one test GPU; nccl (= RCCL): one GPU per rank
     local = str(rank) if backend == "nccl" else "0"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=local,
@@ -45,7 +43,7 @@ def _worker(rank, world, port, pr, pc, n, nb, out, transport, lookahead, backend
         cov = MaternCovariance(2)
         nugget = 10.0 * math.exp(th[0]) * gnp.eps
         grid = ProcessGrid(pr, pc)
-        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=HipLocalOps(), transport=transport, lookahead=lookahead)
+        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=HipLocalOps(), transport=transport, lookahead=lookahead, step_abi=(step_abi == "1"))
         ch.build_local_gram(cov, x, th, nugget)
         info = ch.factor()
         nll = ch.negative_log_likelihood(z)

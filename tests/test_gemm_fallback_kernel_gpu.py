@@ -1,6 +1,7 @@
-"""The switches the GEMM / sweep kernels read ONCE per process ("Switches"), each at its non-default setting in a
+"""GPMP_GEMM_V2=0 -- the one kernel-level switch left (DESIGN.md section 4 "Switches"): every product on the register-staged
+kernel, the fall-back should the LDS-direct kernel misbehave on some driver / firmware.  Read once per process, so it runs in a
 child process: Cholesky, many-right-hand-side solve, single-vector solves and the four GEMM transposition cases against
-NumPy / LAPACK.  One child at a time (the GPU box allows few processes on the card)."""
+NumPy / LAPACK."""
 import os
 import subprocess
 import sys
@@ -48,16 +49,7 @@ for ta in (0, 1):
 print("CHILD_OK")
 """ % ROOT
 
-SETTINGS = [
-    {"GPMP_GEMM_V2": "0"},
-    {"GPMP_GEMM_CSPREAD": "0"},
-    {"GPMP_GEMM_PAIR16": "0"},
-    {"GPMP_GEMM_SMALL_NT": "0"},
-    {"GPMP_GEMM_SMALL_NT_MAX": "100000"},
-    {"GPMP_GEMM_LEAN": "0"},
-    {"GPMP_CHAIN_PRIO": "0"},
-    {"GPMP_TRSV_PERSIST": "0"},
-]
+SETTINGS = [{"GPMP_GEMM_V2": "0"}]
 
 
 @pytest.mark.parametrize("setting", SETTINGS, ids=lambda s: ",".join(f"{k[5:]}={v}" for k, v in s.items()))

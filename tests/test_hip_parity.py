@@ -139,30 +139,25 @@ def test_dgemm_lean_kernel(gnp, M, N, K, lower):
         assert rel_err(got, ref) < 1e-13
 
 
-@pytest.mark.parametrize("rows16", ["0", "100000"])
 @pytest.mark.parametrize("M,N,K,lower,inplace", [(900, 128, 128, 0, 1), (50, 128, 128, 0, 1), (333, 384, 128, 1, 0), (1000, 256, 256, 1, 0),
-                                                  (17, 70, 48, 0, 0), (640, 640, 512, 1, 0)])
-def test_dgemm_latency_kernel_tile_heights(gnp, M, N, K, lower, inplace, rows16):
-    """the latency NT kernel of the panel chain with 32-row and with 16-row tiles (GPMP_GEMM_SMALL_ROWS16_BELOW, read at every
-    call): plain, lower-only tile skip, and the in-place panel scaling C == A with N == K == 128"""
-    import os
+                                                  (17, 70, 48, 0, 0), (640, 640, 512, 1, 0), (6000, 128, 128, 0, 1), (5200, 256, 128, 1, 0)])
+def test_dgemm_latency_kernel_tile_heights(gnp, M, N, K, lower, inplace):
+    """the latency NT kernel of the panel chain with 16-row tiles (launches of fewer than 160 32-row tiles) and with 32-row tiles
+    (M = 6000, 5200: above that count): plain, lower-only tile skip, and the in-place panel scaling C == A with N == K == 128"""
     from gpmp_amd import _lib
 
     lib = _lib.load()
     rng = np.random.default_rng(M + 7 * N + K)
     A, B, C0 = rng.standard_normal((M, K)), rng.standard_normal((N, K)), rng.standard_normal((M, N))
     At, Bt, Ct = (gnp.as_matrix(gnp.asarray(a), copy=True) for a in (A, B, C0))
-    os.environ["GPMP_GEMM_SMALL_ROWS16_BELOW"] = rows16
-    try:
-        if inplace:
-            _lib.check(lib.gpmp_dgemm(0, 1, M, N, K, 1.0, gnp._ptr(At), gnp._ld(At), gnp._ptr(Bt), gnp._ld(Bt), 0.0, gnp._ptr(At), gnp._ld(At),
-                                      0, gnp._stream()), "gpmp_dgemm")
-            assert rel_err(gnp.to_np(At), A @ B.T) < 1e-13
-            return
-        _lib.check(lib.gpmp_dgemm(0, 1, M, N, K, -1.5, gnp._ptr(At), gnp._ld(At), gnp._ptr(Bt), gnp._ld(Bt), 0.5, gnp._ptr(Ct), gnp._ld(Ct),
-                                  lower, gnp._stream()), "gpmp_dgemm")
-    finally:
-        os.environ.pop("GPMP_GEMM_SMALL_ROWS16_BELOW", None)
+    rows16 = "1" if ((N + 127) // 128) * ((M + 31) // 32) < 160 else "0"
+    if inplace:
+        _lib.check(lib.gpmp_dgemm(0, 1, M, N, K, 1.0, gnp._ptr(At), gnp._ld(At), gnp._ptr(Bt), gnp._ld(Bt), 0.0, gnp._ptr(At), gnp._ld(At),
+                                  0, gnp._stream()), "gpmp_dgemm")
+        assert rel_err(gnp.to_np(At), A @ B.T) < 1e-13
+        return
+    _lib.check(lib.gpmp_dgemm(0, 1, M, N, K, -1.5, gnp._ptr(At), gnp._ld(At), gnp._ptr(Bt), gnp._ld(Bt), 0.5, gnp._ptr(Ct), gnp._ld(Ct),
+                              lower, gnp._stream()), "gpmp_dgemm")
     got, ref = gnp.to_np(Ct), -1.5 * A @ B.T + 0.5 * C0
     if lower:
         h = 16 if rows16 != "0" else 32
@@ -301,25 +296,15 @@ def test_factor_and_solve_in_one_call(gnp, n, m):
     B = rng.standard_normal((n, m))
     F0 = gnp.cholesky_factor(gnp.asarray(K))
     V0 = gnp.to_np(F0.solve_lower(gnp.asarray(B)))
-    import os
-
     L0 = np.tril(gnp.to_np(F0.L))
-    schedules = ({"GPMP_POTRF_SOLVE_ALONG_BELOW": "0", "GPMP_POTRF_SOLVE_OVERLAP": "0"},
-                 {"GPMP_POTRF_SOLVE_ALONG_BELOW": "0", "GPMP_POTRF_SOLVE_OVERLAP": "1"}, {})
-    for env in schedules:                              # the library reads the switches at every call
-        os.environ.update(env)
-        try:
-            F1, V1 = gnp.cholesky_factor_solve(gnp.asarray(K), gnp.asarray(B), overwrite=False)
-        finally:
-            for k_ in env:
-                os.environ.pop(k_, None)
-        L1 = np.tril(gnp.to_np(F1.L))
-        if n > 2048 or env:
-            assert np.array_equal(L0, L1)              # same kernels, same order: bit-identical factor
-        else:                                          # up to 2048 columns the factorisation alone takes the one-stream route,
-            assert rel_err(L1, L0) < 1e-12             # the factor-and-solve call the look-ahead one (panel-by-panel solve)
-        assert rel_err(gnp.to_np(V1), V0) < 1e-12
-        assert rel_err(L1 @ gnp.to_np(V1), B) < 1e-9
+    F1, V1 = gnp.cholesky_factor_solve(gnp.asarray(K), gnp.asarray(B), overwrite=False)
+    L1 = np.tril(gnp.to_np(F1.L))
+    if n > 2048:
+        assert np.array_equal(L0, L1)                  # same kernels, same order: bit-identical factor
+    else:                                              # up to 2048 columns the factorisation alone takes the one-stream route,
+        assert rel_err(L1, L0) < 1e-12                 # the factor-and-solve call the look-ahead one (solve along the panels)
+    assert rel_err(gnp.to_np(V1), V0) < 1e-12
+    assert rel_err(L1 @ gnp.to_np(V1), B) < 1e-9
     # the factor object returned by the fused call serves further solves
     z = rng.standard_normal(n)
     # two routes to K^-1 z whose factors differ in the last bits (n <= 2048): the solutions may differ by O(cond(K) eps) --
@@ -333,8 +318,9 @@ def test_factor_and_solve_in_one_call(gnp, n, m):
 @pytest.mark.parametrize("n", [100, 129, 300, 1000, 1500, 2049, 3333, 5000])
 def test_trtri_doubling_vs_forward_solve_and_numpy(gnp, n):
     """T = L^-1: the doubling scheme (two batched launches per level, W^T parked in the zero half of T) against the forward
-    solve on the identity and NumPy; sizes with ragged last blocks, ragged last pairs and a single block"""
-    import os
+    solve on the identity (the many-right-hand-side solve) and NumPy; sizes with ragged last blocks, ragged last pairs and a
+    single block"""
+    import torch
     from oracle import gp_oracle as orc
 
     rng = np.random.default_rng(n)
@@ -343,26 +329,19 @@ def test_trtri_doubling_vs_forward_solve_and_numpy(gnp, n):
     F = gnp.cholesky_factor(gnp.asarray(K))
     L = np.tril(gnp.to_np(F.L))
     ref = np.linalg.inv(L)
-    got = {}
-    for mode in ("0", "1"):
-        os.environ["GPMP_TRTRI_DOUBLING"] = mode
-        try:
-            got[mode] = gnp.to_np(F.inverse_factor())
-        finally:
-            os.environ.pop("GPMP_TRTRI_DOUBLING", None)
-    for mode in got:
-        assert np.array_equal(np.triu(got[mode], 1), np.zeros((n, n)))          # strict upper triangle exactly zero
-        assert np.max(np.abs(got[mode] @ L - np.eye(n))) < 1e-9
-    assert np.max(np.abs(got["1"] - ref)) < 1e-9 * np.max(np.abs(ref))
-    assert np.max(np.abs(got["1"] - got["0"])) < 1e-10 * np.max(np.abs(ref))
+    got = gnp.to_np(F.inverse_factor())
+    fwd = gnp.to_np(F.solve_lower(torch.eye(n, dtype=torch.float64, device=F.L.device)))
+    assert np.array_equal(np.triu(got, 1), np.zeros((n, n)))          # strict upper triangle exactly zero
+    assert np.max(np.abs(got @ L - np.eye(n))) < 1e-9
+    assert np.max(np.abs(got - ref)) < 1e-9 * np.max(np.abs(ref))
+    assert np.max(np.abs(got - np.tril(fwd))) < 1e-10 * np.max(np.abs(ref))
 
 
 @pytest.mark.parametrize("n", [300, 1000, 4101, 9000])
 @pytest.mark.parametrize("r", [1, 2, 3, 4, 7, 10, 16])
 def test_single_vector_solves_persistent_vs_chain(gnp, n, r):
     """op(L)^-1 B for <= 16 right-hand sides (the sweep that reads L once; 10 = [z, P] of a linear mean in d = 8): the one-launch kernel (workgroups hand x_k over through device memory) against
-    the launch-per-block chain and against SciPy, forward and transposed, ragged last block included"""
-    import os
+    SciPy, forward and transposed, ragged last block included (n = 300: one or two blocks -- the launch-per-block chain)"""
     import scipy.linalg as sla
     from oracle import gp_oracle as orc
 
@@ -374,16 +353,8 @@ def test_single_vector_solves_persistent_vs_chain(gnp, n, r):
     B = rng.standard_normal((n, r)) if r > 1 else rng.standard_normal(n)
     for trans in (False, True):
         ref = sla.solve_triangular(L, B, lower=True, trans=1 if trans else 0)
-        got = {}
-        for mode in ("0", "1"):
-            os.environ["GPMP_TRSV_PERSIST"] = mode
-            try:
-                got[mode] = gnp.to_np(F.solve_lower(gnp.asarray(B), trans=trans))
-            finally:
-                os.environ.pop("GPMP_TRSV_PERSIST", None)
-        scale = np.max(np.abs(ref))
-        assert np.max(np.abs(got["1"] - ref)) < 1e-9 * scale
-        assert np.max(np.abs(got["1"] - got["0"])) < 1e-11 * scale
+        got = gnp.to_np(F.solve_lower(gnp.asarray(B), trans=trans))
+        assert np.max(np.abs(got - ref)) < 1e-9 * np.max(np.abs(ref))
 
 
 def test_single_vector_solve_persistent_under_load(gnp):
@@ -494,18 +465,14 @@ def test_stream_release_frees_the_solve_state_and_a_later_solve_starts_afresh(gn
     assert lib.gpmp_solve_status(h, None) == 0 and lib.gpmp_stream_release(h) == 0
 
 
-@pytest.mark.parametrize("strip", [16, 32, 64, 128])
-@pytest.mark.parametrize("n,m", [(1536, 700), (2048, 1024), (1280, 514), (1500, 900)])
-def test_forward_solve_many_rhs_fused_leaves(gnp, n, m, strip, monkeypatch):
-    """L^-1 B with the factor's scratch area (n > 1024): fused 512-row leaves incl. a narrow last column strip, on 128-column
-    strips and on the narrowed ones (64 / 32 / 16 columns: chosen so that a leaf has about GPMP_TRSM_LEAF_MIN_STRIPS workgroups);
-    n = 1500 has a ragged last leaf (launch-per-block path) behind fused ones"""
+@pytest.mark.parametrize("n,m", [(1536, 700), (2048, 1024), (1280, 514), (1500, 900), (1536, 9000), (1536, 16400), (1536, 30002)])
+def test_forward_solve_many_rhs_fused_leaves(gnp, n, m):
+    """L^-1 B with the factor's scratch area (n > 1024): fused 512-row leaves incl. a narrow last column strip, on every strip
+    width the library picks from the number of right-hand sides -- 16 columns (m < 8192), 32 (m = 9000), 64 (m = 16400: fewer than
+    192 strips of 128) and 128 (m = 30002: one strip per compute unit); n = 1500 has a ragged last leaf (launch-per-block path)
+    behind fused ones"""
     import scipy.linalg as sla
     from oracle import gp_oracle as orc
-
-    monkeypatch.setenv("GPMP_TRSM_LEAF_NARROW_BELOW", "0" if strip == 128 else "1000000")
-    # strips of `strip` columns: the narrowing stops at the first width with at least MIN_STRIPS strips
-    monkeypatch.setenv("GPMP_TRSM_LEAF_MIN_STRIPS", {128: "0", 64: "0", 32: str((m + 31) // 32), 16: "1000000"}[strip])
 
     rng = np.random.default_rng(n + m)
     x = rng.random((n, 3))
@@ -711,24 +678,21 @@ def test_cholesky_and_solves_vs_lapack(gp, gnp, n):
 
 @pytest.mark.parametrize("n", [1100, 1537, 2048, 2300])
 def test_cholesky_one_stream_and_lookahead_routes_agree(gnp, n):
-    """potrf_lower takes the one-stream blocked route up to 2048 columns and the look-ahead route above
-    (GPMP_POTRF_BLOCKED_BELOW, read at every call): both must give the LAPACK factor, on either side of the switch"""
-    import os
+    """the factorisation alone takes the one-stream blocked route up to 2048 columns and the look-ahead route above; the
+    factor-and-solve call (more than 16 right-hand sides, 1024 < n <= 8192) always takes the look-ahead route with the solve along
+    the panels: both must give the LAPACK factor, on either side of the 2048 boundary"""
     from oracle import gp_oracle as orc
 
     x, _ = make_xz(n, 3, n)
     K = orc.maternp_covariance(x, None, 2, theta_aniso(3, scale=0.4)) + 1e-6 * np.eye(n)
     Lref = np.linalg.cholesky(K)
-    got = {}
-    for route, below in (("one_stream", "4096"), ("lookahead", "1024")):
-        os.environ["GPMP_POTRF_BLOCKED_BELOW"] = below
-        try:
-            got[route] = np.tril(gnp.to_np(gnp.cholesky_factor(gnp.asarray(K)).L))
-        finally:
-            os.environ.pop("GPMP_POTRF_BLOCKED_BELOW", None)
+    B = np.random.default_rng(n).standard_normal((n, 64))
+    got = {"alone": np.tril(gnp.to_np(gnp.cholesky_factor(gnp.asarray(K)).L)),
+           "with_solve": np.tril(gnp.to_np(gnp.cholesky_factor_solve(gnp.asarray(K), gnp.asarray(B), overwrite=False)[0].L))}
+    for route in got:
         assert rel_err(got[route], Lref) < 1e-10
         assert rel_err(got[route] @ got[route].T, K) < 1e-14
-    assert rel_err(got["one_stream"], got["lookahead"]) < 1e-12
+    assert rel_err(got["alone"], got["with_solve"]) < 1e-12
 
 
 def test_cholesky_not_positive_definite_raises_linalgerror(gp, gnp, golden):

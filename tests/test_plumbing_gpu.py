@@ -182,15 +182,17 @@ def test_svd_with_default_arguments_does_not_trust_the_hermitian_flag(gnp, kind)
 
 
 @pytest.mark.parametrize("m,width", [(40000, 80), (50000, 112), (46000, 96)])
-def test_forward_solve_leaves_with_fitted_strip_widths(gnp, m, width, monkeypatch):
+def test_forward_solve_leaves_with_fitted_strip_widths(gnp, m, width):
     """Round 4: with many right-hand sides the fused 512-row leaves of the forward solve take 112- / 96- / 80-column strips when
-    that fills the machine better than 128 (gemm_f64.hip: launch_trsm_leaf_forward); the solution must be the one of the
-    128-column strips (GPMP_TRSM_LEAF_FIT=0) to rounding and LAPACK's on sampled columns (gpmp/num/numpy_backend.py:467)."""
+    that fills the machine better than 128 (gemm_f64.hip: launch_trsm_leaf_forward); the solution must be LAPACK's on sampled
+    columns (gpmp/num/numpy_backend.py:467) and the launch-per-block route's (no scratch area: no fused leaves) everywhere."""
     import scipy.linalg as sla
     import torch
 
+    from gpmp_amd import _lib
     from oracle import gp_oracle as orc
 
+    lib = _lib.load()
     n = 1536                                                    # three leaves of 512 rows + the updates between them
     rng = np.random.default_rng(m)
     x = rng.random((n, 3))
@@ -198,31 +200,25 @@ def test_forward_solve_leaves_with_fitted_strip_widths(gnp, m, width, monkeypatc
     F = gnp.cholesky_factor(gnp.asarray(K))
     B = torch.randn((n, m), dtype=torch.float64, device=F.L.device, generator=torch.Generator(device=F.L.device).manual_seed(m))
     X = F.solve_lower(B.clone())
-    monkeypatch.setenv("GPMP_TRSM_LEAF_FIT", "0")
-    X0 = F.solve_lower(B.clone())
+    X0 = gnp.as_matrix(B, copy=True)
+    _lib.check(lib.gpmp_trsm_lower(gnp._ptr(F.L), n, gnp._ld(F.L), gnp._ptr(F.dinv), gnp._ptr(X0), m, gnp._ld(X0), 0, None, gnp._stream()),
+               "gpmp_trsm_lower")
     assert float((X - X0).abs().max()) < 1e-11 * float(X0.abs().max())
-    monkeypatch.setenv("GPMP_TRSM_LEAF_ROWS", "1024")          # the measured-neutral alternative: eight blocks per fused leaf
-    X2 = F.solve_lower(B.clone())
-    assert float((X2 - X0).abs().max()) < 1e-11 * float(X0.abs().max())
     cols = np.concatenate((np.arange(0, 300), np.arange(m - 300, m), rng.choice(m, 400, replace=False)))
     ref = sla.solve_triangular(np.tril(gnp.to_np(F.L)), B[:, torch.as_tensor(cols, device=B.device)].cpu().numpy(), lower=True)
     assert np.max(np.abs(X[:, torch.as_tensor(cols, device=B.device)].cpu().numpy() - ref)) < 1e-10 * np.max(np.abs(ref))
 
 
 @pytest.mark.parametrize("M,N,K", [(512, 50000, 512), (1024, 50000, 1024), (2048, 30002, 512), (640, 46000, 1024)])
-def test_gemm_with_fitted_tile_width_vs_128_and_numpy(gnp, M, N, K, monkeypatch):
+def test_gemm_with_fitted_tile_width_vs_numpy(gnp, M, N, K):
     """Round 4: plain products on the LDS-direct kernel take 112- or 96-column tiles when that fills the last round of the machine
-    better (gemm_f64.hip: launch_t, GPMP_GEMM_FIT_N).  Same product as with 128-column tiles (same k order per entry: bit-identical)
-    and as NumPy on sampled columns, incl. a ragged last tile."""
+    better (gemm_f64.hip: launch_t).  Against NumPy on sampled columns, incl. a ragged last tile."""
     import torch
 
     rng = np.random.default_rng(M + N + K)
     A = gnp.asarray(rng.standard_normal((M, K)))
     B = gnp.asarray(rng.standard_normal((K, N)))
     C1 = gnp.matmul(A, B)
-    monkeypatch.setenv("GPMP_GEMM_FIT_N", "0")
-    C0 = gnp.matmul(A, B)
-    assert torch.equal(C1, C0)
     cols = np.concatenate((np.arange(0, 260), np.arange(N - 260, N), rng.choice(N, 300, replace=False)))
     ref = gnp.to_np(A) @ gnp.to_np(B)[:, cols]
     assert np.max(np.abs(C1[:, torch.as_tensor(cols, device=C1.device)].cpu().numpy() - ref)) < 1e-12 * np.sqrt(K) * 10

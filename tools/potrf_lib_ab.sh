@@ -1,9 +1,12 @@
 #!/bin/bash
-# binary against binary on one box: potrf wall time (best / median of 9) with the library at $1 and the in-tree one, sizes $2...
+# binary against binary on one box: Cholesky wall time with the library at $1 (GPMP_HIP_LIB) and the in-tree one, sizes $2...
+# (the way to A/B a change inside a kernel or a schedule constant: build the other variant into another .so)
 base=$1; shift
 for rep in 1 2; do
   for lib in "$base" ""; do
-    echo "== GPMP_HIP_LIB=${lib:-<in-tree>}"
-    GPMP_HIP_LIB=$lib timeout -k 10 120 python3 tools/potrf_ab.py GPMP_UNUSED_SWITCH 0 1 "$@" 2>&1 | grep "^n=" | grep "=     0:"
+    for n in "$@"; do
+      echo "== GPMP_HIP_LIB=${lib:-<in-tree>} n=$n"
+      GPMP_HIP_LIB=$lib timeout -k 10 120 python3 tools/potrf_only.py $n 2>&1 | grep "^potrf ms"
+    done
   done
 done
