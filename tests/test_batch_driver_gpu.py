@@ -108,9 +108,14 @@ def _cond_scale(K):
     return max(1.0, float(ev[-1] / max(ev[0], 1e-300)) / 1e6)
 
 
-@pytest.mark.parametrize("noise", [0, 1])
-@pytest.mark.parametrize("q", [0, 1, 3, 4, 7, 8, 16])
-@pytest.mark.parametrize("sizes", [(4096, 3000), (2048, 1300, 1537), (300, 128, 77, 257)])
+_SMALL, _MID, _BIG = (300, 128, 77, 257), (2048, 1300, 1537), (4096, 3000)
+# every q on the small ragged set; q = 0, 1, 7, 16 on the 2048-point set (host eigenvalues + inverse per problem: 3 s a case);
+# q = 0 and 16 with the noise term on the 4096-point set (20 s a case)
+_ORACLE_CASES = ([(_SMALL, q, nz) for q in (0, 1, 3, 4, 7, 8, 16) for nz in (0, 1)] + [(_MID, q, nz) for q in (0, 1, 7, 16) for nz in (0, 1)]
+                 + [(_BIG, 0, 1), (_BIG, 16, 1)])
+
+
+@pytest.mark.parametrize("sizes,q,noise", _ORACLE_CASES, ids=lambda v: str(v).replace(" ", ""))
 def test_batch_driver_against_the_oracle_at_its_edges(env, sizes, q, noise):
     """the batched kernel against the CPU ORACLE (not against another HIP driver): ragged slots up to the 4096-point limit,
     q = 0 (ML: likelihood.py:18-52) and q = 1 ... 16 (REML: likelihood.py:92-129; q = 8, 16: the wide mean-space kernel of round 5),
@@ -119,10 +124,6 @@ def test_batch_driver_against_the_oracle_at_its_edges(env, sizes, q, noise):
     5e8 at n = 2048)"""
     from oracle import gp_oracle as orc
 
-    if max(sizes) == 2048 and q in (3, 4, 8):
-        pytest.skip("the 2048-point set runs q = 0, 1, 7, 16 (host eigenvalues + inverse per problem: 3 s a case)")
-    if max(sizes) > 2048 and (q not in (0, 16) or noise == 0):
-        pytest.skip("the 4096-point set runs q = 0 and q = 16 with the noise term (host eigenvalues + inverse per problem: 20 s a case)")
     d = 3
     th = np.concatenate(([0.2], -np.log(0.3 + 0.2 * np.arange(d))))
     if noise:
