@@ -25,6 +25,11 @@ from ..kernel.matern import MaternCovariance
 from .linalg import MeanSpace, covariance_factor
 
 
+# value_and_state is the first half of a value + gradient evaluation (``evaluate_pre_grad``: a gradient call follows): from this size
+# on the factorisation builds T = L^-1 along (gpmp_potrf_trtri_lower_async) -- below, the library takes the plain sequence anyway
+INVERSE_ALONG_FROM = 8192
+
+
 def _grad_trace(cov: MaternCovariance, Kinv, xi, covparam, F, G):
     lib = _lib.load()
     xi = gnp._points(xi)
@@ -58,7 +63,7 @@ class MLZeroMeanAnalytic:
         if self.mean_offset is not None:
             zi = zi - self.mean_offset(xi)
         n = xi.shape[0]
-        F = covariance_factor(self.model, xi, covparam)
+        F = covariance_factor(self.model, xi, covparam, with_inverse=n >= INVERSE_ALONG_FROM)
         w = F.solve_lower(zi)
         norm2 = float(gnp.sum(w * w).item())
         value = 0.5 * (n * math.log(2.0 * math.pi) + F.logdet() + norm2)
@@ -79,7 +84,7 @@ class REMLAnalytic:
 
     def value_and_state(self, covparam, xi, zi):
         xi, zi = gnp.asarray(xi), gnp.asarray(zi).reshape(-1)
-        F = covariance_factor(self.model, xi, covparam)
+        F = covariance_factor(self.model, xi, covparam, with_inverse=xi.shape[0] >= INVERSE_ALONG_FROM)
         P = _mean_values(self.model, xi, self.model.meanparam)
         n, q = P.shape
         ms = MeanSpace(F, zi, P)
@@ -102,6 +107,7 @@ class REMLAnalytic:
 # ---- many small problems in one call ------------------------------------------------------------------
 BATCH_MAX_N = 4096      # GPMP_BATCH_MAX_N (include/gpmp_hip.h)
 BATCH_MAX_Q = 16        # GPMP_BATCH_MAX_Q
+BATCH_MIN_PROBLEMS_ABOVE_2048 = 8
 
 
 def batch_qualifies(model, use_mean=False):
@@ -148,6 +154,11 @@ def batch_values_and_gradients(model, covparams, batches, want_grad=True, use_me
     d = int(xs[0].shape[1])
     nmax, B = max(ns), len(xs)
     if nmax > BATCH_MAX_N or any(int(x.shape[1]) != d for x in xs):
+        return None
+    if nmax > 2048 and B < BATCH_MIN_PROBLEMS_ABOVE_2048:
+        # few large problems: one at a time through the look-ahead factorisation is faster than the batched one-stream route
+        # (n = 4096: B = 4: 6.7 ms per problem batched against 4.7 one at a time; B = 16: 2.8 against 4.6 --
+        #  profiles/r5/batch_small_problems_throughput_n2048_n4096.log)
         return None
     Ps, q = None, 0
     if use_mean:
