@@ -35,7 +35,6 @@ SIGNATURES = {
     "gpmp_dinv_elems": (c_size_t, [c_int]),
     "gpmp_potrf_lower_async": (c_int, [_P, c_int, c_long, _P, _P, _P]),
     "gpmp_potrf_trsm_lower_async": (c_int, [_P, c_int, c_long, _P, _P, _P, c_int, c_long, _P]),
-    "gpmp_potrf_trtri_lower_async": (c_int, [_P, c_int, c_long, _P, _P, _P, c_long, _P]),
     "gpmp_trsm_lower": (c_int, [_P, c_int, c_long, _P, _P, c_int, c_long, c_int, _P, _P]),
     "gpmp_solve_status": (c_int, [_P, _P]),
     "gpmp_trsm_right_lower": (c_int, [_P, c_int, c_long, _P, _P, c_int, c_long, _P]),

@@ -25,11 +25,6 @@ from ..kernel.matern import MaternCovariance
 from .linalg import MeanSpace, covariance_factor
 
 
-# value_and_state is the first half of a value + gradient evaluation (``evaluate_pre_grad``: a gradient call follows): from this size
-# on the factorisation builds T = L^-1 along (gpmp_potrf_trtri_lower_async) -- below, the library takes the plain sequence anyway
-INVERSE_ALONG_FROM = 8192
-
-
 def _grad_trace(cov: MaternCovariance, Kinv, xi, covparam, F, G):
     lib = _lib.load()
     xi = gnp._points(xi)
@@ -63,7 +58,7 @@ class MLZeroMeanAnalytic:
         if self.mean_offset is not None:
             zi = zi - self.mean_offset(xi)
         n = xi.shape[0]
-        F = covariance_factor(self.model, xi, covparam, with_inverse=n >= INVERSE_ALONG_FROM)
+        F = covariance_factor(self.model, xi, covparam)
         w = F.solve_lower(zi)
         norm2 = float(gnp.sum(w * w).item())
         value = 0.5 * (n * math.log(2.0 * math.pi) + F.logdet() + norm2)
@@ -84,7 +79,7 @@ class REMLAnalytic:
 
     def value_and_state(self, covparam, xi, zi):
         xi, zi = gnp.asarray(xi), gnp.asarray(zi).reshape(-1)
-        F = covariance_factor(self.model, xi, covparam, with_inverse=xi.shape[0] >= INVERSE_ALONG_FROM)
+        F = covariance_factor(self.model, xi, covparam)
         P = _mean_values(self.model, xi, self.model.meanparam)
         n, q = P.shape
         ms = MeanSpace(F, zi, P)

@@ -16,10 +16,9 @@ from .utils import mean_values as _mean_values
 from ..kernel.matern import MaternCovariance
 
 
-def covariance_factor(model, xi, covparam, solve_along=None, with_inverse=False):
+def covariance_factor(model, xi, covparam, solve_along=None):
     """Cholesky factor of K(xi, xi): lower-triangle Gram build when the covariance is declared Matern.
-    ``solve_along``: an n x m matrix B to be overwritten by L^-1 B in the same library call -> (factor, L^-1 B).
-    ``with_inverse``: T = L^-1 built in the same library call (``F.inverse_factor()`` then hands it out)."""
+    ``solve_along``: an n x m matrix B to be overwritten by L^-1 B in the same library call -> (factor, L^-1 B)."""
     cov = model.covariance
     if isinstance(cov, MaternCovariance):
         K = cov.gram_lower(xi, covparam)
@@ -27,7 +26,7 @@ def covariance_factor(model, xi, covparam, solve_along=None, with_inverse=False)
         K = gnp.asarray(cov(xi, xi, covparam))
     if solve_along is not None:
         return gnp.cholesky_factor_solve(K, solve_along, overwrite=True)
-    return gnp.cholesky_factor(K, overwrite=True, with_inverse=with_inverse)
+    return gnp.cholesky_factor(K, overwrite=True)
 
 
 class MeanSpace:

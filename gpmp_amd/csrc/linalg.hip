@@ -314,24 +314,6 @@ struct SolveAlong {
   double* gws = nullptr;
 };
 
-// Inverse along (round 5, config 4): T = L^-1 is wanted right behind the factorisation (ML / REML gradient, leave-one-out).  The
-// inverse by doubling of the LEADING h columns (h = the top-level split of the doubling scheme) and the first product of the top
-// level, W = L21 T11, only need the first h columns of L: they are enqueued on the third stream as soon as the panel that ends at
-// column h is factored and run beside the chain-bound tail of the factorisation; the trailing block's inverse and the second
-// product follow on the caller's stream (gpmp_potrf_trtri_lower_async).
-struct InverseAlong {
-  double* T = nullptr;
-  long ldt = 0;
-  int h = 0;
-};
-struct TrtriPart {                 // which part of the doubling scheme a call runs (default: all of it)
-  long s_lo = 0, s_hi = 1L << 40;  // levels s_lo <= s < s_hi
-  int products = 3;                // bit 0: W = L21 T11, bit 1: T21 = -T22 W
-  bool diag = true, tril = true;   // copy the diagonal-block inverses in first / zero the strict upper triangle at the end
-};
-int trtri_doubling(const double* L, int n, long ldl, const double* dinv, double* T, long ldt, hipStream_t st,
-                   const ProblemBatch* pb = nullptr, long stride_t = 0, const TrtriPart& part = TrtriPart());
-
 // Schedule constants of the look-ahead factorisation, each the outcome of an A/B in one process (logs: profiles/r1 ... r4,
 // HISTORY section 4 "Switches"; rounds 1-4 kept them as environment switches):
 constexpr int LA_WIDE_ABOVE = 4096;          // 1024-column panels while more rows than this are left (rank-1024 updates: ~89 % of peak), 256-column panels below: in the chain-bound tail the in-panel updates then ride in the trailing update
@@ -339,8 +321,7 @@ constexpr int LA_LEAN_ABOVE = 4096;          // panel products take the small-fo
 constexpr int LA_SPLIT_ABOVE = 8192;         // look-ahead update of a 1024-column panel in three column pieces while more rows than this are left
 constexpr int LA_MAIN_AFTER_LA_BELOW = 4096; // at or below: a step's trailing update starts only after the next panel's look-ahead update
 
-int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hipStream_t s0, const SolveAlong* sa = nullptr,
-                    const InverseAlong* ia = nullptr) {
+int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hipStream_t s0, const SolveAlong* sa = nullptr) {
   int dev = 0;
   GPMP_HIP_TRY(hipGetDevice(&dev));
   const std::shared_ptr<DeviceState> ds = device_state(dev);
@@ -374,8 +355,7 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
   GPMP_HIP_TRY(hipEventRecord(e_f, s1));
   hipEvent_t e_u2 = nullptr;                    // trailing update k-1 finished (on s0)
   int n1_solved = 0;
-  if ((sa != nullptr || ia != nullptr) && g_solve_stream == nullptr) GPMP_HIP_TRY(hipStreamCreateWithFlags(&g_solve_stream, hipStreamNonBlocking));
-  hipEvent_t e_inv = nullptr;                   // leading part of the inverse enqueued (on g_solve_stream)
+  if (sa != nullptr && g_solve_stream == nullptr) GPMP_HIP_TRY(hipStreamCreateWithFlags(&g_solve_stream, hipStreamNonBlocking));
   if (sa != nullptr) {   // the solve stream starts after everything already queued by the caller (B is built there)
     hipEvent_t eb = g_la.next();
     GPMP_HIP_TRY(hipEventRecord(eb, s0));
@@ -470,8 +450,7 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     // one starts behind its look-ahead update anyway), the solve stream, the final join.  An event between two kernels of
     // the chain stream costs ~5 us of packet processing (kernel trace: 9-11 us gaps around the look-ahead update against
     // 0-1 us between kernels that follow each other directly).
-    const bool inv_here = ia != nullptr && p2 == ia->h;
-    const bool need_ef = sa != nullptr || inv_here || k + 2 >= np || (n - p2 > LA_MAIN_AFTER_LA_BELOW);
+    const bool need_ef = sa != nullptr || k + 2 >= np || (n - p2 > LA_MAIN_AFTER_LA_BELOW);
     hipEvent_t e_f_next = e_f;
     if (need_ef) {
       e_f_next = g_la.next();
@@ -489,18 +468,6 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
       rc = early_update(n1_solved);
       if (rc) return rc;
     }
-    if (inv_here) {
-      // columns [0, h) of L are final: the leading block's inverse and W = L21 T11 of the top level, beside the rest of the factorisation
-      GPMP_HIP_TRY(hipStreamWaitEvent(g_solve_stream, e_f_next, 0));
-      rc = trtri_doubling(A, ia->h, lda, dinv, ia->T, ia->ldt, g_solve_stream);
-      if (rc) return rc;
-      TrtriPart top;
-      top.s_lo = ia->h; top.s_hi = 2L * ia->h; top.products = 1; top.diag = false; top.tril = false;
-      rc = trtri_doubling(A, n, lda, dinv, ia->T, ia->ldt, g_solve_stream, nullptr, 0, top);
-      if (rc) return rc;
-      e_inv = g_la.next();
-      GPMP_HIP_TRY(hipEventRecord(e_inv, g_solve_stream));
-    }
     // -- main: rank-w update of the rest of the trailing matrix with P_k
     GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_main_go, 0));
     if (p2 < n) {
@@ -517,18 +484,6 @@ int potrf_lookahead(double* A, int n, long lda, double* dinv, int* info_dev, hip
     hipEvent_t e_rows = g_la.next();
     GPMP_HIP_TRY(hipEventRecord(e_rows, g_solve_stream));
     GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_rows, 0));
-  }
-  if (ia != nullptr) {
-    if (e_inv == nullptr) { set_error("inverse along: no panel ends at column %d", ia->h); return -1; }
-    GPMP_HIP_TRY(hipStreamWaitEvent(s0, e_inv, 0));
-    // the trailing block's inverse, then T21 = -T22 W and the zeroing of the strict upper triangle (W's parking place included)
-    const int h = ia->h;
-    rc = trtri_doubling(A + (long)h * lda + h, n - h, lda, dinv + (size_t)(h / NB) * NB * NB, ia->T + (long)h * ia->ldt + h, ia->ldt, s0);
-    if (rc) return rc;
-    TrtriPart top;
-    top.s_lo = h; top.s_hi = 2L * h; top.products = 2; top.diag = false; top.tril = true;
-    rc = trtri_doubling(A, n, lda, dinv, ia->T, ia->ldt, s0, nullptr, 0, top);
-    if (rc) return rc;
   }
   return 0;
 }
@@ -583,14 +538,12 @@ int trsm_backward(const double* L, int n, long ldl, const double* dinv, double* 
 // T11 (first product, as the transposed left operand) and of T22 (second product) is skipped tile-wise, so the W blocks
 // above the diagonal are never read as part of a triangle; they are zeroed at the end.
 int trtri_doubling(const double* L, int n, long ldl, const double* dinv, double* T, long ldt, hipStream_t st,
-                   const ProblemBatch* pb, long stride_t, const TrtriPart& what) {
+                   const ProblemBatch* pb = nullptr, long stride_t = 0) {
   const int nprob = pb != nullptr ? pb->nprob : 1;
   const long sl = pb != nullptr ? pb->stride_a : 0;
-  int rc = what.diag ? launch_diag_blocks(T, n, ldt, dinv, st, nprob, stride_t, pb != nullptr ? pb->stride_dinv : 0) : 0;
+  int rc = launch_diag_blocks(T, n, ldt, dinv, st, nprob, stride_t, pb != nullptr ? pb->stride_dinv : 0);
   if (rc) return rc;
-  const bool first = (what.products & 1) != 0, second = (what.products & 2) != 0;
   for (long s = NB; s < n; s *= 2) {
-    if (s < what.s_lo || s >= what.s_hi) continue;
     const int npairs = (int)(n / (2 * s));                  // pairs with two full halves
     const long tail0 = (long)npairs * 2 * s;                // a ragged pair starts here if tail0 + s < n
     for (int part = 0; part < 2; ++part) {
@@ -612,13 +565,13 @@ int trtri_doubling(const double* L, int n, long ldl, const double* dinv, double*
         g1.kstart_col = 1;                                   // T11(l, j) = 0 for l < j
         g1.batch = batch; g1.stride_a = 2 * s * (ldl + 1); g1.stride_b = 2 * s * (ldt + 1); g1.stride_c = 2 * s * (ldt + 1);
         g1.batch2 = nprob; g1.stride2_a = sl; g1.stride2_b = stride_t; g1.stride2_c = stride_t;
-        rc = first ? launch_gemm(true, false, len2, (int)s, (int)s, 1.0, L21, ldl, T11, ldt, 0.0, W, ldt, g1, st) : 0;
+        rc = launch_gemm(true, false, len2, (int)s, (int)s, 1.0, L21, ldl, T11, ldt, 0.0, W, ldt, g1, st);
         if (rc) return rc;
         GemmOpts g2;
         g2.kend_row = 1;                                     // T22(i, l) = 0 for l > i
         g2.batch = batch; g2.stride_a = g2.stride_b = g2.stride_c = 2 * s * (ldt + 1);
         g2.batch2 = nprob; g2.stride2_a = g2.stride2_b = g2.stride2_c = stride_t;
-        rc = second ? launch_gemm(true, false, len2, (int)s, len2, -1.0, T22, ldt, W, ldt, 0.0, T21, ldt, g2, st) : 0;
+        rc = launch_gemm(true, false, len2, (int)s, len2, -1.0, T22, ldt, W, ldt, 0.0, T21, ldt, g2, st);
         if (rc) return rc;
         continue;
       }
@@ -626,17 +579,17 @@ int trtri_doubling(const double* L, int n, long ldl, const double* dinv, double*
       g1.kstart_row = 1;                                     // (T11^T)(i, l) = T11(l, i) = 0 for l < i
       g1.batch = batch; g1.stride_a = 2 * s * (ldt + 1); g1.stride_b = 2 * s * (ldl + 1); g1.stride_c = 2 * s * (ldt + 1);
       g1.batch2 = nprob; g1.stride2_a = stride_t; g1.stride2_b = sl; g1.stride2_c = stride_t;
-      rc = first ? launch_gemm(false, true, (int)s, len2, (int)s, 1.0, T11, ldt, L21, ldl, 0.0, Wt, ldt, g1, st) : 0;
+      rc = launch_gemm(false, true, (int)s, len2, (int)s, 1.0, T11, ldt, L21, ldl, 0.0, Wt, ldt, g1, st);
       if (rc) return rc;
       GemmOpts g2;
       g2.kend_row = 1;                                       // T22(i, l) = 0 for l > i
       g2.batch = batch; g2.stride_a = g2.stride_b = g2.stride_c = 2 * s * (ldt + 1);
       g2.batch2 = nprob; g2.stride2_a = g2.stride2_b = g2.stride2_c = stride_t;
-      rc = second ? launch_gemm(true, true, len2, (int)s, len2, -1.0, T22, ldt, Wt, ldt, 0.0, T21, ldt, g2, st) : 0;
+      rc = launch_gemm(true, true, len2, (int)s, len2, -1.0, T22, ldt, Wt, ldt, 0.0, T21, ldt, g2, st);
       if (rc) return rc;
     }
   }
-  return what.tril ? launch_tril(T, n, ldt, st, nprob, stride_t) : 0;
+  return launch_tril(T, n, ldt, st, nprob, stride_t);
 }
 
 }  // namespace
@@ -781,32 +734,6 @@ extern "C" int gpmp_potrf_trsm_lower_async(double* A, int n, long lda, double* d
   if (rc || m == 0) return rc;
   if (m <= TRSV_FEW_MAX) return trsv_few(A, n, lda, dinv, B, m, ldb, 0, st);
   return trsm_forward(A, n, lda, dinv, B, m, ldb, gws, st);
-}
-
-extern "C" int gpmp_potrf_trtri_lower_async(double* A, int n, long lda, double* dinv, int* info_dev, double* T, long ldt,
-                                            gpmp_stream_t stream) {
-  GPMP_ARG(A != nullptr, 1, "A is NULL");
-  GPMP_ARG(n >= 0, 2, "n < 0");
-  GPMP_ARG(lda >= n, 3, "lda < n");
-  GPMP_ARG(dinv != nullptr, 4, "dinv is NULL");
-  GPMP_ARG(info_dev != nullptr, 5, "info_dev is NULL");
-  GPMP_ARG(T != nullptr && ldt >= n, 6, "T is NULL or ldt < n");
-  if (n == 0) return 0;
-  hipStream_t st = as_stream(stream);
-  GPMP_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
-  // the leading block of the doubling scheme's top level: h = 128 * 2^k < n.  Its inverse runs along the factorisation where the
-  // latter has a chain-bound tail worth filling and a panel ends exactly at h (1024-column panels while more than 4096 rows are
-  // left, 256 below: h is a multiple of 1024 from n > 8192 on)
-  long h = NB;
-  while (2 * h < n) h *= 2;
-  if (n >= 8192 && h % (2 * OUTER_BLOCKS * NB) == 0) {
-    InverseAlong ia;
-    ia.T = T; ia.ldt = ldt; ia.h = (int)h;
-    return potrf_lookahead(A, n, lda, dinv, info_dev, st, nullptr, &ia);
-  }
-  int rc = (n <= POTRF_ONE_STREAM_MAX) ? potrf_blocked(A, n, lda, dinv, info_dev, 0, st) : potrf_lookahead(A, n, lda, dinv, info_dev, st);
-  if (rc) return rc;
-  return trtri_doubling(A, n, lda, dinv, T, ldt, st);
 }
 
 extern "C" int gpmp_trtri_diag_blocks(const double* L, int n, long ldl, double* dinv, gpmp_stream_t stream) {

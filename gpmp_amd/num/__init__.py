@@ -344,12 +344,11 @@ def scaled_distance_elementwise(loginvrho, x, y):
 class CholFactor:
     """Lower Cholesky factor in HBM + the inverses of its 128 x 128 diagonal blocks."""
 
-    __slots__ = ("L", "dinv", "n", "_logdet", "_T")
+    __slots__ = ("L", "dinv", "n", "_logdet")
 
-    def __init__(self, L, dinv, T=None):
+    def __init__(self, L, dinv):
         self.L, self.dinv, self.n = L, dinv, L.shape[0]
         self._logdet = None
-        self._T = T               # L^-1 when the factorisation was asked to build it along (cholesky_factor(with_inverse=True))
 
     def logdet(self):
         """2 sum log L_ii (likelihood.py:50) -> python float."""
@@ -385,9 +384,6 @@ class CholFactor:
     def inverse_factor(self):
         """T = L^-1 (lower triangular, strict upper part zero)."""
         lib = _lib.load()
-        if self._T is not None:
-            T, self._T = self._T, None        # handed out once: callers overwrite or drop it (K^-1 is built over the factor's buffers)
-            return T
         T = alloc_matrix(self.n, self.n)
         _lib.check(lib.gpmp_trtri_lower(_ptr(self.L), self.n, _ld(self.L), _ptr(self.dinv), _ptr(T), _ld(T), _stream()),
                    "gpmp_trtri_lower")
@@ -403,10 +399,8 @@ class CholFactor:
         return Kinv
 
 
-def cholesky_factor(A, overwrite=False, check=True, with_inverse=False) -> CholFactor:
-    """Factor a symmetric positive definite matrix (only its lower triangle is read).  ``with_inverse``: also build T = L^-1 in
-    the same library call (gpmp_potrf_trtri_lower_async: the leading part of the inverse runs beside the chain-bound tail of
-    the factorisation) -- for callers that will ask for ``inverse_factor()`` anyway (criterion + gradient, leave-one-out)."""
+def cholesky_factor(A, overwrite=False, check=True) -> CholFactor:
+    """Factor a symmetric positive definite matrix (only its lower triangle is read)."""
     lib = _lib.load()
     A = asarray(A)
     if A.dim() != 2 or A.shape[0] != A.shape[1]:
@@ -415,20 +409,14 @@ def cholesky_factor(A, overwrite=False, check=True, with_inverse=False) -> CholF
     L = as_matrix(A, copy=not overwrite)
     dinv = torch.empty(builtins.max(int(lib.gpmp_dinv_elems(n)), 1), dtype=torch.float64, device=_dev())
     info = torch.zeros(1, dtype=torch.int32, device=_dev())
-    T = None
-    if with_inverse:
-        T = alloc_matrix(n, n)
-        _lib.check(lib.gpmp_potrf_trtri_lower_async(_ptr(L), n, _ld(L), _ptr(dinv), _ptr(info), _ptr(T), _ld(T), _stream()),
-                   "gpmp_potrf_trtri_lower_async")
-    else:
-        _lib.check(lib.gpmp_potrf_lower_async(_ptr(L), n, _ld(L), _ptr(dinv), _ptr(info), _stream()), "gpmp_potrf_lower_async")
+    _lib.check(lib.gpmp_potrf_lower_async(_ptr(L), n, _ld(L), _ptr(dinv), _ptr(info), _stream()), "gpmp_potrf_lower_async")
     if check:
         k = int(info.item())
         if k != 0:
             raise HipLinAlgError(
                 f"Matrix is not positive definite: Cholesky factorization failed at leading minor {k} (potrf info={k})"
             )
-    return CholFactor(L, dinv, T)
+    return CholFactor(L, dinv)
 
 
 def cholesky_factor_solve(A, B, overwrite=True, check=True):

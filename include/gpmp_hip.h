@@ -123,23 +123,13 @@ size_t gpmp_dinv_elems(int n);
  * gpmp/num/numpy_backend.py:30-46,158-162); the factor is then unspecified.  Enqueue only. */
 int gpmp_potrf_lower_async(double* A, int n, long lda, double* dinv, int* info_dev, gpmp_stream_t stream);
 
-/* gpmp_potrf_lower_async followed by B <- L^-1 B (n x m, as gpmp_trsm_lower with trans = 0).  At chain-bound sizes
- * (1024 < n <= 8192, more than 16 right-hand sides) the rows of B are solved a quarter of the matrix at a time on an internal
- * stream as soon as the panels they need are factored, so that the solve fills the machine the factorisation leaves idle (the
- * path of one prediction: cholesky_solve on K(xi,xi) and K(xi,xt), gpmp/core/kriging.py:59-62); above, the solve follows the
- * factorisation on `stream`.  dinv: gpmp_dinv_elems(n) doubles (block inverses + scratch of the solve leaves).
+/* gpmp_potrf_lower_async followed by B <- L^-1 B (n x m, as gpmp_trsm_lower with trans = 0), with the solve of the leading
+ * half of the rows enqueued on an internal stream as soon as those columns of L are final, so that it overlaps the
+ * chain-bound trailing half of the factorisation (the path of one prediction: cholesky_solve on K(xi,xi) and K(xi,xt),
+ * gpmp/core/kriging.py:59-62).  dinv: gpmp_dinv_elems(n) doubles (block inverses + scratch of the solve leaves).
  * Everything is joined into `stream` before return; *info_dev as gpmp_potrf_lower_async (B is then unspecified). */
 int gpmp_potrf_trsm_lower_async(double* A, int n, long lda, double* dinv, int* info_dev, double* B, int m, long ldb,
                                 gpmp_stream_t stream);
-
-/* gpmp_potrf_lower_async followed by T <- L^-1 (as gpmp_trtri_lower): what a criterion WITH its gradient, or a leave-one-out
- * evaluation, needs right behind the factorisation (gpmp/core/linalg.py:17-46 forms C^-1 by a solve against the identity;
- * gpmp/num/torch_backend.py:574-604 differentiates through the factorisation).  From n = 8192 on, the inverse of the leading
- * block of columns (the top-level split of the doubling scheme) and its product with the rows below are enqueued on an internal
- * stream as soon as those columns are final and run beside the chain-bound tail of the factorisation.  T: n x n, ldt >= n,
- * distinct from A.  Everything is joined into `stream` before return; *info_dev as gpmp_potrf_lower_async (T is then unspecified). */
-int gpmp_potrf_trtri_lower_async(double* A, int n, long lda, double* dinv, int* info_dev, double* T, long ldt,
-                                 gpmp_stream_t stream);
 
 /* B <- op(L)^-1 B for an n x m row-major B; trans = 0: L, 1: L^T.  Replaces
  * scipy.linalg.solve_triangular (numpy_backend.py:467-468, gpmp/core/linalg.py:41).  If

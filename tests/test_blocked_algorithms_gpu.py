@@ -57,28 +57,3 @@ def test_inverse_factor_vs_lapack(gnp, n):
     L = np.tril(gnp.to_np(F.L))
     assert np.array_equal(np.triu(T, 1), np.zeros((n, n)))
     assert rel_err(T @ L, np.eye(n)) < 1e-9
-
-
-@pytest.mark.parametrize("n", [5003, 8192, 9300, 16384])
-def test_factor_with_inverse_along_equals_the_sequence(gnp, n):
-    """gpmp_potrf_trtri_lower_async (round 5): factor + T = L^-1 in one call; from n = 8192 on the leading block's inverse and its
-    product with the rows below run beside the tail of the factorisation (n = 9300: a ragged top-level pair; 5003: the plain
-    sequence).  Same kernels on the same operands in the same order per entry: L and T are IDENTICAL to potrf followed by trtri,
-    and T L = I (what gpmp/core/linalg.py:17-46 gets from solve_triangular(C, eye(n)))."""
-    import torch
-
-    K, _ = _spd(n)
-    Kd = gnp.asarray(K)
-    F0 = gnp.cholesky_factor(Kd)
-    T0 = F0.inverse_factor()
-    F1 = gnp.cholesky_factor(Kd, with_inverse=True)
-    T1 = F1.inverse_factor()
-    assert torch.equal(torch.tril(F0.L), torch.tril(F1.L))
-    assert torch.equal(T0, T1)
-    assert torch.equal(torch.triu(T1, 1), torch.zeros_like(T1))
-    L = torch.tril(F1.L)
-    R = gnp.matmul(T1, L)
-    R.diagonal().sub_(1.0)
-    assert float(R.abs().max()) < 1e-9
-    T2 = F1.inverse_factor()                      # handed out once; a second request computes it again
-    assert T2.data_ptr() != T1.data_ptr() and torch.equal(T2, T1)
