@@ -11,15 +11,18 @@ Two sides, run one after the other (each side alone fits the 288 GB of one MI355
            ranks SHARING the GPU over gloo: local Gram, factor, NLL, prediction (+ weights: the backward solve), then value +
            gradient at --grad-n; compared with the .npz of ``single``.
 
-The pool's process guard allows at most SIX processes on the card, so the grid is 2 x 3 (six ranks, 22.9 GB of local matrix
-each) and not the 2 x 4 of eight GPUs; the local kernels of the 2 x 4 coordinates at this n run in tools/dist_rank_emulation.py.
+The pool's process guard allows at most SIX processes on the card, so with one PROCESS per rank the grid is 2 x 3 (six ranks,
+22.9 GB of local matrix each).  ``--threads`` runs the ranks as THREADS of one process instead (torch's in-process "threaded"
+process group of torch.testing: collectives are host copies between the threads; every rank has its own HipLocalOps, streams and
+buffers on the shared GPU) -- that is how the 2 x 4 grid of BASELINE config 5 itself runs here: eight ranks, 17.2 GB each.
 The gradient's working set (factor + T + the neighbour's T + one block of T^T T per rank) is 3.4 x the local matrix: at
 n = 131072 that is 500 GB over the ranks -- it needs the eight GPUs -- so the value + gradient is compared at --grad-n.
 
 What is checked is what the reference computes at gpmp/num/numpy_backend.py:465-469 (cholesky_solve) and
 gpmp/core/likelihood.py:18-52 (the zero-mean NLL); gpmp/core/kriging.py:35-67 (mean / variance / weights).
 
-    python tools/config5_full.py all                                   # both sides + comparison ("CONFIG5 FULL OK")
+    python tools/config5_full.py all                                   # both sides + comparison ("CONFIG5 FULL OK"), 2 x 3 processes over gloo
+    python tools/config5_full.py all --threads --grid 2x4              # the same on the 2 x 4 grid, eight thread-ranks in one process
     python tools/config5_full.py all --size-n 32768 --grad-n 16384 --m 2048     # the same at a size for the default GPU suite
 """
 import argparse
@@ -175,16 +178,70 @@ def single(a):
 # ------------------------------------------------------------------------------------------------------------------
 # distributed side
 # ------------------------------------------------------------------------------------------------------------------
-def dist_worker(rank, world, port, a):
+def _thread_rank_class():
+    """BlockCyclicCholesky for ranks that are threads of one process (torch.testing's "threaded" process group has broadcast,
+    all-reduce and all-gather, no reduce and no point-to-point): a reduce is an all-reduce whose result the destination keeps,
+    the gradient's ring shift a round of broadcasts inside the process row of which every rank keeps the one from its source."""
     import torch
+    import torch.distributed as dist
+
+    from gpmp_amd.dist import BlockCyclicCholesky
+
+    class ThreadRankCholesky(BlockCyclicCholesky):
+        def _reduce(self, t, dst_rank, group, what):
+            self._log(group, f"reduce:{what}", dst_rank, t.numel())
+            ct = t.detach().to("cpu").contiguous()
+            dist.all_reduce(ct, op=dist.ReduceOp.SUM, group=group)
+            if self.grid.rank == dst_rank:
+                t.copy_(ct)
+            return t
+
+        def _ring_shift(self, t, shift):
+            g = self.grid
+            src_c = (g.c + shift) % g.pc
+            self._log(g.row_group, f"ring_shift{shift}", -1, t.shape[0])
+            mine = t.detach().to("cpu").contiguous()
+            keep = None
+            for cc in range(g.pc):
+                w = sum(self.bs(J) for J in g.local_col_blocks(self.nblocks, cc))
+                buf = mine if cc == g.c else torch.empty((t.shape[0], w), dtype=t.dtype)
+                dist.broadcast(buf, src=g.rank_of(g.r, cc), group=g.row_group)
+                if cc == src_c:
+                    keep = buf
+                    self.bytes_received += buf.numel() * 8
+            return keep.to(t.device)
+
+    return ThreadRankCholesky
+
+
+def dist_worker(rank, world, port, a):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from gpmp_amd.dist import BlockCyclicCholesky
+
+        def exchange(obj):
+            parts = [None] * world
+            dist.all_gather_object(parts, obj)
+            return parts
+
+        dist_body(rank, world, a, BlockCyclicCholesky, exchange)
+    finally:
+        dist.destroy_process_group()
+
+
+def dist_body(rank, world, a, Cholesky, exchange):
+    """One rank of the distributed side (a process over gloo, or a thread of the one process under --threads).
+    ``exchange(obj)`` -> the objects of all ranks, in rank order."""
+    import torch
+    import torch.distributed as dist
+
+    if True:
         import gpmp_amd.num as gnp
-        from gpmp_amd.dist import BlockCyclicCholesky, HipLocalOps, ProcessGrid
+        from gpmp_amd.dist import HipLocalOps, ProcessGrid
         from gpmp_amd.kernel import MaternCovariance
 
         pr, pc = (int(v) for v in a.grid.split("x"))
@@ -204,7 +261,7 @@ def dist_worker(rank, world, port, a):
             if rank == 0:
                 log("dist: " + msg)
 
-        ch = BlockCyclicCholesky(grid, n, nb=NB, ops=HipLocalOps(), transport=a.transport, profile=True)
+        ch = Cholesky(grid, n, nb=NB, ops=HipLocalOps(), transport=a.transport, profile=True)
         if a.device_comm:
             ch.backend = "nccl"        # the device-resident communication branches (what runs under RCCL), moved by gloo
         t0 = tick()
@@ -216,7 +273,7 @@ def dist_worker(rank, world, port, a):
         phases = ch.phase_times()
         t2 = tick()
         sec["factor"] = t2 - t1
-        say(f"factor: info {info}, {sec['factor']:.1f} s = {n ** 3 / 3 / sec['factor'] / 1e12:.1f} TFLOP/s aggregate over the shared GPU; "
+        say(f"factor: info {info}, {sec['factor']:.1f} s = {n ** 3 / 3 / sec['factor'] / 1e12:.1f} TFLOP/s aggregate over the shared GPU (messages through host memory); "
             f"rank 0 phases (ms, summed HIP-event spans): { {k: round(v) for k, v in phases.items()} }")
         nll = ch.negative_log_likelihood(z)
         logdet = ch.logdet()
@@ -244,7 +301,7 @@ def dist_worker(rank, world, port, a):
         if a.grad_n:
             gn = a.grad_n
             th2 = np.concatenate(([theta[0], math.log(NOISE)], theta[1:]))
-            chg = BlockCyclicCholesky(grid, gn, nb=NB, ops=HipLocalOps(), transport=a.transport)
+            chg = Cholesky(grid, gn, nb=NB, ops=HipLocalOps(), transport=a.transport)
             if a.device_comm:
                 chg.backend = "nccl"
             chg.build_local_gram(cov, gnp.asarray(x[:gn]), theta, NOISE)
@@ -256,10 +313,12 @@ def dist_worker(rank, world, port, a):
             received += chg.bytes_received
             say(f"n={gn}: factor (info {ginfo}) {sec['grad_factor']:.1f} s, ML value + gradient {sec['value_and_grad']:.1f} s")
             del chg
-        rec = {"rank": rank, "pid": os.getpid(), "coords": (grid.r, grid.c), "local_matrix": local_shape, "GB_received": received / 1e9,
-               "device": torch.cuda.get_device_name(0), "peak_GB_allocated": torch.cuda.max_memory_allocated() / 1e9}
-        parts = [None] * world
-        dist.all_gather_object(parts, (rec, ri[rsel], ci[csel], Lloc, (j0, j1), grid.r, mean, var, lam_rows))
+        import threading
+
+        rec = {"rank": rank, "pid": os.getpid(), "thread": threading.get_ident() if a.threads else None, "coords": (grid.r, grid.c), "local_matrix": local_shape, "GB_received": received / 1e9,
+               "device": getattr(a, "device_name", None) or torch.cuda.get_device_name(torch.cuda.current_device()),
+               "peak_GB_allocated": torch.cuda.max_memory_allocated(torch.cuda.current_device()) / 1e9}
+        parts = exchange((rec, ri[rsel], ci[csel], Lloc, (j0, j1), grid.r, mean, var, lam_rows))
         if rank == 0:
             Ls = np.full((len(rows_np), len(cols_np)), np.nan)
             zpm, zpv = np.full(m, np.nan), np.full(m, np.nan)
@@ -280,10 +339,70 @@ def dist_worker(rank, world, port, a):
                      grad_value=np.nan if val is None else val, grad=np.zeros(0) if grad is None else grad,
                      seconds=json.dumps(sec), phases=json.dumps(phases), ranks=json.dumps(recs))
             for rc in recs:
-                log(f"dist: rank {rc['rank']} pid {rc['pid']} coords {tuple(rc['coords'])} local matrix {tuple(rc['local_matrix'])} "
-                    f"received {rc['GB_received']:.1f} GB peak allocated {rc['peak_GB_allocated']:.1f} GB on {rc['device']}")
-    finally:
-        dist.destroy_process_group()
+                who = f"pid {rc['pid']}" + (f" thread {rc['thread']}" if rc.get("thread") else "")
+                log(f"dist: rank {rc['rank']} {who} coords {tuple(rc['coords'])} local matrix {tuple(rc['local_matrix'])} "
+                    f"received {rc['GB_received']:.1f} GB; peak allocated {rc['peak_GB_allocated']:.1f} GB"
+                    f"{' (all thread-ranks of the process together)' if rc.get('thread') else ''} on {rc['device']}")
+
+
+def run_dist_threads(a):
+    """The distributed side with the ranks as THREADS of this process (see the module docstring): the grid of eight ranks the
+    process guard denies to processes.  Bounded like the process form: a watchdog ends the process if the ranks are still running
+    after --limit seconds."""
+    import threading
+    import traceback
+
+    import torch
+    import torch.distributed as dist
+    from torch.testing._internal.distributed import multi_threaded_pg as mtpg
+
+    pr, pc = (int(v) for v in a.grid.split("x"))
+    world = pr * pc
+    if a.transport != "bcast" or a.device_comm:
+        raise SystemExit("--threads: the in-process group has no point-to-point operations and moves host tensors: bcast transport only")
+    import gpmp_amd.num  # noqa: F401 -- the library is loaded and its signatures declared ONCE, before the rank threads start
+    from gpmp_amd import _lib
+
+    _lib.load()
+    torch.cuda.init()
+    a.device_name = torch.cuda.get_device_name(0)           # (asked here: torch's device-property cache is filled by the thread that initialised it)
+    mtpg._install_threaded_pg()
+    torch._C._distributed_c10d._set_thread_isolation_mode(True)      # (group registry per thread, as torch's MultiThreadedTestCase does)
+    store = dist.HashStore()
+    Cholesky = _thread_rank_class()
+    board, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="threaded", rank=rank, world_size=world, store=store)
+
+            def exchange(obj):
+                board[rank] = obj
+                dist.barrier()
+                return list(board)
+
+            dist_body(rank, world, a, Cholesky, exchange)
+            dist.barrier()
+        except BaseException:  # noqa: BLE001 -- a failing rank must release the others from their collectives
+            errors.append(f"rank {rank}:\n{traceback.format_exc()}")
+            mtpg.ProcessLocalGroup.exception_handle(None)
+
+    def watchdog():
+        log(f"dist: thread-ranks still running after {a.limit:.0f} s: ending the process")
+        os._exit(3)
+
+    timer = threading.Timer(a.limit, watchdog)
+    timer.daemon = True
+    timer.start()
+    threads = [threading.Thread(target=rank_main, args=(r,), name=f"rank{r}") for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    timer.cancel()
+    if errors:
+        raise SystemExit("distributed side failed:\n" + errors[0])
 
 
 def run_dist(a):
@@ -338,11 +457,12 @@ def compare(a):
         tol.update(grad_value_rel=1e-11 * cs, grad_rel=1e-7)
     ok = errs["info"] == 0 and bool(np.isfinite(d["mean"]).all() and np.isfinite(d["lam_sample"]).all()) and all(errs[k] <= t for k, t in tol.items())
     log("single-GPU seconds: " + str(s["seconds"]))
-    log("distributed seconds (max-synchronised phases, ranks sharing ONE GPU over gloo): " + str(d["seconds"]))
+    log(f"distributed seconds (max-synchronised phases, ranks sharing ONE GPU, {'thread-ranks: collectives = host copies between threads' if a.threads else 'over gloo'}): " + str(d["seconds"]))
     log("deviations (block-cyclic vs single GPU): " + json.dumps(errs))
     log("tolerances: " + json.dumps(tol))
+    how = "thread-ranks of one process (in-process group)" if a.threads else "one process per rank over gloo"
     print(f"CONFIG5 FULL {'OK' if ok else 'FAILED'}: n={a.n} grid {a.grid} block {NB} transport {a.transport}"
-          f"{' device-resident comm' if a.device_comm else ''}; gradient at n={a.grad_n}", flush=True)
+          f"{' device-resident comm' if a.device_comm else ''}, {how}; gradient at n={a.grad_n}", flush=True)
     return 0 if ok else 1
 
 
@@ -355,6 +475,7 @@ def main():
     ap.add_argument("--grid", default="2x3")
     ap.add_argument("--transport", default="bcast")
     ap.add_argument("--device-comm", action="store_true")
+    ap.add_argument("--threads", action="store_true", help="ranks as threads of ONE process (in-process 'threaded' process group): the 2 x 4 grid")
     ap.add_argument("--limit", type=float, default=1500.0, help="seconds allowed to the distributed side before its workers are killed")
     ap.add_argument("--out", default="/tmp/config5_single.npz")
     ap.add_argument("--dist-out", default="/tmp/config5_dist.npz")
@@ -363,7 +484,7 @@ def main():
     if a.what == "single":
         return single(a)
     if a.what == "dist":
-        return run_dist(a)
+        return run_dist_threads(a) if a.threads else run_dist(a)
     if a.what == "compare":
         return compare(a)
     # all: the single-GPU side in a child process of its own (its 137 GB are gone when it ends), then the ranks, then the comparison
@@ -372,7 +493,13 @@ def main():
     r = subprocess.run(args, env=env, timeout=a.limit)
     if r.returncode != 0:
         raise SystemExit(f"single-GPU side failed ({r.returncode})")
-    run_dist(a)
+    if a.threads:
+        # (in a child as well: the thread-ranks initialise the GPU in their process; this one stays a GPU-free coordinator)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "dist"] + sys.argv[2:], env=env, timeout=a.limit + 60)
+        if r.returncode != 0:
+            raise SystemExit(f"distributed side failed ({r.returncode})")
+    else:
+        run_dist(a)
     return compare(a)
 
 
