@@ -28,6 +28,14 @@ def _run(args, limit):
     return r.stdout
 
 
+def test_config5_schedule_with_values_at_n32768_on_the_2x4_grid_of_thread_ranks(tmp_path):
+    """the grid of BASELINE config 5 itself: eight ranks as THREADS of one process (torch.testing's in-process process group; every
+    rank its own HipLocalOps, streams and buffers on the shared GPU) -- the process guard denies eight processes.  Pc = 4 also takes
+    the gradient's ring through all three of its branches (same column set, full pair, half-way pair)."""
+    _run(["--threads", "--grid", "2x4", "--size-n", "32768", "--grad-n", "16384", "--m", "2048", "--limit", "300", "--out", str(tmp_path / "s.npz"),
+          "--dist-out", str(tmp_path / "d.npz")], 700)
+
+
 def test_config5_schedule_with_values_at_n32768_on_the_2x2_grid(tmp_path):
     _run(["--grid", "2x2", "--size-n", "32768", "--grad-n", "16384", "--m", "2048", "--limit", "300", "--out", str(tmp_path / "s.npz"),
           "--dist-out", str(tmp_path / "d.npz")], 700)

@@ -239,110 +239,109 @@ def dist_body(rank, world, a, Cholesky, exchange):
     import torch
     import torch.distributed as dist
 
-    if True:
-        import gpmp_amd.num as gnp
-        from gpmp_amd.dist import HipLocalOps, ProcessGrid
-        from gpmp_amd.kernel import MaternCovariance
+    import gpmp_amd.num as gnp
+    from gpmp_amd.dist import HipLocalOps, ProcessGrid
+    from gpmp_amd.kernel import MaternCovariance
 
-        pr, pc = (int(v) for v in a.grid.split("x"))
-        n, m = a.n, a.m
-        x, z, theta, xt = inputs(n, m)
-        cov = MaternCovariance(2)
-        grid = ProcessGrid(pr, pc)
-        xd = gnp.asarray(x)
-        sec = {}
+    pr, pc = (int(v) for v in a.grid.split("x"))
+    n, m = a.n, a.m
+    x, z, theta, xt = inputs(n, m)
+    cov = MaternCovariance(2)
+    grid = ProcessGrid(pr, pc)
+    xd = gnp.asarray(x)
+    sec = {}
 
-        def tick():
-            torch.cuda.synchronize()
-            dist.barrier()
-            return time.perf_counter()
+    def tick():
+        torch.cuda.synchronize()
+        dist.barrier()
+        return time.perf_counter()
 
-        def say(msg):
-            if rank == 0:
-                log("dist: " + msg)
-
-        ch = Cholesky(grid, n, nb=NB, ops=HipLocalOps(), transport=a.transport, profile=True)
-        if a.device_comm:
-            ch.backend = "nccl"        # the device-resident communication branches (what runs under RCCL), moved by gloo
-        t0 = tick()
-        ch.build_local_gram(cov, xd, theta, NOISE)
-        t1 = tick()
-        sec["gram"] = t1 - t0
-        say(f"local Gram {tuple(ch.A.shape)} = {ch.A.numel() * 8 / 1e9:.1f} GB per rank: {sec['gram']:.2f} s")
-        info = ch.factor()
-        phases = ch.phase_times()
-        t2 = tick()
-        sec["factor"] = t2 - t1
-        say(f"factor: info {info}, {sec['factor']:.1f} s = {n ** 3 / 3 / sec['factor'] / 1e12:.1f} TFLOP/s aggregate over the shared GPU (messages through host memory); "
-            f"rank 0 phases (ms, summed HIP-event spans): { {k: round(v) for k, v in phases.items()} }")
-        nll = ch.negative_log_likelihood(z)
-        logdet = ch.logdet()
-        t3 = tick()
-        sec["nll"] = t3 - t2
-        say(f"nll {nll!r} logdet {logdet!r}: {sec['nll']:.1f} s")
-        # ---- sampled entries of the factor
-        rows_np, cols_np = samples(n, m)
-        ri, ci = ch.global_row_index(), ch.global_col_index()
-        rsel, csel = np.nonzero(np.isin(ri, rows_np))[0], np.nonzero(np.isin(ci, cols_np))[0]
-        Lloc = gnp.to_np(ch.A[torch.as_tensor(rsel, device=ch.A.device)][:, torch.as_tensor(csel, device=ch.A.device)]) if len(rsel) and len(csel) else np.zeros((0, 0))
-        # ---- prediction with weights
-        mean, var, (j0, j1), lam = ch.predict(cov, xd, z, xt, theta, return_lambdas=True)
-        lam_rows = gnp.to_np(lam[torch.as_tensor(rsel, device=lam.device)]) if len(rsel) and j1 > j0 else np.zeros((len(rsel), j1 - j0))
-        del lam
-        t4 = tick()
-        sec["predict_with_weights"] = t4 - t3
-        say(f"prediction at {m} points + weights (forward + backward many-RHS solves): {sec['predict_with_weights']:.1f} s")
-        received = ch.bytes_received
-        local_shape = tuple(ch.A.shape)
-        del ch
-        torch.cuda.empty_cache()
-        # ---- value + gradient at grad_n
-        val = grad = None
-        if a.grad_n:
-            gn = a.grad_n
-            th2 = np.concatenate(([theta[0], math.log(NOISE)], theta[1:]))
-            chg = Cholesky(grid, gn, nb=NB, ops=HipLocalOps(), transport=a.transport)
-            if a.device_comm:
-                chg.backend = "nccl"
-            chg.build_local_gram(cov, gnp.asarray(x[:gn]), theta, NOISE)
-            ginfo = chg.factor()
-            t5 = tick()
-            val, grad = chg.value_and_grad(x[:gn], z[:gn], th2, 2, noise=True)
-            t6 = tick()
-            sec["grad_factor"], sec["value_and_grad"] = t5 - t4, t6 - t5
-            received += chg.bytes_received
-            say(f"n={gn}: factor (info {ginfo}) {sec['grad_factor']:.1f} s, ML value + gradient {sec['value_and_grad']:.1f} s")
-            del chg
-        import threading
-
-        rec = {"rank": rank, "pid": os.getpid(), "thread": threading.get_ident() if a.threads else None, "coords": (grid.r, grid.c), "local_matrix": local_shape, "GB_received": received / 1e9,
-               "device": getattr(a, "device_name", None) or torch.cuda.get_device_name(torch.cuda.current_device()),
-               "peak_GB_allocated": torch.cuda.max_memory_allocated(torch.cuda.current_device()) / 1e9}
-        parts = exchange((rec, ri[rsel], ci[csel], Lloc, (j0, j1), grid.r, mean, var, lam_rows))
+    def say(msg):
         if rank == 0:
-            Ls = np.full((len(rows_np), len(cols_np)), np.nan)
-            zpm, zpv = np.full(m, np.nan), np.full(m, np.nan)
-            lam_s = np.full((len(rows_np), m), np.nan)
-            rpos = {int(g): i for i, g in enumerate(rows_np)}
-            cpos = {int(g): i for i, g in enumerate(cols_np)}
-            recs = []
-            for (rc, gr, gc, blk, (b0, b1), r_, mu, vv, lr) in parts:
-                recs.append(rc)
-                ir, ic = [rpos[int(g)] for g in gr], [cpos[int(g)] for g in gc]
-                if len(ir) and len(ic):
-                    Ls[np.ix_(ir, ic)] = blk
-                if b1 > b0:
-                    zpm[b0:b1], zpv[b0:b1] = mu, vv
-                    if len(ir):
-                        lam_s[np.ix_(ir, np.arange(b0, b1))] = lr
-            np.savez(a.dist_out, info=info, nll=nll, logdet=logdet, L_sample=Ls, mean=zpm, var=zpv, lam_sample=lam_s,
-                     grad_value=np.nan if val is None else val, grad=np.zeros(0) if grad is None else grad,
-                     seconds=json.dumps(sec), phases=json.dumps(phases), ranks=json.dumps(recs))
-            for rc in recs:
-                who = f"pid {rc['pid']}" + (f" thread {rc['thread']}" if rc.get("thread") else "")
-                log(f"dist: rank {rc['rank']} {who} coords {tuple(rc['coords'])} local matrix {tuple(rc['local_matrix'])} "
-                    f"received {rc['GB_received']:.1f} GB; peak allocated {rc['peak_GB_allocated']:.1f} GB"
-                    f"{' (all thread-ranks of the process together)' if rc.get('thread') else ''} on {rc['device']}")
+            log("dist: " + msg)
+
+    ch = Cholesky(grid, n, nb=NB, ops=HipLocalOps(), transport=a.transport, profile=True)
+    if a.device_comm:
+        ch.backend = "nccl"        # the device-resident communication branches (what runs under RCCL), moved by gloo
+    t0 = tick()
+    ch.build_local_gram(cov, xd, theta, NOISE)
+    t1 = tick()
+    sec["gram"] = t1 - t0
+    say(f"local Gram {tuple(ch.A.shape)} = {ch.A.numel() * 8 / 1e9:.1f} GB per rank: {sec['gram']:.2f} s")
+    info = ch.factor()
+    phases = ch.phase_times()
+    t2 = tick()
+    sec["factor"] = t2 - t1
+    say(f"factor: info {info}, {sec['factor']:.1f} s = {n ** 3 / 3 / sec['factor'] / 1e12:.1f} TFLOP/s aggregate over the shared GPU (messages through host memory); "
+        f"rank 0 phases (ms, summed HIP-event spans): { {k: round(v) for k, v in phases.items()} }")
+    nll = ch.negative_log_likelihood(z)
+    logdet = ch.logdet()
+    t3 = tick()
+    sec["nll"] = t3 - t2
+    say(f"nll {nll!r} logdet {logdet!r}: {sec['nll']:.1f} s")
+    # ---- sampled entries of the factor
+    rows_np, cols_np = samples(n, m)
+    ri, ci = ch.global_row_index(), ch.global_col_index()
+    rsel, csel = np.nonzero(np.isin(ri, rows_np))[0], np.nonzero(np.isin(ci, cols_np))[0]
+    Lloc = gnp.to_np(ch.A[torch.as_tensor(rsel, device=ch.A.device)][:, torch.as_tensor(csel, device=ch.A.device)]) if len(rsel) and len(csel) else np.zeros((0, 0))
+    # ---- prediction with weights
+    mean, var, (j0, j1), lam = ch.predict(cov, xd, z, xt, theta, return_lambdas=True)
+    lam_rows = gnp.to_np(lam[torch.as_tensor(rsel, device=lam.device)]) if len(rsel) and j1 > j0 else np.zeros((len(rsel), j1 - j0))
+    del lam
+    t4 = tick()
+    sec["predict_with_weights"] = t4 - t3
+    say(f"prediction at {m} points + weights (forward + backward many-RHS solves): {sec['predict_with_weights']:.1f} s")
+    received = ch.bytes_received
+    local_shape = tuple(ch.A.shape)
+    del ch
+    torch.cuda.empty_cache()
+    # ---- value + gradient at grad_n
+    val = grad = None
+    if a.grad_n:
+        gn = a.grad_n
+        th2 = np.concatenate(([theta[0], math.log(NOISE)], theta[1:]))
+        chg = Cholesky(grid, gn, nb=NB, ops=HipLocalOps(), transport=a.transport)
+        if a.device_comm:
+            chg.backend = "nccl"
+        chg.build_local_gram(cov, gnp.asarray(x[:gn]), theta, NOISE)
+        ginfo = chg.factor()
+        t5 = tick()
+        val, grad = chg.value_and_grad(x[:gn], z[:gn], th2, 2, noise=True)
+        t6 = tick()
+        sec["grad_factor"], sec["value_and_grad"] = t5 - t4, t6 - t5
+        received += chg.bytes_received
+        say(f"n={gn}: factor (info {ginfo}) {sec['grad_factor']:.1f} s, ML value + gradient {sec['value_and_grad']:.1f} s")
+        del chg
+    import threading
+
+    rec = {"rank": rank, "pid": os.getpid(), "thread": threading.get_ident() if a.threads else None, "coords": (grid.r, grid.c), "local_matrix": local_shape, "GB_received": received / 1e9,
+           "device": getattr(a, "device_name", None) or torch.cuda.get_device_name(torch.cuda.current_device()),
+           "peak_GB_allocated": torch.cuda.max_memory_allocated(torch.cuda.current_device()) / 1e9}
+    parts = exchange((rec, ri[rsel], ci[csel], Lloc, (j0, j1), grid.r, mean, var, lam_rows))
+    if rank == 0:
+        Ls = np.full((len(rows_np), len(cols_np)), np.nan)
+        zpm, zpv = np.full(m, np.nan), np.full(m, np.nan)
+        lam_s = np.full((len(rows_np), m), np.nan)
+        rpos = {int(g): i for i, g in enumerate(rows_np)}
+        cpos = {int(g): i for i, g in enumerate(cols_np)}
+        recs = []
+        for (rc, gr, gc, blk, (b0, b1), r_, mu, vv, lr) in parts:
+            recs.append(rc)
+            ir, ic = [rpos[int(g)] for g in gr], [cpos[int(g)] for g in gc]
+            if len(ir) and len(ic):
+                Ls[np.ix_(ir, ic)] = blk
+            if b1 > b0:
+                zpm[b0:b1], zpv[b0:b1] = mu, vv
+                if len(ir):
+                    lam_s[np.ix_(ir, np.arange(b0, b1))] = lr
+        np.savez(a.dist_out, info=info, nll=nll, logdet=logdet, L_sample=Ls, mean=zpm, var=zpv, lam_sample=lam_s,
+                 grad_value=np.nan if val is None else val, grad=np.zeros(0) if grad is None else grad,
+                 seconds=json.dumps(sec), phases=json.dumps(phases), ranks=json.dumps(recs))
+        for rc in recs:
+            who = f"pid {rc['pid']}" + (f" thread {rc['thread']}" if rc.get("thread") else "")
+            log(f"dist: rank {rc['rank']} {who} coords {tuple(rc['coords'])} local matrix {tuple(rc['local_matrix'])} "
+                f"received {rc['GB_received']:.1f} GB; peak allocated {rc['peak_GB_allocated']:.1f} GB"
+                f"{' (all thread-ranks of the process together)' if rc.get('thread') else ''} on {rc['device']}")
 
 
 def run_dist_threads(a):
