@@ -29,10 +29,12 @@ def _run(args, limit):
 
 
 def test_config5_schedule_with_values_at_n32768_on_the_2x4_grid_of_thread_ranks(tmp_path):
-    """the grid of BASELINE config 5 itself: eight ranks as THREADS of one process (torch.testing's in-process process group; every
-    rank its own HipLocalOps, streams and buffers on the shared GPU) -- the process guard denies eight processes.  Pc = 4 also takes
-    the gradient's ring through all three of its branches (same column set, full pair, half-way pair)."""
-    _run(["--threads", "--grid", "2x4", "--size-n", "32768", "--grad-n", "16384", "--m", "2048", "--limit", "300", "--out", str(tmp_path / "s.npz"),
+    """the grid of BASELINE config 5 itself: eight ranks as THREADS of one process (tools/thread_ranks.py; every rank its own
+    HipLocalOps, streams and buffers on the shared GPU) -- the process guard denies eight processes -- on the DEVICE-RESIDENT branch
+    of the product code (what runs under RCCL), with messages ordered by stream events only, as RCCL orders them: no host
+    synchronisation hides a missing dependency between the schedule's three streams.  Pc = 4 also takes the gradient's ring through
+    all three of its branches (same column set, full pair, half-way pair)."""
+    _run(["--threads", "--device-comm", "--grid", "2x4", "--size-n", "32768", "--grad-n", "16384", "--m", "2048", "--limit", "300", "--out", str(tmp_path / "s.npz"),
           "--dist-out", str(tmp_path / "d.npz")], 700)
 
 

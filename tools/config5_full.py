@@ -12,9 +12,10 @@ Two sides, run one after the other (each side alone fits the 288 GB of one MI355
            gradient at --grad-n; compared with the .npz of ``single``.
 
 The pool's process guard allows at most SIX processes on the card, so with one PROCESS per rank the grid is 2 x 3 (six ranks,
-22.9 GB of local matrix each).  ``--threads`` runs the ranks as THREADS of one process instead (torch's in-process "threaded"
-process group of torch.testing: collectives are host copies between the threads; every rank has its own HipLocalOps, streams and
-buffers on the shared GPU) -- that is how the 2 x 4 grid of BASELINE config 5 itself runs here: eight ranks, 17.2 GB each.
+22.9 GB of local matrix each).  ``--threads`` runs the ranks as THREADS of one process instead (tools/thread_ranks.py: every rank has
+its own HipLocalOps, streams and buffers on the shared GPU) -- that is how the 2 x 4 grid of BASELINE config 5 itself runs here:
+eight ranks, 17.2 GB each -- with host-staged messages (the branch of the product code that runs over gloo) or, with
+``--device-comm``, with device-resident messages on an in-process fabric that orders them by stream events only, as RCCL does.
 The gradient's working set (factor + T + the neighbour's T + one block of T^T T per rank) is 3.4 x the local matrix: at
 n = 131072 that is 500 GB over the ranks -- it needs the eight GPUs -- so the value + gradient is compared at --grad-n.
 
@@ -23,6 +24,7 @@ gpmp/core/likelihood.py:18-52 (the zero-mean NLL); gpmp/core/kriging.py:35-67 (m
 
     python tools/config5_full.py all                                   # both sides + comparison ("CONFIG5 FULL OK"), 2 x 3 processes over gloo
     python tools/config5_full.py all --threads --grid 2x4              # the same on the 2 x 4 grid, eight thread-ranks in one process
+    python tools/config5_full.py all --threads --device-comm --grid 2x4      # ... device-resident messages, stream-ordered (RCCL's semantics)
     python tools/config5_full.py all --size-n 32768 --grad-n 16384 --m 2048     # the same at a size for the default GPU suite
 """
 import argparse
@@ -178,42 +180,6 @@ def single(a):
 # ------------------------------------------------------------------------------------------------------------------
 # distributed side
 # ------------------------------------------------------------------------------------------------------------------
-def _thread_rank_class():
-    """BlockCyclicCholesky for ranks that are threads of one process (torch.testing's "threaded" process group has broadcast,
-    all-reduce and all-gather, no reduce and no point-to-point): a reduce is an all-reduce whose result the destination keeps,
-    the gradient's ring shift a round of broadcasts inside the process row of which every rank keeps the one from its source."""
-    import torch
-    import torch.distributed as dist
-
-    from gpmp_amd.dist import BlockCyclicCholesky
-
-    class ThreadRankCholesky(BlockCyclicCholesky):
-        def _reduce(self, t, dst_rank, group, what):
-            self._log(group, f"reduce:{what}", dst_rank, t.numel())
-            ct = t.detach().to("cpu").contiguous()
-            dist.all_reduce(ct, op=dist.ReduceOp.SUM, group=group)
-            if self.grid.rank == dst_rank:
-                t.copy_(ct)
-            return t
-
-        def _ring_shift(self, t, shift):
-            g = self.grid
-            src_c = (g.c + shift) % g.pc
-            self._log(g.row_group, f"ring_shift{shift}", -1, t.shape[0])
-            mine = t.detach().to("cpu").contiguous()
-            keep = None
-            for cc in range(g.pc):
-                w = sum(self.bs(J) for J in g.local_col_blocks(self.nblocks, cc))
-                buf = mine if cc == g.c else torch.empty((t.shape[0], w), dtype=t.dtype)
-                dist.broadcast(buf, src=g.rank_of(g.r, cc), group=g.row_group)
-                if cc == src_c:
-                    keep = buf
-                    self.bytes_received += buf.numel() * 8
-            return keep.to(t.device)
-
-    return ThreadRankCholesky
-
-
 def dist_worker(rank, world, port, a):
     import torch.distributed as dist
 
@@ -272,7 +238,7 @@ def dist_body(rank, world, a, Cholesky, exchange):
     phases = ch.phase_times()
     t2 = tick()
     sec["factor"] = t2 - t1
-    say(f"factor: info {info}, {sec['factor']:.1f} s = {n ** 3 / 3 / sec['factor'] / 1e12:.1f} TFLOP/s aggregate over the shared GPU (messages through host memory); "
+    say(f"factor: info {info}, {sec['factor']:.1f} s = {n ** 3 / 3 / sec['factor'] / 1e12:.1f} TFLOP/s aggregate over the shared GPU {' (device-resident messages, stream-ordered)' if getattr(a, 'stream_ordered', False) else ' (messages through host memory)'}; "
         f"rank 0 phases (ms, summed HIP-event spans): { {k: round(v) for k, v in phases.items()} }")
     nll = ch.negative_log_likelihood(z)
     logdet = ch.logdet()
@@ -345,61 +311,36 @@ def dist_body(rank, world, a, Cholesky, exchange):
 
 
 def run_dist_threads(a):
-    """The distributed side with the ranks as THREADS of this process (see the module docstring): the grid of eight ranks the
-    process guard denies to processes.  Bounded like the process form: a watchdog ends the process if the ranks are still running
-    after --limit seconds."""
-    import threading
-    import traceback
-
+    """The distributed side with the ranks as THREADS of this process (tools/thread_ranks.py): the grid of eight ranks the process
+    guard denies to processes.  ``--device-comm``: the device-resident branch of the product code on the stream-ordered in-process
+    fabric (RCCL's stream semantics, no host synchronisation); otherwise the host-staged branch on host copies between the threads."""
     import torch
-    import torch.distributed as dist
-    from torch.testing._internal.distributed import multi_threaded_pg as mtpg
+
+    import gpmp_amd.num  # noqa: F401 -- the library is loaded and its signatures declared ONCE, before the rank threads start
+    from gpmp_amd import _lib
+    from tools import thread_ranks
 
     pr, pc = (int(v) for v in a.grid.split("x"))
     world = pr * pc
-    if a.transport != "bcast" or a.device_comm:
-        raise SystemExit("--threads: the in-process group has no point-to-point operations and moves host tensors: bcast transport only")
-    import gpmp_amd.num  # noqa: F401 -- the library is loaded and its signatures declared ONCE, before the rank threads start
-    from gpmp_amd import _lib
-
+    if a.transport != "bcast" and not a.device_comm:
+        raise SystemExit("--threads without --device-comm: the in-process group has no point-to-point operation: bcast transport only")
     _lib.load()
     torch.cuda.init()
     a.device_name = torch.cuda.get_device_name(0)           # (asked here: torch's device-property cache is filled by the thread that initialised it)
-    mtpg._install_threaded_pg()
-    torch._C._distributed_c10d._set_thread_isolation_mode(True)      # (group registry per thread, as torch's MultiThreadedTestCase does)
-    store = dist.HashStore()
-    Cholesky = _thread_rank_class()
-    board, errors = [None] * world, []
+    board = [None] * world
 
-    def rank_main(rank):
-        try:
-            torch.cuda.set_device(0)
-            dist.init_process_group(backend="threaded", rank=rank, world_size=world, store=store)
+    def body(rank, world_, fabric, classes):
+        Cholesky = classes[1] if a.device_comm else classes[0]
+        a_rank = argparse.Namespace(**vars(a))
+        a_rank.stream_ordered = bool(a.device_comm)
+        a_rank.device_comm = False                         # (the class carries the branch; dist_body's own switch is for the gloo form)
 
-            def exchange(obj):
-                board[rank] = obj
-                dist.barrier()
-                return list(board)
+        def exchange(obj):
+            return fabric.allgather(rank, obj)
 
-            dist_body(rank, world, a, Cholesky, exchange)
-            dist.barrier()
-        except BaseException:  # noqa: BLE001 -- a failing rank must release the others from their collectives
-            errors.append(f"rank {rank}:\n{traceback.format_exc()}")
-            mtpg.ProcessLocalGroup.exception_handle(None)
+        dist_body(rank, world_, a_rank, Cholesky, exchange)
 
-    def watchdog():
-        log(f"dist: thread-ranks still running after {a.limit:.0f} s: ending the process")
-        os._exit(3)
-
-    timer = threading.Timer(a.limit, watchdog)
-    timer.daemon = True
-    timer.start()
-    threads = [threading.Thread(target=rank_main, args=(r,), name=f"rank{r}") for r in range(world)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    timer.cancel()
+    errors = thread_ranks.run(world, body, limit_s=a.limit)
     if errors:
         raise SystemExit("distributed side failed:\n" + errors[0])
 
@@ -456,10 +397,11 @@ def compare(a):
         tol.update(grad_value_rel=1e-11 * cs, grad_rel=1e-7)
     ok = errs["info"] == 0 and bool(np.isfinite(d["mean"]).all() and np.isfinite(d["lam_sample"]).all()) and all(errs[k] <= t for k, t in tol.items())
     log("single-GPU seconds: " + str(s["seconds"]))
-    log(f"distributed seconds (max-synchronised phases, ranks sharing ONE GPU, {'thread-ranks: collectives = host copies between threads' if a.threads else 'over gloo'}): " + str(d["seconds"]))
+    log(f"distributed seconds (max-synchronised phases, ranks sharing ONE GPU, {'thread-ranks' if a.threads else 'over gloo'}): " + str(d["seconds"]))
     log("deviations (block-cyclic vs single GPU): " + json.dumps(errs))
     log("tolerances: " + json.dumps(tol))
-    how = "thread-ranks of one process (in-process group)" if a.threads else "one process per rank over gloo"
+    how = ("thread-ranks of one process, " + ("device-resident messages ordered by stream events only (RCCL's semantics, in process)" if a.device_comm
+                                              else "host-staged messages copied between the threads")) if a.threads else "one process per rank over gloo"
     print(f"CONFIG5 FULL {'OK' if ok else 'FAILED'}: n={a.n} grid {a.grid} block {NB} transport {a.transport}"
           f"{' device-resident comm' if a.device_comm else ''}, {how}; gradient at n={a.grad_n}", flush=True)
     return 0 if ok else 1
