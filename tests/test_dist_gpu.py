@@ -588,3 +588,81 @@ def test_every_distributed_entry_point_under_rccl(pr, pc, transport):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gloo_cuda_comm_probe.py"), str(pr), str(pc), transport, "nccl"],
                        env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0 and "DEVICE-COMM PROBE OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def _stream_ordered_entry_points(pr, pc, delay_cycles, n=2100, m=333, nb=256):
+    """every distributed entry point of the DEVICE-RESIDENT branch on the stream-ordered in-process fabric (tools/thread_ranks.py),
+    thread-ranks sharing the GPU; -> dict of results assembled from the ranks"""
+    import gpmp_amd.num as gnp  # noqa: F401 -- library loaded before the rank threads start
+    from tools import thread_ranks
+
+    d = 4
+    x, z = make_xz(n, d, 11)
+    xt, _ = make_xz(m, d, 12)
+    th = theta_aniso(d, scale=0.5)
+    P = np.hstack((np.ones((n, 1)), x[:, :1]))
+    Pt = np.hstack((np.ones((m, 1)), xt[:, :1]))
+    out = {}
+
+    def body(rank, world, fabric, classes):
+        from gpmp_amd.dist import HipLocalOps, ProcessGrid
+        from gpmp_amd.kernel import MaternCovariance
+
+        cov = MaternCovariance(2)
+        Ch = classes[1]
+        Ch.max_delay_cycles = delay_cycles
+        grid = ProcessGrid(pr, pc)
+        ch = Ch(grid, n, nb=nb, ops=HipLocalOps())
+        ch.build_local_gram(cov, x, th, 10.0 * math.exp(th[0]) * gnp.eps)
+        info = ch.factor()
+        nll = ch.negative_log_likelihood(z)
+        reml = ch.negative_log_restricted_likelihood(z, P)
+        mean, var, (j0, j1), lam = ch.predict(cov, x, z, xt, th, P=P, Pt=Pt, return_lambdas=True)
+        zloo, s2, eloo, idx = ch.loo(z, P)
+        val, grad = ch.value_and_grad(x, z, th, 2, P=P)
+        torch.cuda.synchronize()
+        out[rank] = (grid.r, j0, j1, mean, var, ch.global_row_index(), lam.cpu().numpy(), idx, zloo, info, nll, reml, val, grad)
+
+    errors = thread_ranks.run(pr * pc, body, limit_s=300.0)
+    assert not errors, errors[0]
+    zpm, zpv, L, zl = np.full(m, np.nan), np.full(m, np.nan), np.full((n, m), np.nan), np.full(n, np.nan)
+    for (r, a, b, mu, v, rows, blk, ix, zz, *_rest) in out.values():
+        zpm[a:b], zpv[a:b] = mu, v
+        if len(rows) and b > a:
+            L[np.ix_(rows, np.arange(a, b))] = blk
+        zl[ix] = zz
+    o = out[0]
+    return dict(info=o[9], nll=o[10], reml=o[11], val=o[12], grad=o[13], zpm=zpm, zpv=zpv, lam=L, zloo=zl,
+                same_scalars=all(v[10] == o[10] and v[11] == o[11] and np.array_equal(v[13], o[13]) for v in out.values()))
+
+
+@pytest.mark.parametrize("pr,pc,delay_cycles", [(2, 4, 0), (2, 4, 3_000_000), (3, 2, 1_000_000)])
+def test_every_entry_point_on_the_stream_ordered_fabric(pr, pc, delay_cycles):
+    """(round 5) The device-resident branch of gpmp_amd/dist (``backend == "nccl"``: what runs under RCCL) with RCCL's STREAM
+    semantics and without RCCL: thread-ranks sharing the GPU, every collective enqueued on the member's current stream and ordered by
+    HIP events only (tools/thread_ranks.py) -- no host synchronisation around a message, unlike gloo.  A missing dependency between
+    the schedule's three streams (a panel buffer reused too early, a consumer that does not wait for its message) shows up as wrong
+    values; ``delay_cycles`` > 0 holds every incoming message back by a pseudo-random time of up to ~1 ms on the receiving stream to
+    widen any such window.  2 x 4 is the grid of BASELINE config 5; 3 x 2 has Pr > Pc and an odd process-row count.  Factorisation,
+    NLL, REML, universal kriging with weights, leave-one-out, REML value + gradient against the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    n, m, d = 2100, 333, 4
+    g = _stream_ordered_entry_points(pr, pc, delay_cycles, n=n, m=m)
+    x, z = make_xz(n, d, 11)
+    xt, _ = make_xz(m, d, 12)
+    th = theta_aniso(d, scale=0.5)
+    mean_fn = lambda a, p: np.hstack((np.ones((len(a), 1)), a[:, :1]))  # noqa: E731
+    kern = lambda a, b, t, pairwise=False: orc.maternp_covariance(a, b, 2, t, pairwise)  # noqa: E731
+    om = orc.OracleModel(mean_fn, kern, None, th, "linear_predictor")
+    oz = orc.OracleModel(None, kern, None, th, "zero")
+    rm, rv, rl = orc.predict(om, x, z, xt, return_lambdas=True)
+    rz, _, _ = orc.loo(om, x, z)
+    rnll = float(orc.negative_log_likelihood_zero_mean(oz, th, x, z))
+    rreml, rgrad = orc.reml_value_and_grad(x, z, mean_fn(x, None), 2, th)
+    assert g["info"] == 0 and g["same_scalars"]
+    assert abs(g["nll"] - rnll) < 1e-9 * abs(rnll) and abs(g["reml"] - rreml) < 1e-9 * abs(rreml) and abs(g["val"] - g["reml"]) < 1e-9 * abs(rreml)
+    assert np.max(np.abs(g["zpm"] - rm)) < 1e-7 and np.max(np.abs(g["zpv"] - rv)) < 1e-7
+    assert np.max(np.abs(g["lam"] - rl)) < 1e-6 * np.max(np.abs(rl))
+    assert np.max(np.abs(g["zloo"] - rz)) < 1e-6
+    assert np.max(np.abs(g["grad"] - rgrad)) < 1e-7 * np.linalg.norm(rgrad)

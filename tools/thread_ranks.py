@@ -133,9 +133,19 @@ def make_classes(fabric):
     class StreamOrderedCholesky(BlockCyclicCholesky):
         """device-resident messages, ordered by events on the members' current streams (module docstring)"""
 
+        # adversarial latency (tests): every incoming message is held back on the receiving stream by a pseudo-random number of
+        # GPU clock cycles up to this bound before it is copied -- a consumer that does not wait for the message's event reads stale data
+        max_delay_cycles = 0
+
         def __init__(self, *a, **kw):
             super().__init__(*a, **kw)
             self.backend = "nccl"            # the branch of the product code that keeps everything on the device
+            self._lcg = 12345 + 7919 * self.grid.rank
+
+        def _hold_back(self, t):
+            if self.max_delay_cycles > 0 and t.is_cuda:
+                self._lcg = (1103515245 * self._lcg + 12345) % (1 << 31)
+                torch.cuda._sleep(int(self._lcg % self.max_delay_cycles))
 
         # -- one collective = two meetings: (a) tensors + "ready" events, (b) "done" events
         def _meet(self, group, payload_fn):
@@ -158,6 +168,7 @@ def make_classes(fabric):
             me, tag, members, seq, cur, got = self._meet(group, lambda: t)
             if me != src_rank:
                 cur.wait_event(got[src_rank][1])
+                self._hold_back(t)
                 t.copy_(got[src_rank][0])
                 self.bytes_received += t.numel() * 8
             # the root goes on (and may overwrite its buffer) only when every receiver has copied
@@ -173,6 +184,7 @@ def make_classes(fabric):
             if dst is None or me == dst:
                 for r in members:
                     cur.wait_event(got[r][1])
+                self._hold_back(t)
                 parts = torch.stack([got[r][0] for r in members])
                 tmp = parts.sum(dim=0) if op == dist.ReduceOp.SUM else (parts.amin(dim=0) if op == dist.ReduceOp.MIN else parts.amax(dim=0))
             # every member's input has been read by the time the writers' "done" events have fired
@@ -197,6 +209,7 @@ def make_classes(fabric):
             me, tag, members, seq, cur, got = self._meet(g.row_group, lambda: t)
             cur.wait_event(got[src][1])
             buf = torch.empty_like(got[src][0])
+            self._hold_back(t)
             buf.copy_(got[src][0])
             self.bytes_received += buf.numel() * 8
             self._finish(tag, seq, me, members, cur, [dst])        # my tensor has been read by the rank I send to
@@ -226,6 +239,7 @@ def run(world, body, limit_s=900.0):
             dist.init_process_group(backend="threaded", rank=rank, world_size=world, store=store)
             body(rank, world, fabric, classes)
             fabric.barrier(rank)
+            dist.destroy_process_group()
         except BaseException:  # noqa: BLE001 -- a failing rank must release the others from their meetings
             errors.append(f"rank {rank}:\n{traceback.format_exc()}")
             fabric.fail(f"rank {rank} raised")
@@ -239,9 +253,13 @@ def run(world, body, limit_s=900.0):
     timer.daemon = True
     timer.start()
     threads = [threading.Thread(target=rank_main, args=(r,), name=f"rank{r}") for r in range(world)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    timer.cancel()
+    try:
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        timer.cancel()
+        torch._C._distributed_c10d._set_thread_isolation_mode(False)
+        mtpg._uninstall_threaded_pg()
     return errors
