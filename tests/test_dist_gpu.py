@@ -666,3 +666,18 @@ def test_every_entry_point_on_the_stream_ordered_fabric(pr, pc, delay_cycles):
     assert np.max(np.abs(g["lam"] - rl)) < 1e-6 * np.max(np.abs(rl))
     assert np.max(np.abs(g["zloo"] - rz)) < 1e-6
     assert np.max(np.abs(g["grad"] - rgrad)) < 1e-7 * np.linalg.norm(rgrad)
+
+
+def test_stream_ordered_fabric_detects_a_missing_stream_dependency():
+    """(round 5) mutation test of the evidence itself (tools/stream_order_mutation_probe.py): with the waits of the bulk stream, or of
+    the side stream, removed from the schedule, the stream-ordered fabric must give a WRONG factorisation on the 2 x 4 grid (and the
+    intact schedule the right one) -- the same mutations pass unnoticed on the host-staged fabric, i.e. over gloo"""
+    import subprocess
+    import sys
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_order_mutation_probe.py")], env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0 and "MUTATION PROBE OK" in r.stdout, (r.stdout[-2000:], r.stderr[-1500:])
