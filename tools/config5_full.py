@@ -159,8 +159,24 @@ def single(a):
     del lam, V, Kit
     sec["predict"] = sync() - t5
     log(f"single: prediction at {m} points with weights: {sec['predict']:.2f} s")
-    del F, L, K, w, alpha
+    # ---- REML with a constant mean on the same factor (gpmp/core/likelihood.py:92-129 through the Schur identity)
+    from gpmp_amd.core.linalg import MeanSpace
+
+    ms = MeanSpace(F, zd, gnp.ones((n, 1)))
+    out["reml"] = 0.5 * ((n - 1) * math.log(2 * math.pi) + ms.logdet_contrast() + ms.quad())
+    del F, L, K, w, alpha, ms
     torch.cuda.empty_cache()
+    # ---- universal kriging (constant mean) at the first points: the single-GPU Model itself (builds and factors K again)
+    t5u = sync()
+    mu_pts = min(m, a.m_uk)
+    const = lambda xx, prm: gnp.ones((xx.shape[0], 1))       # noqa: E731
+    uk = gp.Model(const, cov, None, th2, "linear_predictor")
+    out["uk_mean"], out["uk_var"] = uk.predict(x, z, xt[:mu_pts], zero_neg_variances=False)
+    del uk
+    torch.cuda.empty_cache()
+    sec["uk_predict_incl_second_factorisation"] = sync() - t5u
+    log(f"single: REML {out['reml']!r}; universal kriging at {mu_pts} points (Model.predict, second factorisation included): "
+        f"{sec['uk_predict_incl_second_factorisation']:.2f} s")
 
     # ---- ML value + gradient at the size the distributed gradient fits on the shared GPU
     if a.grad_n:
@@ -257,6 +273,13 @@ def dist_body(rank, world, a, Cholesky, exchange):
     t4 = tick()
     sec["predict_with_weights"] = t4 - t3
     say(f"prediction at {m} points + weights (forward + backward many-RHS solves): {sec['predict_with_weights']:.1f} s")
+    # ---- REML and universal kriging (constant mean) on the same distributed factor
+    mu_pts = min(m, a.m_uk)
+    reml = ch.negative_log_restricted_likelihood(z, np.ones((n, 1)))
+    uk_mean, uk_var, (u0, u1) = ch.predict(cov, xd, z, xt[:mu_pts], theta, P=np.ones((n, 1)), Pt=np.ones((mu_pts, 1)))
+    t4 = tick()
+    sec["reml_and_universal_kriging"] = t4 - t3 - sec["predict_with_weights"]
+    say(f"REML {reml!r}; universal kriging at {mu_pts} points: {sec['reml_and_universal_kriging']:.1f} s")
     received = ch.bytes_received
     local_shape = tuple(ch.A.shape)
     del ch
@@ -283,15 +306,18 @@ def dist_body(rank, world, a, Cholesky, exchange):
     rec = {"rank": rank, "pid": os.getpid(), "thread": threading.get_ident() if a.threads else None, "coords": (grid.r, grid.c), "local_matrix": local_shape, "GB_received": received / 1e9,
            "device": getattr(a, "device_name", None) or torch.cuda.get_device_name(torch.cuda.current_device()),
            "peak_GB_allocated": torch.cuda.max_memory_allocated(torch.cuda.current_device()) / 1e9}
-    parts = exchange((rec, ri[rsel], ci[csel], Lloc, (j0, j1), grid.r, mean, var, lam_rows))
+    parts = exchange((rec, ri[rsel], ci[csel], Lloc, (j0, j1), grid.r, mean, var, lam_rows, (u0, u1), uk_mean, uk_var))
     if rank == 0:
         Ls = np.full((len(rows_np), len(cols_np)), np.nan)
         zpm, zpv = np.full(m, np.nan), np.full(m, np.nan)
         lam_s = np.full((len(rows_np), m), np.nan)
+        ukm, ukv = np.full(mu_pts, np.nan), np.full(mu_pts, np.nan)
         rpos = {int(g): i for i, g in enumerate(rows_np)}
         cpos = {int(g): i for i, g in enumerate(cols_np)}
         recs = []
-        for (rc, gr, gc, blk, (b0, b1), r_, mu, vv, lr) in parts:
+        for (rc, gr, gc, blk, (b0, b1), r_, mu, vv, lr, (c0, c1), um, uv) in parts:
+            if c1 > c0:
+                ukm[c0:c1], ukv[c0:c1] = um, uv
             recs.append(rc)
             ir, ic = [rpos[int(g)] for g in gr], [cpos[int(g)] for g in gc]
             if len(ir) and len(ic):
@@ -300,7 +326,7 @@ def dist_body(rank, world, a, Cholesky, exchange):
                 zpm[b0:b1], zpv[b0:b1] = mu, vv
                 if len(ir):
                     lam_s[np.ix_(ir, np.arange(b0, b1))] = lr
-        np.savez(a.dist_out, info=info, nll=nll, logdet=logdet, L_sample=Ls, mean=zpm, var=zpv, lam_sample=lam_s,
+        np.savez(a.dist_out, info=info, nll=nll, logdet=logdet, reml=reml, uk_mean=ukm, uk_var=ukv, L_sample=Ls, mean=zpm, var=zpv, lam_sample=lam_s,
                  grad_value=np.nan if val is None else val, grad=np.zeros(0) if grad is None else grad,
                  seconds=json.dumps(sec), phases=json.dumps(phases), ranks=json.dumps(recs))
         for rc in recs:
@@ -387,9 +413,13 @@ def compare(a):
         "mean_abs": float(np.max(np.abs(d["mean"] - s["mean"]))),
         "var_abs": float(np.max(np.abs(d["var"] - s["var"]))),
         "lambda_rel": float(np.max(np.abs(d["lam_sample"] - s["lam_sample"])) / float(s["lam_max"])),
+        "reml_rel": abs(float(d["reml"]) - float(s["reml"])) / abs(float(s["reml"])),
+        "uk_mean_abs": float(np.max(np.abs(d["uk_mean"] - s["uk_mean"]))),
+        "uk_var_abs": float(np.max(np.abs(d["uk_var"] - s["uk_var"]))),
     }
     tol = {"single_residual_rel": 1e-12, "logdet_rel": 1e-12 * cs, "nll_rel": 1e-12 * cs, "L_entries_rel": 1e-10 * cs,
-           "mean_abs": 1e-10 * cs * zs, "var_abs": 1e-10 * cs, "lambda_rel": 1e-7}
+           "mean_abs": 1e-10 * cs * zs, "var_abs": 1e-10 * cs, "lambda_rel": 1e-7,
+           "reml_rel": 1e-12 * cs, "uk_mean_abs": 1e-10 * cs * zs, "uk_var_abs": 1e-10 * cs}
     if a.grad_n:
         g1, g0 = d["grad"], s["grad"]
         errs["grad_value_rel"] = abs(float(d["grad_value"]) - float(s["grad_value"])) / abs(float(s["grad_value"]))
@@ -413,6 +443,7 @@ def main():
     ap.add_argument("--size-n", dest="n", type=int, default=131072)
     ap.add_argument("--m", type=int, default=6144)
     ap.add_argument("--grad-n", type=int, default=73728)
+    ap.add_argument("--m-uk", type=int, default=1024, help="prediction points of the universal-kriging (constant mean) comparison")
     ap.add_argument("--grid", default="2x3")
     ap.add_argument("--transport", default="bcast")
     ap.add_argument("--device-comm", action="store_true")
