@@ -1,6 +1,8 @@
-"""GPU tests of the distributed layer with the real local arithmetic (HipLocalOps through the C ABI).
-Ranks share the single test GPU and talk over gloo (RCCL needs one GPU per rank); the schedule and the
-kernels are the ones the 8-GPU run uses."""
+"""GPU tests of the distributed layer with the real local arithmetic (HipLocalOps through the C ABI).  RCCL needs one GPU per
+rank and this pool has one-GPU boxes, so the ranks SHARE the test GPU: as processes over gloo (host-staged messages; at most five
+beside the test runner: the pool's process guard), as thread-ranks on the stream-ordered in-process fabric of tools/thread_ranks.py
+(device-resident messages ordered by stream events only: RCCL's stream semantics, the 2 x 4 grid of config 5), and -- one rank --
+through ProcessGroupNCCL itself.  The schedule and the kernels are the ones the 8-GPU run uses."""
 import math
 import os
 import socket
