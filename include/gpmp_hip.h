@@ -27,7 +27,11 @@
  *    both launch models work with one copy of the library: one process per GPU (what bench.py and gpmp_amd/dist do), or
  *    one process with one host thread per GPU, each thread with its device current.  Threads on different devices do not
  *    wait for each other; two threads on the same device are serialised while they enqueue a factorisation.  One calling
- *    thread at a time per stream.  gpmp_device_release() returns what the library holds for the current device.
+ *    thread at a time per stream.  gpmp_device_release() returns what the library holds for the current device (safe against
+ *    an enqueue section still running on another thread: the state is held by shared ownership).  Tested: one process per
+ *    GPU; SEVERAL host threads on ONE device (eight thread-ranks of the distributed tests share a GPU); the per-device table
+ *    under the host sanitizers (gpmp_debug_device_table_selftest).  NOT tested: more than one device ordinal driven from
+ *    one process -- the GPU pool this was developed on has one-GPU boxes.
  *  - covparam layout (gpmp/kernel/matern.py:78-79,88-89): theta = [log sigma^2, log(1/rho_1..d)];
  *    with `noise` != 0 the layout is [log sigma^2, log sigma_noise^2, log(1/rho_1..d)]
  *    (examples/gpmp_example07_nd_regression.py:95-131).
