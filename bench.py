@@ -376,7 +376,7 @@ def cpu_baseline_for_line(n, m, d, threads, m_sample):
     want_full = os.environ.get("GPMP_BENCH_CPU_FULL", "1" if (n, m, d) == (32768, 50000, 8) else "0") == "1"
     reason = None
     if want_full:
-        rec, reason = cpu_baseline_measured(n, m, d, float(os.environ.get("GPMP_BENCH_CPU_FULL_TIMEOUT", "420")))
+        rec, reason = cpu_baseline_measured(n, m, d, float(os.environ.get("GPMP_BENCH_CPU_FULL_TIMEOUT", "360")))
         if rec is not None:
             out = {"value": rec["points_per_s"], "unit": "points/s", "cores": rec["threads"], "kind": "port", "assembled": False,
                    "sample": f"ONE full-size predict + NLL step of the oracle (SciPy cdist + Matern ufuncs + LAPACK: the reference's NumPy-backend "
