@@ -550,13 +550,14 @@ def test_distributed_model_surface_hip(tmp_path, pr, pc, meantype):
     assert abs(got[-1] - rc) < 1e-11 * cs * abs(rc)
 
 
-@pytest.mark.parametrize("pr,pc,transport", [(2, 2, "bcast"), (1, 2, "p2p")])
+@pytest.mark.parametrize("pr,pc,transport", [(1, 2, "p2p")])
 def test_device_resident_communication_branches_over_gloo_cuda(pr, pc, transport):
     """(round 4) The branches that only run under RCCL -- comm tensors, scalars and the few-column solve kept on the DEVICE,
     collectives called with CUDA tensors from the three streams -- exercised without RCCL: gloo moves CUDA tensors too, so the
     ranks share the one GPU with ``backend`` forced to the RCCL code path (tools/gloo_cuda_comm_probe.py).  Factorisation, NLL,
-    REML, universal kriging with weights, leave-one-out and the REML gradient against the oracle.  RCCL's own stream / ordering
-    behaviour is not what this can check."""
+    REML, universal kriging with weights, leave-one-out and the REML gradient against the oracle.  Kept for the ``p2p`` transport
+    (grouped send / recv of CUDA tensors through torch.distributed); the ``bcast`` form of this branch is checked more strictly
+    since round 5 by test_every_entry_point_on_the_stream_ordered_fabric (no host synchronisation around a message)."""
     import subprocess
     import sys
 
