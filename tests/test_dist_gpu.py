@@ -639,14 +639,15 @@ def _stream_ordered_entry_points(pr, pc, delay_cycles, n=2100, m=333, nb=256):
                 same_scalars=all(v[10] == o[10] and v[11] == o[11] and np.array_equal(v[13], o[13]) for v in out.values()))
 
 
-@pytest.mark.parametrize("pr,pc,delay_cycles", [(2, 4, 0), (2, 4, 3_000_000), (3, 2, 1_000_000)])
+@pytest.mark.parametrize("pr,pc,delay_cycles", [(2, 4, 0), (2, 4, 3_000_000), (3, 2, 1_000_000), (4, 2, 1_000_000), (3, 3, 1_000_000), (1, 8, 1_000_000)])
 def test_every_entry_point_on_the_stream_ordered_fabric(pr, pc, delay_cycles):
     """(round 5) The device-resident branch of gpmp_amd/dist (``backend == "nccl"``: what runs under RCCL) with RCCL's STREAM
     semantics and without RCCL: thread-ranks sharing the GPU, every collective enqueued on the member's current stream and ordered by
     HIP events only (tools/thread_ranks.py) -- no host synchronisation around a message, unlike gloo.  A missing dependency between
     the schedule's three streams (a panel buffer reused too early, a consumer that does not wait for its message) shows up as wrong
     values; ``delay_cycles`` > 0 holds every incoming message back by a pseudo-random time of up to ~1 ms on the receiving stream to
-    widen any such window.  2 x 4 is the grid of BASELINE config 5; 3 x 2 has Pr > Pc and an odd process-row count.  Factorisation,
+    widen any such window.  2 x 4 is the grid of BASELINE config 5; 3 x 2, 4 x 2, 3 x 3 and 1 x 8 are grids no multi-process test can reach
+    on a one-GPU box (Pr > Pc, odd counts, a single process row of eight: the gradient ring with four shifts).  Factorisation,
     NLL, REML, universal kriging with weights, leave-one-out, REML value + gradient against the oracle."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
