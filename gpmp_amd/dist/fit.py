@@ -15,7 +15,7 @@ import numpy as np
 from .cholesky import BlockCyclicCholesky
 
 
-def distributed_criterion(grid, cov, x, z, P=None, nb=1024, ops=None, transport=None, p=None, noise=None):
+def distributed_criterion(grid, cov, x, z, P=None, nb=1024, ops=None, transport=None, p=None, noise=None, factor_class=None):
     """-> f(covparam) = (value, gradient) on the grid.  ``cov``: a covariance callable (``MaternCovariance``: p and the noise
     flag are read from it; any other callable needs ``p`` / ``noise``), x: (n, d) and z: (n,) replicated host arrays, P: the
     (n, q) mean design for REML or None for the zero-mean likelihood.  A failed factorisation gives (+inf, 0): the reference's
@@ -26,11 +26,12 @@ def distributed_criterion(grid, cov, x, z, P=None, nb=1024, ops=None, transport=
     p = int(getattr(cov, "p", p))
     noise = bool(getattr(cov, "noise", noise))
     eps = float(np.finfo(np.float64).eps)
+    Factor = BlockCyclicCholesky if factor_class is None else factor_class
 
     def f(covparam):
         th = np.asarray(covparam, dtype=np.float64)
         diag = math.exp(th[1]) if noise else 10.0 * math.exp(th[0]) * eps          # matern.py:90 / the noise variance
-        ch = BlockCyclicCholesky(grid, n, nb=nb, ops=ops, transport=transport)
+        ch = Factor(grid, n, nb=nb, ops=ops, transport=transport)
         ch.build_local_gram(cov, x, th, diag)
         if ch.factor() != 0:
             return math.inf, np.zeros_like(th)

@@ -23,7 +23,7 @@ from .fit import fit_covparam
 
 class DistributedModel:
     def __init__(self, grid, mean, covariance, meanparam=None, covparam=None, meantype="linear_predictor", nb=1024, ops=None,
-                 transport=None):
+                 transport=None, factor_class=None):
         if meantype not in ("zero", "parameterized", "linear_predictor"):
             raise ValueError("meantype must be one of 'zero', 'parameterized', 'linear_predictor'")       # core/utils.py:84-118
         if (meantype == "zero") != (mean is None):
@@ -31,6 +31,9 @@ class DistributedModel:
         self.grid, self.mean, self.covariance = grid, mean, covariance
         self.meanparam, self.covparam, self.meantype = meanparam, covparam, meantype
         self.nb, self.ops, self.transport = nb, ops, transport
+        # the factorisation class: BlockCyclicCholesky, or a subclass with another transport under the same schedule (tests:
+        # tools/thread_ranks.py runs the ranks as threads of one process)
+        self.factor_class = BlockCyclicCholesky if factor_class is None else factor_class
         self._cache = None                    # (key, factor): predict after a criterion at the same parameters re-uses nothing
                                               # implicitly -- the cache holds the factor of the LAST (xi, covparam) only
 
@@ -47,7 +50,7 @@ class DistributedModel:
         key = (xi.shape, hash(xi.tobytes()), th.tobytes())
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1]
-        ch = BlockCyclicCholesky(self.grid, xi.shape[0], nb=self.nb, ops=self.ops, transport=self.transport)
+        ch = self.factor_class(self.grid, xi.shape[0], nb=self.nb, ops=self.ops, transport=self.transport)
         ch.build_local_gram(self.covariance, xi, th, self._diag(th))
         ch.factor()
         self._cache = (key, ch)
@@ -148,6 +151,6 @@ class DistributedModel:
             P = self._design(xi)
         th0 = self.covparam if covparam0 is None else covparam0
         self.covparam, info = fit_covparam(self.grid, self.covariance, xi, zi, th0, P=P, bounds=bounds, options=options, nb=self.nb,
-                                           ops=self.ops, transport=self.transport)
+                                           ops=self.ops, transport=self.transport, factor_class=self.factor_class)
         self._cache = None
         return self.covparam, info

@@ -593,7 +593,7 @@ def test_every_distributed_entry_point_under_rccl(pr, pc, transport):
     assert r.returncode == 0 and "DEVICE-COMM PROBE OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
 
 
-def _stream_ordered_entry_points(pr, pc, delay_cycles, n=2100, m=333, nb=256):
+def _stream_ordered_entry_points(pr, pc, delay_cycles, n=2100, m=333, nb=256, with_model=False):
     """every distributed entry point of the DEVICE-RESIDENT branch on the stream-ordered in-process fabric (tools/thread_ranks.py),
     thread-ranks sharing the GPU; -> dict of results assembled from the ranks"""
     import gpmp_amd.num as gnp  # noqa: F401 -- library loaded before the rank threads start
@@ -625,7 +625,21 @@ def _stream_ordered_entry_points(pr, pc, delay_cycles, n=2100, m=333, nb=256):
         val, grad = ch.value_and_grad(x, z, th, 2, P=P)
         torch.cuda.synchronize()
         out[rank] = (grid.r, j0, j1, mean, var, ch.global_row_index(), lam.cpu().numpy(), idx, zloo, info, nll, reml, val, grad)
+        if with_model:
+            # the Model surface and a short parameter fit on the same fabric (every rank makes the same calls)
+            from gpmp_amd.dist import DistributedModel
 
+            mean_fn = lambda a, p: np.hstack((np.ones((len(a), 1)), np.asarray(a)[:, :1]))        # noqa: E731
+            model = DistributedModel(grid, mean_fn, cov, None, th, "linear_predictor", nb=nb, ops=HipLocalOps(), factor_class=Ch)
+            m_zpm, m_zpv, m_lam = model.predict(x, z, xt, return_lambdas=True)
+            m_zloo, _, _ = model.loo(x, z)
+            m_reml = model.negative_log_restricted_likelihood(th, x, z)
+            model.covparam = th + 0.3
+            th_fit, fit = model.select_parameters(x, z, options={"maxiter": 2})
+            torch.cuda.synchronize()
+            model_out[rank] = (m_zpm, m_zpv, m_lam, m_zloo, m_reml, fit["history"][0][1], fit["fun"], th_fit)
+
+    model_out = {}
     errors = thread_ranks.run(pr * pc, body, limit_s=300.0)
     assert not errors, errors[0]
     zpm, zpv, L, zl = np.full(m, np.nan), np.full(m, np.nan), np.full((n, m), np.nan), np.full(n, np.nan)
@@ -635,8 +649,13 @@ def _stream_ordered_entry_points(pr, pc, delay_cycles, n=2100, m=333, nb=256):
             L[np.ix_(rows, np.arange(a, b))] = blk
         zl[ix] = zz
     o = out[0]
-    return dict(info=o[9], nll=o[10], reml=o[11], val=o[12], grad=o[13], zpm=zpm, zpv=zpv, lam=L, zloo=zl,
-                same_scalars=all(v[10] == o[10] and v[11] == o[11] and np.array_equal(v[13], o[13]) for v in out.values()))
+    res = dict(info=o[9], nll=o[10], reml=o[11], val=o[12], grad=o[13], zpm=zpm, zpv=zpv, lam=L, zloo=zl,
+               same_scalars=all(v[10] == o[10] and v[11] == o[11] and np.array_equal(v[13], o[13]) for v in out.values()))
+    if with_model:
+        mo = model_out[0]
+        res["model"] = dict(zpm=mo[0], zpv=mo[1], lam=mo[2], zloo=mo[3], reml=mo[4], fit_first=mo[5], fit_last=mo[6],
+                            same_on_all_ranks=all(np.array_equal(v[0], mo[0]) and np.array_equal(v[7], mo[7]) for v in model_out.values()))
+    return res
 
 
 @pytest.mark.parametrize("pr,pc,delay_cycles", [(2, 4, 0), (2, 4, 3_000_000), (3, 2, 1_000_000), (4, 2, 1_000_000), (3, 3, 1_000_000), (1, 8, 1_000_000)])
@@ -652,7 +671,8 @@ def test_every_entry_point_on_the_stream_ordered_fabric(pr, pc, delay_cycles):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     n, m, d = 2100, 333, 4
-    g = _stream_ordered_entry_points(pr, pc, delay_cycles, n=n, m=m)
+    with_model = (pr, pc, delay_cycles) == (2, 4, 0)
+    g = _stream_ordered_entry_points(pr, pc, delay_cycles, n=n, m=m, with_model=with_model)
     x, z = make_xz(n, d, 11)
     xt, _ = make_xz(m, d, 12)
     th = theta_aniso(d, scale=0.5)
@@ -670,6 +690,14 @@ def test_every_entry_point_on_the_stream_ordered_fabric(pr, pc, delay_cycles):
     assert np.max(np.abs(g["lam"] - rl)) < 1e-6 * np.max(np.abs(rl))
     assert np.max(np.abs(g["zloo"] - rz)) < 1e-6
     assert np.max(np.abs(g["grad"] - rgrad)) < 1e-7 * np.linalg.norm(rgrad)
+    if with_model:
+        # DistributedModel.predict(return_lambdas=True) / loo / criterion / select_parameters on the same fabric
+        mo = g["model"]
+        assert mo["same_on_all_ranks"]
+        assert np.max(np.abs(mo["zpm"] - rm)) < 1e-7 and np.max(np.abs(mo["zpv"] - np.maximum(rv, 0.0))) < 1e-7
+        assert mo["lam"].shape == rl.shape and np.max(np.abs(mo["lam"] - rl)) < 1e-6 * np.max(np.abs(rl))
+        assert np.max(np.abs(mo["zloo"] - rz)) < 1e-6 and abs(mo["reml"] - rreml) < 1e-9 * abs(rreml)
+        assert mo["fit_last"] < mo["fit_first"]
 
 
 def test_stream_ordered_fabric_detects_a_missing_stream_dependency():
