@@ -593,7 +593,7 @@ def test_every_distributed_entry_point_under_rccl(pr, pc, transport):
     assert r.returncode == 0 and "DEVICE-COMM PROBE OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
 
 
-def _stream_ordered_entry_points(pr, pc, delay_cycles, n=2100, m=333, nb=256, with_model=False):
+def _stream_ordered_entry_points(pr, pc, delay_cycles, n=2100, m=333, nb=256, with_model=False, **factor_kw):
     """every distributed entry point of the DEVICE-RESIDENT branch on the stream-ordered in-process fabric (tools/thread_ranks.py),
     thread-ranks sharing the GPU; -> dict of results assembled from the ranks"""
     import gpmp_amd.num as gnp  # noqa: F401 -- library loaded before the rank threads start
@@ -615,7 +615,7 @@ def _stream_ordered_entry_points(pr, pc, delay_cycles, n=2100, m=333, nb=256, wi
         Ch = classes[1]
         Ch.max_delay_cycles = delay_cycles
         grid = ProcessGrid(pr, pc)
-        ch = Ch(grid, n, nb=nb, ops=HipLocalOps())
+        ch = Ch(grid, n, nb=nb, ops=HipLocalOps(), **factor_kw)
         ch.build_local_gram(cov, x, th, 10.0 * math.exp(th[0]) * gnp.eps)
         info = ch.factor()
         nll = ch.negative_log_likelihood(z)
@@ -658,21 +658,25 @@ def _stream_ordered_entry_points(pr, pc, delay_cycles, n=2100, m=333, nb=256, wi
     return res
 
 
-@pytest.mark.parametrize("pr,pc,delay_cycles", [(2, 4, 0), (2, 4, 3_000_000), (3, 2, 1_000_000), (4, 2, 1_000_000), (3, 3, 1_000_000), (1, 8, 1_000_000)])
-def test_every_entry_point_on_the_stream_ordered_fabric(pr, pc, delay_cycles):
+@pytest.mark.parametrize("pr,pc,delay_cycles,factor_kw", [(2, 4, 0, {}), (2, 4, 3_000_000, {}), (3, 2, 1_000_000, {}), (4, 2, 1_000_000, {}),
+                                                           (3, 3, 1_000_000, {}), (1, 8, 1_000_000, {}), (2, 4, 1_000_000, {"lookahead": False}),
+                                                           (2, 4, 1_000_000, {"reserve_cus": 16})],
+                         ids=lambda v: "-".join(f"{k}={w}" for k, w in v.items()) if isinstance(v, dict) else str(v))
+def test_every_entry_point_on_the_stream_ordered_fabric(pr, pc, delay_cycles, factor_kw):
     """(round 5) The device-resident branch of gpmp_amd/dist (``backend == "nccl"``: what runs under RCCL) with RCCL's STREAM
     semantics and without RCCL: thread-ranks sharing the GPU, every collective enqueued on the member's current stream and ordered by
     HIP events only (tools/thread_ranks.py) -- no host synchronisation around a message, unlike gloo.  A missing dependency between
     the schedule's three streams (a panel buffer reused too early, a consumer that does not wait for its message) shows up as wrong
     values; ``delay_cycles`` > 0 holds every incoming message back by a pseudo-random time of up to ~1 ms on the receiving stream to
     widen any such window.  2 x 4 is the grid of BASELINE config 5; 3 x 2, 4 x 2, 3 x 3 and 1 x 8 are grids no multi-process test can reach
-    on a one-GPU box (Pr > Pc, odd counts, a single process row of eight: the gradient ring with four shifts).  Factorisation,
+    on a one-GPU box (Pr > Pc, odd counts, a single process row of eight: the gradient ring with four shifts); the last two cases run
+    the factorisation without look-ahead and with its bulk updates on a CU-masked stream (``reserve_cus``).  Factorisation,
     NLL, REML, universal kriging with weights, leave-one-out, REML value + gradient against the oracle."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     n, m, d = 2100, 333, 4
     with_model = (pr, pc, delay_cycles) == (2, 4, 0)
-    g = _stream_ordered_entry_points(pr, pc, delay_cycles, n=n, m=m, with_model=with_model)
+    g = _stream_ordered_entry_points(pr, pc, delay_cycles, n=n, m=m, with_model=with_model, **factor_kw)
     x, z = make_xz(n, d, 11)
     xt, _ = make_xz(m, d, 12)
     th = theta_aniso(d, scale=0.5)

@@ -1,4 +1,4 @@
-"""Forward solve L^-1 K(xi, xt) alone (diagnostic; run under rocprofv3 --kernel-trace --stats)."""
+"""Forward solve L^-1 K(xi, xt) and backward solve L^-T (.) alone (diagnostic; run under rocprofv3 --kernel-trace --stats)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,4 +15,8 @@ F = gnp.cholesky_factor(cov.gram_lower(xi, theta), overwrite=True)
 for rep in range(2):
     B = cov(xi, xt, theta); torch.cuda.synchronize()
     t0 = time.perf_counter(); V = F.solve_lower(B, overwrite=True); torch.cuda.synchronize()
-    print("trsm ms", 1e3 * (time.perf_counter() - t0))
+    dt = time.perf_counter() - t0
+    print(f"forward  trsm ms {1e3 * dt:8.2f}  {float(n) * n * m / dt / 1e12:5.1f} TFLOP/s")
+    torch.cuda.synchronize(); t0 = time.perf_counter(); W = F.solve_lower(V, trans=True, overwrite=True); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"backward trsm ms {1e3 * dt:8.2f}  {float(n) * n * m / dt / 1e12:5.1f} TFLOP/s")
