@@ -24,6 +24,13 @@ At N > 1 the 2-D block-cyclic Cholesky of BASELINE.json configs[4] runs BY DEFAU
 group of N fresh processes under a time limit (GPMP_BENCH_DIST_TIMEOUT): a wedged or failing collective there costs
 `extra.dist_potrf` (status + the phase in flight are recorded) and the exit code (3 = timeout, 4 = error), not the
 headline line.
+CPU baseline (rank 0 at N = 1): at the headline shape ONE full-size step of the oracle is MEASURED in this run, in a child process
+(`--role cpu-full`) under a time limit; the bounded-sample model is the fall-back.  Environment: GPMP_BENCH_CPU_FULL (1 at the
+headline shape; 0: model only), GPMP_BENCH_CPU_FULL_TIMEOUT (360 s), GPMP_BENCH_CPU_MODEL (1: the model beside the measurement),
+GPMP_BENCH_LIVE_PMC (1: two rocprofv3 counter passes of one step each measure roofline.traffic in the run); N > 1: GPMP_BENCH_BACKEND
+(nccl; gloo = rehearsal on fewer GPUs than ranks), GPMP_BENCH_DIST (1), GPMP_BENCH_DIST_TIMEOUT (420 s), GPMP_BENCH_DIST_N,
+GPMP_BENCH_DIST_STRONG / GPMP_BENCH_DIST_MORE (1: the strong-scaling / predict + gradient parts of the distributed extra),
+GPMP_BENCH_STRONG_NM, GPMP_BENCH_HEADLINE_TIMEOUT (1500 s); tests: GPMP_BENCH_STUB_MODULE.
 """
 import argparse
 import json
