@@ -102,7 +102,6 @@ class REMLAnalytic:
 # ---- many small problems in one call ------------------------------------------------------------------
 BATCH_MAX_N = 4096      # GPMP_BATCH_MAX_N (include/gpmp_hip.h)
 BATCH_MAX_Q = 16        # GPMP_BATCH_MAX_Q
-BATCH_MIN_PROBLEMS_ABOVE_2048 = 8
 
 
 def batch_qualifies(model, use_mean=False):
@@ -127,7 +126,7 @@ def batch_piece_limit(nmax, d, q, want_grad, device=None):
     return max(1, budget // per_problem)
 
 
-def batch_values_and_gradients(model, covparams, batches, want_grad=True, use_mean=False, mean_offset=None, _piece=False):
+def batch_values_and_gradients(model, covparams, batches, want_grad=True, use_mean=False, mean_offset=None):
     """Criterion values (and gradients) of B small problems through ONE library call (gpmp_nll_grad_batch: every
     kernel batched over the problems) -- the throughput path behind ``gnp.BatchDifferentiableSelectionCriterion``
     (gpmp/num/torch_backend.py:607-718) and multi-parameter log_prob evaluations (gpmp/mcmc/param_posterior.py:229-278).
@@ -150,11 +149,6 @@ def batch_values_and_gradients(model, covparams, batches, want_grad=True, use_me
     nmax, B = max(ns), len(xs)
     if nmax > BATCH_MAX_N or any(int(x.shape[1]) != d for x in xs):
         return None
-    if nmax > 2048 and B < BATCH_MIN_PROBLEMS_ABOVE_2048 and not _piece:
-        # few large problems: one at a time through the look-ahead factorisation is faster than the batched one-stream route
-        # (n = 4096: B = 4: 6.7 ms per problem batched against 4.7 one at a time; B = 16: 2.8 against 4.6 --
-        #  profiles/r5/batch_small_problems_throughput_n2048_n4096.log)
-        return None
     Ps, q = None, 0
     if use_mean:
         Ps = [_mean_values(model, x, model.meanparam) for x in xs]
@@ -172,8 +166,7 @@ def batch_values_and_gradients(model, covparams, batches, want_grad=True, use_me
         vals, grads = [], []
         for b0 in range(0, B, b_piece):
             sl = slice(b0, min(B, b0 + b_piece))
-            out = batch_values_and_gradients(model, th_all if th_all.ndim == 1 else th_all[sl], batches[sl], want_grad, use_mean, mean_offset,
-                                             _piece=True)          # (a short last piece of a large call stays on the batched route)
+            out = batch_values_and_gradients(model, th_all if th_all.ndim == 1 else th_all[sl], batches[sl], want_grad, use_mean, mean_offset)
             if out is None:
                 return None
             vals.append(out[0])

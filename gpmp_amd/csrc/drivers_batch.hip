@@ -391,6 +391,29 @@ BatchLayout batch_layout(int nmax, int d, int q, int B, bool grad) {
   return l;
 }
 
+// op(L_b)^-1 Y_b for every problem.  Two routes: ONE launch of the workgroup-per-problem kernel (its time hardly depends on B up to
+// one workgroup per compute unit, but grows with nmax^2: 17 ms for both directions at nmax = 4096), or B launches of the
+// single-problem one-launch sweep (trsv_few: 0.1 - 0.2 ms each, all compute units on ONE problem).  Measured crossover
+// (profiles/r5/batch_n4096_*_kernel_stats.csv): the per-problem sweeps win while B < nmax / 100 -- the few-large-problems case.
+template <bool TRANS>
+int batch_solve(const double* K, long ldk, long sK, const double* dinv, long sD, double* Y, long ldy, long sY, int nmax, int r, int q,
+                int B, hipStream_t st) {
+  if (nmax >= 3 * NB && (long)B * 100 < nmax) {
+    for (int b = 0; b < B; ++b)
+      for (int c0 = 0; c0 < r; c0 += TRSV_FEW_MAX) {
+        const int mc = r - c0 < TRSV_FEW_MAX ? r - c0 : TRSV_FEW_MAX;
+        int rc = trsv_few(K + (long)b * sK, nmax, ldk, dinv + (long)b * sD, Y + (long)b * sY + c0, mc, ldy, TRANS ? 1 : 0, st);
+        if (rc) return rc;
+      }
+    return 0;
+  }
+  if (q <= 3) hipLaunchKernelGGL((batch_trsv_kernel<TRANS, 4>), dim3(B), dim3(256), 0, st, K, ldk, sK, dinv, sD, Y, ldy, sY, nmax, r);
+  else if (q <= 7) hipLaunchKernelGGL((batch_trsv_kernel<TRANS, 8>), dim3(B), dim3(256), 0, st, K, ldk, sK, dinv, sD, Y, ldy, sY, nmax, r);
+  else hipLaunchKernelGGL((batch_trsv_kernel<TRANS, BR>), dim3(B), dim3(256), 0, st, K, ldk, sK, dinv, sD, Y, ldy, sY, nmax, r);
+  GPMP_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 }  // namespace
 }  // namespace gpmp
 
@@ -479,41 +502,25 @@ extern "C" int gpmp_nll_grad_batch(const double* x, long stride_x, const double*
   hipLaunchKernelGGL(batch_pack_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, st, z, stride_z, P, ldp, stride_p, q, ns, nmax, Y,
                      l.ldq, (long)l.sY);
   GPMP_HIP_TRY(hipGetLastError());
-  // (three instantiations: 4 right-hand sides for q <= 3 -- every reference example --, 8 for q <= 7, 17 for q <= 16)
-  if (q <= 3) {
-    hipLaunchKernelGGL((batch_trsv_kernel<false, 4>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, Y, l.ldq, (long)l.sY,
-                       nmax, 1 + q);
-    GPMP_HIP_TRY(hipGetLastError());
+  // (three instantiations of the value kernel: q <= 3 -- every reference example --, q <= 7, q <= 16)
+  rc = batch_solve<false>(K, l.ld, (long)l.sK, dinv, (long)l.sD, Y, l.ldq, (long)l.sY, nmax, 1 + q, q, B, st);
+  if (rc) return rc;
+  if (q <= 3)
     hipLaunchKernelGGL(batch_value_kernel<3>, dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, Y, l.ldq, (long)l.sY, P, ldp, stride_p, q, ns,
                        nmax, ws + l.small, info_dev, values_dev);
-  } else if (q <= 7) {
-    hipLaunchKernelGGL((batch_trsv_kernel<false, 8>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, Y, l.ldq, (long)l.sY,
-                       nmax, 1 + q);
-    GPMP_HIP_TRY(hipGetLastError());
+  else if (q <= 7)
     hipLaunchKernelGGL(batch_value_kernel<7>, dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, Y, l.ldq, (long)l.sY, P, ldp, stride_p, q, ns,
                        nmax, ws + l.small, info_dev, values_dev);
-  } else {
-    hipLaunchKernelGGL((batch_trsv_kernel<false, BR>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, Y, l.ldq, (long)l.sY,
-                       nmax, 1 + q);
-    GPMP_HIP_TRY(hipGetLastError());
+  else
     hipLaunchKernelGGL(batch_value_wide_kernel, dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, Y, l.ldq, (long)l.sY, P, ldp, stride_p, q, ns,
                        nmax, ws + l.small, info_dev, values_dev);
-  }
   GPMP_HIP_TRY(hipGetLastError());
   if (!grad) return 0;
   // ---- gradient: X = L^-T W = K^-1 [z, P]; F, G; K^-1 = T^T T over the factor's slot; trace per problem
   double* X = ws + l.X;
   GPMP_HIP_TRY(hipMemcpyAsync(X, Y, sizeof(double) * l.sY * B, hipMemcpyDeviceToDevice, st));
-  if (q <= 3)
-    hipLaunchKernelGGL((batch_trsv_kernel<true, 4>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, X, l.ldq, (long)l.sY,
-                       nmax, 1 + q);
-  else if (q <= 7)
-    hipLaunchKernelGGL((batch_trsv_kernel<true, 8>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, X, l.ldq, (long)l.sY,
-                       nmax, 1 + q);
-  else
-    hipLaunchKernelGGL((batch_trsv_kernel<true, BR>), dim3(B), dim3(256), 0, st, K, l.ld, (long)l.sK, dinv, (long)l.sD, X, l.ldq, (long)l.sY,
-                       nmax, 1 + q);
-  GPMP_HIP_TRY(hipGetLastError());
+  rc = batch_solve<true>(K, l.ld, (long)l.sK, dinv, (long)l.sD, X, l.ldq, (long)l.sY, nmax, 1 + q, q, B, st);
+  if (rc) return rc;
   hipLaunchKernelGGL(batch_rows_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, st, X, l.ldq, (long)l.sY, ws + l.small, q, ns,
                      ws + l.F, ws + l.G, l.ldq, (long)l.sY);
   GPMP_HIP_TRY(hipGetLastError());

@@ -288,21 +288,23 @@ def test_batched_call_cut_into_pieces_by_workspace_budget(env, monkeypatch):
             assert np.allclose(v1, v0, rtol=1e-12, atol=0) and rel_err(g1, g0) < 1e-10 and np.allclose(v2, v0, rtol=1e-12, atol=0)
 
 
-def test_batched_route_above_2048_points_needs_eight_problems(env):
-    """(round 5) slots above 2048 points: a few large problems go one at a time through the look-ahead factorisation (faster:
-    profiles/r5/batch_small_problems_throughput_n2048_n4096.log), eight or more through ONE batched call -- same values either way"""
+def test_few_large_problems_take_the_per_problem_sweeps(env):
+    """(round 5) slots above 2048 points, few problems: inside the batched call the triangular solves run as the single-problem
+    one-launch sweep per problem (B < nmax / 100) instead of the workgroup-per-problem kernel -- n = 4096, B = 4: 26.6 -> 10.5 ms
+    (profiles/r5/batch_small_problems_throughput_r5_final.log).  Same values as one problem at a time, with and without a mean."""
     import gpmp_amd as gp
     import gpmp_amd.num as gnp
-    from gpmp_amd.core.gradients import MLZeroMeanAnalytic, batch_values_and_gradients
+    from gpmp_amd.core.gradients import MLZeroMeanAnalytic, REMLAnalytic, batch_values_and_gradients
 
     d, n = 3, 2100
     th = np.concatenate(([0.2, math.log(1e-4)], -np.log(0.3 + 0.2 * np.arange(d))))
-    model = gp.Model(None, gp.kernel.MaternCovariance(2, noise=True), None, th, "zero")
-    batches = [tuple(gnp.asarray(a) for a in _data(n - 7 * b, d, 300 + b)) for b in range(8)]
-    assert batch_values_and_gradients(model, th, batches[:3], True) is None
-    vals, grads = batch_values_and_gradients(model, th, batches, True)
-    ana = MLZeroMeanAnalytic(model)
-    for b in (0, 7):
-        v, st = ana.value_and_state(th, *batches[b])
-        g = ana.gradient_from_state(st)
-        assert abs(vals[b] - v) < 1e-8 * abs(v) and rel_err(grads[b], g) < 1e-6
+    cov = gp.kernel.MaternCovariance(2, noise=True)
+    batches = [tuple(gnp.asarray(a) for a in _data(n - 7 * b, d, 300 + b)) for b in range(3)]
+    lin = lambda x, prm: gnp.hstack((gnp.ones((x.shape[0], 1)), x))       # noqa: E731
+    for model, ana, use_mean in ((gp.Model(None, cov, None, th, "zero"), MLZeroMeanAnalytic, False), (gp.Model(lin, cov, None, th), REMLAnalytic, True)):
+        vals, grads = batch_values_and_gradients(model, th, batches, True, use_mean=use_mean)
+        one = ana(model)
+        for b in range(3):
+            v, st = one.value_and_state(th, *batches[b])
+            g = one.gradient_from_state(st)
+            assert abs(vals[b] - v) < 1e-8 * abs(v) and rel_err(grads[b], g) < 1e-6
