@@ -2,8 +2,9 @@
 single-GPU product path and the real ``BlockCyclicCholesky`` (ranks sharing the GPU over gloo: the schedule, streams and kernels of
 the 8-GPU run) on the same inputs and compares log-determinant, NLL, sampled entries of the factor, posterior mean / variance,
 kriging weights and the ML value + gradient.  The pool's process guard allows SIX processes on the card and the test runner is
-one of them (it has used the GPU in earlier tests), so inside the suite the grid is 2 x 2: n = 32768 by default,
-``GPMP_TEST_CONFIG5_FULL=1`` for n = 131072 (K = 137 GB on the single-GPU side, 4 x 34 GB on the distributed side; ~10 minutes).
+one of them (it has used the GPU in earlier tests), so inside the suite the process form runs on the 2 x 2 grid (n = 16384) and
+the 2 x 4 grid of config 5 itself as eight THREAD-ranks (n = 32768: tools/thread_ranks.py, device-resident stream-ordered messages);
+``GPMP_TEST_CONFIG5_FULL=1`` for n = 131072 on 2 x 2 processes (K = 137 GB on the single-GPU side, 4 x 34 GB on the distributed side).
 Run on its own (``python tools/config5_full.py all``) the tool takes the 2 x 3 grid: profiles/r5/config5_full_n131072_grid2x3_shared_gpu.log.
 What is compared is what gpmp/num/numpy_backend.py:465-469 and gpmp/core/likelihood.py:18-52 compute."""
 import os
@@ -38,8 +39,9 @@ def test_config5_schedule_with_values_at_n32768_on_the_2x4_grid_of_thread_ranks(
           "--dist-out", str(tmp_path / "d.npz")], 700)
 
 
-def test_config5_schedule_with_values_at_n32768_on_the_2x2_grid(tmp_path):
-    _run(["--grid", "2x2", "--size-n", "32768", "--grad-n", "16384", "--m", "2048", "--limit", "300", "--out", str(tmp_path / "s.npz"),
+def test_config5_schedule_with_values_at_n16384_on_the_2x2_grid_of_processes(tmp_path):
+    """the host-staged branch: one PROCESS per rank over gloo (the test runner is the fifth GPU process)"""
+    _run(["--grid", "2x2", "--size-n", "16384", "--grad-n", "8192", "--m", "2048", "--limit", "300", "--out", str(tmp_path / "s.npz"),
           "--dist-out", str(tmp_path / "d.npz")], 700)
 
 
