@@ -84,6 +84,11 @@ struct GemmOpts {
   long stride2_a = 0, stride2_b = 0, stride2_c = 0;
   int lean = 0;             // NT products with K <= 512 issued next to a machine-filling GEMM on another stream: take the
                             // small-footprint kernel that starts beside the two resident workgroups of that GEMM on every CU
+  // Staircase tile set (the trailing update of a 2-D block-cyclic factor, dist.hip): the group g of 8 tile rows (1024 rows) only has
+  // its first  min(tiles_n, 8 (floor((stair_num g + stair_off) / stair_den) + 1 - stair_sub))  tile columns (none when that is
+  // <= 0 or the numerator is negative); stair_den > 0 enables it.  Tiles are enumerated group by group, row fastest -- the plain
+  // order with a per-group column count -- so the XCD-aware chunking and the 8 x 8 co-residency are kept.
+  int stair_num = 0, stair_den = 0, stair_off = 0, stair_sub = 0;
 };
 int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, long lda,
                 const double* B, long ldb, double beta, double* C, long ldc, const GemmOpts& o,

@@ -219,9 +219,22 @@ extern "C" int gpmp_dist_trailing_update(double* A, long lda, int n, int nb, int
   GPMP_ARG(panel != nullptr && colop != nullptr, 10, "NULL operand");
   const int bk = L.bs(k);
   GPMP_ARG(ldp >= bk && ldc >= bk, 11, "operand leading dimension below the block width");
-  const int G = 4;                                                   // block rows per GEMM of the staircase
   int first = rows_after >= 0 ? L.first_row_after(rows_after) : i0;
   if (first < i0) first = i0;                                        // rows_after < k: the panel has no rows above block k
+  if (first >= nrb) return 0;
+  if (nb == 8 * NB && bk == nb) {
+    // ONE launch over the staircase (round 5): local block row li = first + g holds the blocks J <= I of its global block row
+    // I = r + pr li, i.e. the local columns lj <= (I - c) / pc -- a tile set the GEMM enumerates directly (GemmOpts::stair_*: a
+    // block row = one group of 8 tile rows, so the XCD-aware chunking and the 8 x 8 co-residency of the plain order are kept).
+    // The staircase of GEMMs below computed up to three wasted blocks per group of four block rows (5 % of the update at
+    // config 5) and ended each of its 16 launches on a partial round of the machine.
+    GemmOpts st8;
+    st8.stair_num = pr; st8.stair_den = pc; st8.stair_off = r + pr * first - c; st8.stair_sub = jlo;
+    const long r0 = L.roff(first), r1 = L.roff(nrb), c0 = L.coff(jlo), c1 = L.coff(jhi);
+    return launch_gemm(true, true, (int)(r1 - r0), (int)(c1 - c0), bk, -1.0, panel + (r0 - L.roff(i0)) * ldp, ldp,
+                       colop + (c0 - L.coff(j0)) * ldc, ldc, 1.0, A + r0 * lda + c0, lda, st8, as_stream(stream));
+  }
+  const int G = 4;                                                   // block rows per GEMM of the staircase (other block sizes, ragged K)
   for (int lg = first; lg < nrb; lg += G) {
     const int le = lg + G < nrb ? lg + G : nrb;
     const int I_last = r + (le - 1) * pr;

@@ -48,9 +48,18 @@ struct GemmParams {
   int tri_block;  // lower-triangular tile sets in 8 x 8 super-tiles (round 4) instead of row by row
   int bn;         // v2, plain NN launches: tile width 128 / 112 / 96 (launch_t)
   int early;      // v2: request tile kt + 2 right behind the barrier of tile kt (64 MFMAs of cover) instead of at the top of tile kt + 1 (48)
+  int stair_num, stair_den, stair_off, stair_sub;   // staircase tile set (GemmOpts): columns of tile-row group g; den > 0 enables
   long sa, sb, sc;   // element strides of A, B, C per batch index
   long sa2, sb2, sc2;   // ... per outer batch index (blockIdx.z)
 };
+
+// tile columns of the group g of 8 tile rows of a staircase tile set (host and device)
+__host__ __device__ __forceinline__ int stair_cols(int num, int den, int off, int sub, int tiles_n, int g) {
+  const int a = num * g + off;
+  if (a < 0) return 0;
+  const int c = 8 * (a / den + 1 - sub);
+  return c < 0 ? 0 : (c > tiles_n ? tiles_n : c);
+}
 
 __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& ti, int& tj) {
   // XCD-aware remap (bijective for any grid size): workgroups are dealt round-robin over the 8
@@ -109,6 +118,18 @@ __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& t
       ti = tn + rr / tn;
       tj = rr % tn;
     }
+  } else if (p.stair_den) {
+    // staircase: group by group (8 tile rows each), row fastest inside a group, the group's own number of tile columns
+    int g = 0, acc = 0, gsize = 8, cols = 0;
+    for (;; ++g) {
+      gsize = (p.tiles_m - 8 * g) < 8 ? (p.tiles_m - 8 * g) : 8;
+      cols = stair_cols(p.stair_num, p.stair_den, p.stair_off, p.stair_sub, p.tiles_n, g);
+      if (v < acc + gsize * cols || 8 * (g + 1) >= p.tiles_m) break;
+      acc += gsize * cols;
+    }
+    const int w = v - acc;
+    ti = 8 * g + w % gsize;
+    tj = w / gsize;
   } else if (p.kstart_col | p.kend_row) {
     // unequal k ranges: longest tiles first, so that the last workgroups to start are the short ones
     // (kstart_col: tile column 0 has the full k range; kend_row: the last tile row has it)
@@ -1089,7 +1110,7 @@ int launch_t(const GemmParams& p, hipStream_t st) {
   // tile width of a plain launch on the LDS-direct kernel (round 4): the width among 128 / 112 / 96 that minimises
   // rounds x width, rounds = ceil(tiles / (2 workgroups x CUs))
   GemmParams pf = p;
-  if (v2ok && p.batch == 1 && p.batch2 == 1 && !p.lower_only && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col) && p.N >= 16 * BN) {
+  if (v2ok && p.batch == 1 && p.batch2 == 1 && !p.lower_only && !p.stair_den && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col) && p.N >= 16 * BN) {
     const long slots = 2L * device_cu_count();
     auto cost = [&](int w) { const long t = (long)p.tiles_m * ((p.N + w - 1) / w); return ((t + slots - 1) / slots) * (long)w; };
     long best = cost(BN);
@@ -1114,7 +1135,7 @@ int launch_t(const GemmParams& p, hipStream_t st) {
     // executed flops of this launch (tiles actually visited, k range actually swept)
     const double kavg = (p.kstart_row || p.kend_row || p.kstart_col || p.kend_col) ? 0.5 * p.K : (double)p.K;
     ProfScope ps((AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN)) + ((v2ok && !small_nt) ? 8 : 0), st,
-                 (!p.lower_only && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col))
+                 (!p.lower_only && !p.stair_den && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col))
                      ? 2.0 * (double)p.M * (double)p.N * (double)p.K * p.batch * p.batch2      // a plain product: its own flops
                      : 2.0 * (double)p.ntiles * BM * BN * kavg * p.batch * p.batch2);
     if (lean_nt) hipLaunchKernelGGL(gemm_nt_lean_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
@@ -1226,7 +1247,16 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   p.kstart_col = o.kstart_col;
   p.tiles_m = (M + BM - 1) / BM;
   p.tiles_n = (N + BN - 1) / BN;
-  if (o.lower_only) {
+  p.stair_num = o.stair_num; p.stair_den = o.stair_den; p.stair_off = o.stair_off; p.stair_sub = o.stair_sub;
+  if (o.stair_den > 0) {
+    if (o.lower_only | o.kstart_row | o.kend_row | o.kstart_col | o.kend_col) { set_error("staircase tile set combined with another tile / k restriction"); return -1; }
+    p.ntiles = 0;
+    for (int g = 0; 8 * g < p.tiles_m; ++g) {
+      const int gsize = (p.tiles_m - 8 * g) < 8 ? (p.tiles_m - 8 * g) : 8;
+      p.ntiles += gsize * stair_cols(o.stair_num, o.stair_den, o.stair_off, o.stair_sub, p.tiles_n, g);
+    }
+    if (p.ntiles == 0) return 0;
+  } else if (o.lower_only) {
     const int tn = p.tiles_n < p.tiles_m ? p.tiles_n : p.tiles_m;
     p.ntiles = tn * (tn + 1) / 2 + (p.tiles_m - tn) * tn;
   } else {
@@ -1257,7 +1287,7 @@ int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const d
   if (M <= 0 || N <= 0) return 0;
   // The LDS-direct kernel needs even M and N (16-byte clipping at the edges): peel an odd last row / column off a
   // large rectangular product so that everything else runs on it.
-  const bool plain = !o.lower_only && !o.kstart_row && !o.kend_row && !o.kstart_col && !o.kend_col && o.batch <= 1 && o.batch2 <= 1;
+  const bool plain = !o.lower_only && !o.stair_den && !o.kstart_row && !o.kend_row && !o.kstart_col && !o.kend_col && o.batch <= 1 && o.batch2 <= 1;
   const int Nr = N % 2, Mr = M % 2;
   if (plain && (Nr || Mr) && (K % BK == 0) && K >= 512 && (M >= 4 * BM || N >= 4 * BN) && C != A && C != B) {
     const int Mf = M - Mr, Nf = N - Nr;

@@ -419,7 +419,9 @@ def test_block_cyclic_universal_kriging_hip(tmp_path, pr, pc, n, m, nb, q):
 
 
 @pytest.mark.parametrize("pr,pc,n,nb", [(2, 3, 1900, 128), (3, 2, 1900, 128), (2, 4, 1900, 128), (4, 2, 1900, 128), (3, 3, 1900, 128), (1, 4, 1900, 128),
-                                        (4, 1, 1900, 128), (2, 3, 2304, 256), (3, 3, 2304, 256)])
+                                        (4, 1, 1900, 128), (2, 3, 2304, 256), (3, 3, 2304, 256),
+                                        # nb = 1024: the trailing update is ONE launch over the staircase tile set (round 5)
+                                        (2, 4, 9000, 1024), (2, 3, 10240, 1024), (3, 2, 7000, 1024), (1, 4, 6144, 1024), (4, 1, 5000, 1024)])
 def test_step_abi_local_kernels_on_any_grid_single_process(pr, pc, n, nb):
     """gpmp_dist_exchange_pack / _unpack / _trailing_update for EVERY rank coordinate of non-square grids (lcm(Pr, Pc) strides,
     ragged last blocks), in ONE process: the buffers a rank would hold after the broadcasts are cut out of a global panel
@@ -487,6 +489,22 @@ def test_step_abi_local_kernels_on_any_grid_single_process(pr, pc, n, nb):
                 for lj, J in enumerate(cb):
                     if J <= k:
                         assert np.array_equal(got[:, lj * nb: lj * nb + bs(J)], want[:, lj * nb: lj * nb + bs(J)])
+                # the split the look-ahead schedule makes -- ONE block column first (restricted to the rows below block k + 1 when this
+                # rank owns the diagonal block (k + 1, k + 1)), the rest after -- gives the same needed blocks bit for bit
+                jcol = [lj for lj, J in enumerate(cb) if J > k]
+                if jcol:
+                    Asp = gnp.as_matrix(gnp.asarray(A[np.ix_(gr, gc)]), copy=True)
+                    j1 = jcol[0]
+                    ra = cb[j1] if (cb[j1] in rb) else -1
+                    for (a_, b_, rows_after) in ((j1, j1 + 1, ra), (j1 + 1, len(cb), -1)):
+                        _lib.check(lib.gpmp_dist_trailing_update(gnp._ptr(Asp), gnp._ld(Asp), n, nb, pr, pc, r, c, k, gnp._ptr(panel), gnp._ld(panel),
+                                                                 gnp._ptr(colop), gnp._ld(colop), a_, b_, rows_after, gnp._stream()), "update (split)")
+                    gsp = gnp.to_np(Asp)
+                    for li, I in enumerate(rb):
+                        for lj, J in enumerate(cb):
+                            if I >= J > k and not (lj == j1 and ra >= 0 and I <= ra):
+                                assert np.array_equal(gsp[li * nb: li * nb + bs(I), lj * nb: lj * nb + bs(J)],
+                                                      got[li * nb: li * nb + bs(I), lj * nb: lj * nb + bs(J)]), (pr, pc, r, c, k, I, J)
 
 
 def _model_worker(rank, world, port, pr, pc, meantype, out):
