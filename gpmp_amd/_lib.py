@@ -80,6 +80,7 @@ SIGNATURES = {
     "gpmp_dist_exchange_unpack": (c_int, [_P, c_long, _P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gpmp_dist_trailing_update": (c_int, [_P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_long, _P, c_long, c_int, c_int,
                                           c_int, _P]),
+    "gpmp_dist_inverse_gram": (c_int, [_P, c_long, _P, c_long, _P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gpmp_loo": (c_int, [_P, _P, _P, c_long, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]),
 }
 

@@ -89,6 +89,11 @@ struct GemmOpts {
   // <= 0 or the numerator is negative); stair_den > 0 enables it.  Tiles are enumerated group by group, row fastest -- the plain
   // order with a per-group column count -- so the XCD-aware chunking and the 8 x 8 co-residency are kept.
   int stair_num = 0, stair_den = 0, stair_off = 0, stair_sub = 0;
+  // Contraction start per GROUP of 8 tile rows / 8 tile columns (the blocks of T^T T on a block-cyclic inverse factor, dist.hip):
+  // the k loop of tile (ti, tj) starts at 1024 max(0, ceil((kg_rnum (ti / 8) + kg_roff) / kg_rden), ceil((kg_cnum (tj / 8) + kg_coff)
+  // / kg_cden)) -- what lies before is structurally zero in both operands' block columns.  den > 0 enables the respective term; tiles
+  // of unequal cost are dealt round-robin over the XCDs.  Combines with the staircase tile set, with nothing else.
+  int kg_rnum = 0, kg_rden = 0, kg_roff = 0, kg_cnum = 0, kg_cden = 0, kg_coff = 0;
 };
 int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, long lda,
                 const double* B, long ldb, double beta, double* C, long ldc, const GemmOpts& o,

@@ -248,3 +248,30 @@ extern "C" int gpmp_dist_trailing_update(double* A, long lda, int n, int nb, int
   }
   return 0;
 }
+
+extern "C" int gpmp_dist_inverse_gram(const double* T, long ldt, const double* T2, long ldt2, double* M, long ldm, int n, int nb, int pr,
+                                      int pc, int r, int c, int c2, int lower_only, gpmp_stream_t stream) {
+  Layout L, L2;
+  if (int rc = make_layout(L, n, nb, pr, pc, r, c)) return rc;
+  if (int rc = make_layout(L2, n, nb, pr, pc, r, c2)) return rc;
+  GPMP_ARG(nb == 8 * NB, 8, "block size must be 1024 (one block = one group of 8 GEMM tiles)");
+  const long rows = L.local_rows(), mc = L.local_cols(), mc2 = L2.local_cols();
+  if (mc == 0 || mc2 == 0) return 0;
+  GPMP_ARG(M != nullptr && ldm >= mc2, 5, "M is NULL or ldm below the column count of the second column set");
+  if (rows == 0) {                                  // this process row holds nothing of T: the partial product is zero
+    GPMP_HIP_TRY(hipMemset2DAsync(M, sizeof(double) * (size_t)ldm, 0, sizeof(double) * (size_t)mc2, (size_t)mc, as_stream(stream)));
+    return 0;
+  }
+  GPMP_ARG(T != nullptr && ldt >= mc, 1, "T is NULL or ldt below the local column count");
+  GPMP_ARG(T2 != nullptr && ldt2 >= mc2, 3, "T2 is NULL or ldt2 below its local column count");
+  // block (I, J) of T^T T2, I = c + pc g (my column set), J = c2 + pc h: T[k, I] = 0 for global block rows k < I, so the contraction
+  // starts at the first local block row >= max(I, J): local block ceil((I - r) / pr) resp. ceil((J - r) / pr)
+  GemmOpts o;
+  o.kg_rnum = pc; o.kg_rden = pr; o.kg_roff = c - r;
+  o.kg_cnum = pc; o.kg_cden = pr; o.kg_coff = c2 - r;
+  if (lower_only) {                                  // the blocks J <= I only: floor((pc g + c - c2) / pc) + 1 leading column blocks
+    o.stair_num = pc; o.stair_den = pc; o.stair_off = c - c2; o.stair_sub = 0;
+  }
+  return launch_gemm(false, false, (int)mc, (int)mc2, (int)rows, 1.0, T, ldt, T2, ldt2, 0.0, M, ldm, o, as_stream(stream));
+}
+

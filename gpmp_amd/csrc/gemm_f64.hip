@@ -49,6 +49,7 @@ struct GemmParams {
   int bn;         // v2, plain NN launches: tile width 128 / 112 / 96 (launch_t)
   int early;      // v2: request tile kt + 2 right behind the barrier of tile kt (64 MFMAs of cover) instead of at the top of tile kt + 1 (48)
   int stair_num, stair_den, stair_off, stair_sub;   // staircase tile set (GemmOpts): columns of tile-row group g; den > 0 enables
+  int kg_rnum, kg_rden, kg_roff, kg_cnum, kg_cden, kg_coff;   // contraction start per group of 8 tile rows / columns (GemmOpts)
   long sa, sb, sc;   // element strides of A, B, C per batch index
   long sa2, sb2, sc2;   // ... per outer batch index (blockIdx.z)
 };
@@ -61,6 +62,20 @@ __host__ __device__ __forceinline__ int stair_cols(int num, int den, int off, in
   return c < 0 ? 0 : (c > tiles_n ? tiles_n : c);
 }
 
+// first k of a tile under GemmOpts::kg_*: 1024 max(0, ceil((num g + off) / den)) for its row group and its column group
+__device__ __forceinline__ int group_kstart(const GemmParams& p, int ti, int tj) {
+  int kb = 0;
+  if (p.kg_rden > 0) {
+    const int a = p.kg_rnum * (ti >> 3) + p.kg_roff;
+    if (a > 0) kb = 1024 * ((a + p.kg_rden - 1) / p.kg_rden);
+  }
+  if (p.kg_cden > 0) {
+    const int a = p.kg_cnum * (tj >> 3) + p.kg_coff;
+    if (a > 0) { const int k2 = 1024 * ((a + p.kg_cden - 1) / p.kg_cden); if (k2 > kb) kb = k2; }
+  }
+  return kb;
+}
+
 __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& ti, int& tj) {
   // XCD-aware remap (bijective for any grid size): workgroups are dealt round-robin over the 8
   // XCDs, so give XCD x the x-th contiguous chunk of the tile list.
@@ -70,7 +85,7 @@ __device__ __forceinline__ void decode_tile(const GemmParams& p, int bid, int& t
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   // tiles of unequal cost (triangular k ranges) are dealt round-robin instead: a contiguous chunk per
   // XCD would hand one XCD all the long tiles (measured on lauum: 29 -> 50+ TFLOP/s)
-  const int v = (p.kstart_row | p.kend_row | p.kstart_col | p.kend_col) ? bid : base + bid / NXCD;
+  const int v = (p.kstart_row | p.kend_row | p.kstart_col | p.kend_col | p.kg_rden | p.kg_cden) ? bid : base + bid / NXCD;
   if (p.lower_only) {
     const int tn = p.tiles_n < p.tiles_m ? p.tiles_n : p.tiles_m;
     const int t1 = tn * (tn + 1) / 2;
@@ -256,6 +271,10 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmParams p) {
   int kbeg = p.kstart_row ? row0 : 0;
   if (p.kstart_col) {
     const int kb = col0 & ~(BK - 1);
+    if (kb > kbeg) kbeg = kb;
+  }
+  if (p.kg_rden | p.kg_cden) {
+    const int kb = group_kstart(p, ti, tj);
     if (kb > kbeg) kbeg = kb;
   }
   int kend = p.K;
@@ -450,6 +469,10 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel_v2(GemmParams p) {
   int kbeg = p.kstart_row ? row0 : 0;
   if (p.kstart_col) {
     const int kb = col0 & ~(BK - 1);
+    if (kb > kbeg) kbeg = kb;
+  }
+  if (p.kg_rden | p.kg_cden) {
+    const int kb = group_kstart(p, ti, tj);
     if (kb > kbeg) kbeg = kb;
   }
   int kend = p.K;
@@ -1110,7 +1133,7 @@ int launch_t(const GemmParams& p, hipStream_t st) {
   // tile width of a plain launch on the LDS-direct kernel (round 4): the width among 128 / 112 / 96 that minimises
   // rounds x width, rounds = ceil(tiles / (2 workgroups x CUs))
   GemmParams pf = p;
-  if (v2ok && p.batch == 1 && p.batch2 == 1 && !p.lower_only && !p.stair_den && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col) && p.N >= 16 * BN) {
+  if (v2ok && p.batch == 1 && p.batch2 == 1 && !p.lower_only && !p.stair_den && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col | p.kg_rden | p.kg_cden) && p.N >= 16 * BN) {
     const long slots = 2L * device_cu_count();
     auto cost = [&](int w) { const long t = (long)p.tiles_m * ((p.N + w - 1) / w); return ((t + slots - 1) / slots) * (long)w; };
     long best = cost(BN);
@@ -1133,9 +1156,9 @@ int launch_t(const GemmParams& p, hipStream_t st) {
                         p.ntiles <= (p.K >= 512 ? 384 : small_max) && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col);
   {
     // executed flops of this launch (tiles actually visited, k range actually swept)
-    const double kavg = (p.kstart_row || p.kend_row || p.kstart_col || p.kend_col) ? 0.5 * p.K : (double)p.K;
+    const double kavg = (p.kstart_row || p.kend_row || p.kstart_col || p.kend_col || p.kg_rden || p.kg_cden) ? 0.5 * p.K : (double)p.K;
     ProfScope ps((AKC ? (BKC ? PK_GEMM_NT : PK_GEMM_NN) : (BKC ? PK_GEMM_TT : PK_GEMM_TN)) + ((v2ok && !small_nt) ? 8 : 0), st,
-                 (!p.lower_only && !p.stair_den && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col))
+                 (!p.lower_only && !p.stair_den && !(p.kstart_row | p.kend_row | p.kstart_col | p.kend_col | p.kg_rden | p.kg_cden))
                      ? 2.0 * (double)p.M * (double)p.N * (double)p.K * p.batch * p.batch2      // a plain product: its own flops
                      : 2.0 * (double)p.ntiles * BM * BN * kavg * p.batch * p.batch2);
     if (lean_nt) hipLaunchKernelGGL(gemm_nt_lean_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 0, st, p);
@@ -1248,6 +1271,11 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   p.tiles_m = (M + BM - 1) / BM;
   p.tiles_n = (N + BN - 1) / BN;
   p.stair_num = o.stair_num; p.stair_den = o.stair_den; p.stair_off = o.stair_off; p.stair_sub = o.stair_sub;
+  p.kg_rnum = o.kg_rnum; p.kg_rden = o.kg_rden; p.kg_roff = o.kg_roff; p.kg_cnum = o.kg_cnum; p.kg_cden = o.kg_cden; p.kg_coff = o.kg_coff;
+  if ((o.kg_rden > 0 || o.kg_cden > 0) && (o.lower_only | o.kstart_row | o.kend_row | o.kstart_col | o.kend_col)) {
+    set_error("group contraction starts combined with another tile / k restriction");
+    return -1;
+  }
   if (o.stair_den > 0) {
     if (o.lower_only | o.kstart_row | o.kend_row | o.kstart_col | o.kend_col) { set_error("staircase tile set combined with another tile / k restriction"); return -1; }
     p.ntiles = 0;
@@ -1268,7 +1296,7 @@ static int launch_gemm_one(bool a_kc, bool b_kc, int M, int N, int K, double alp
   // 92.2 -> 93.1 % of peak; neutral at 1024, -0.3 at 512: profiles/r4/gemm_early_issue_ab.log)
   p.early = K >= 2048 ? 1 : 0;
   // lower-triangular tile sets of equal-cost tiles in 8 x 8 super-tiles (fabric-side fetch of the Cholesky's trailing update / 2.24)
-  p.tri_block = !(o.kstart_row | o.kend_row | o.kstart_col | o.kend_col);
+  p.tri_block = !(o.kstart_row | o.kend_row | o.kstart_col | o.kend_col | o.kg_rden | o.kg_cden);
   p.batch = o.batch > 1 ? o.batch : 1;
   p.sa = o.stride_a; p.sb = o.stride_b; p.sc = o.stride_c;
   p.batch2 = o.batch2 > 1 ? o.batch2 : 1;
@@ -1287,7 +1315,7 @@ int launch_gemm(bool a_kc, bool b_kc, int M, int N, int K, double alpha, const d
   if (M <= 0 || N <= 0) return 0;
   // The LDS-direct kernel needs even M and N (16-byte clipping at the edges): peel an odd last row / column off a
   // large rectangular product so that everything else runs on it.
-  const bool plain = !o.lower_only && !o.stair_den && !o.kstart_row && !o.kend_row && !o.kstart_col && !o.kend_col && o.batch <= 1 && o.batch2 <= 1;
+  const bool plain = !o.lower_only && !o.stair_den && !o.kg_rden && !o.kg_cden && !o.kstart_row && !o.kend_row && !o.kstart_col && !o.kend_col && o.batch <= 1 && o.batch2 <= 1;
   const int Nr = N % 2, Mr = M % 2;
   if (plain && (Nr || Mr) && (K % BK == 0) && K >= 512 && (M >= 4 * BM || N >= 4 * BN) && C != A && C != B) {
     const int Mf = M - Mr, Nf = N - Nr;

@@ -267,6 +267,14 @@ class HipLocalOps:
         self._lib.check(self.lib.gpmp_dist_exchange_unpack(g._ptr(piece), g._ld(piece), g._ptr(colop), g._ld(colop), n, nb, pr, pc, rp, c, k,
                                                            bk, g._stream()), "gpmp_dist_exchange_unpack")
 
+    def inverse_gram(self, T, T2, M, lay, c2, lower_only):
+        """M <- T^T T2 for the column sets (c, c2) of the block-cyclic inverse factor, every block with its exact contraction range,
+        ONE launch (gpmp_dist_inverse_gram); lower_only: the blocks J <= I only"""
+        g = self.gnp
+        n, nb, pr, pc, r, c = lay
+        self._lib.check(self.lib.gpmp_dist_inverse_gram(g._ptr(T), g._ld(T), g._ptr(T2), g._ld(T2), g._ptr(M), g._ld(M), n, nb, pr, pc, r, c,
+                                                        int(c2), 1 if lower_only else 0, g._stream()), "gpmp_dist_inverse_gram")
+
     def trailing_update(self, A, lay, k, panel, colop, jlo, jhi, rows_after):
         g = self.gnp
         n, nb, pr, pc, r, c = lay
@@ -1462,6 +1470,14 @@ class BlockCyclicCholesky:
             if not (len(ci) and len(ci2) and len(self.row_blocks)):
                 continue
             lowG_all = Gh[ci2] if g.r == 0 else None          # the low-rank part enters exactly once per block: on process row 0
+            # round 5: with the C ABI's local half (nb = 1024) ALL blocks of this shift are ONE launch -- a staircase tile set (the
+            # blocks J <= I) with the contraction start of every block row / block column in the kernel's k loop -- instead of one
+            # product per block column, most of them too small to fill the machine
+            fused = self._abi and hasattr(ops, "inverse_gram") and self.nb == 1024
+            Mfused = None
+            if fused:
+                Mfused = ops.empty(len(ci), len(ci2))
+                ops.inverse_gram(T, T2, Mfused, self._lay, c2, strips_only)
             if strips_only:
                 for li, I in enumerate(my_blocks):
                     oI, wI = self.coff[li], self.bs(I)
@@ -1469,11 +1485,14 @@ class BlockCyclicCholesky:
                     ro = row_start(I)
                     if pref == 0:
                         continue
-                    strip = ops.empty(wI, pref)
-                    if ro < nrows_loc:
-                        ops.gemm_tn_into(T[ro:, oI:oI + wI], T2[ro:, :pref], strip)
+                    if fused:
+                        strip = Mfused[oI:oI + wI, :pref]
                     else:
-                        strip.zero_()                                            # no local row below: only the low-rank part is left
+                        strip = ops.empty(wI, pref)
+                        if ro < nrows_loc:
+                            ops.gemm_tn_into(T[ro:, oI:oI + wI], T2[ro:, :pref], strip)
+                        else:
+                            strip.zero_()                                        # no local row below: only the low-rank part is left
                     lowF = Fh[ci[oI:oI + wI]] if g.r == 0 else None
                     xr = xs_c[oI:oI + wI]
                     if sft == 0:
@@ -1487,6 +1506,9 @@ class BlockCyclicCholesky:
                         tot += 2.0 * ops.grad_trace_cross(strip, xr, x[ci2[:pref]], p, th, noise, lowF,
                                                           None if lowG_all is None else lowG_all[:pref]).to(dev)
                     del strip
+            elif fused:
+                lowF = Fh[ci] if g.r == 0 else None
+                tot += 2.0 * ops.grad_trace_cross(Mfused, xs_c, x[ci2], p, th, noise, lowF, lowG_all).to(dev)
             else:
                 Mblk = ops.empty(len(ci), len(ci2))
                 for li, I in enumerate(my_blocks):                               # row strips: J <= I

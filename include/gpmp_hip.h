@@ -387,6 +387,16 @@ int gpmp_dist_exchange_unpack(const double* piece, long ldq, double* colop, long
 int gpmp_dist_trailing_update(double* A, long lda, int n, int nb, int pr, int pc, int r, int c, int k, const double* panel,
                               long ldp, const double* colop, long ldc, int jlo, int jhi, int rows_after, gpmp_stream_t stream);
 
+/* The blocks of T^T T2 on a block-cyclic INVERSE factor (what K^-1 = T^T T needs for the gradient of the ML / REML criteria;
+ * gpmp/num/numpy_backend.py:458-463 forms the inverse; the reference differentiates by autograd / finite differences): T and T2
+ * are this rank's local rows of T = L^-1 for the column sets c and c2 (c2 == c: T2 = T; otherwise the neighbour's part, received
+ * by the host).  M (local columns of set c) x (local columns of set c2) <- T^T T2 with the contraction of block (I, J) starting at the
+ * first local block row >= max(I, J) -- T is lower triangular, everything before is structurally zero -- in ONE launch; lower_only
+ * != 0: only the blocks J <= I are computed (the rest of M is left untouched).  The sum over the process rows is the host's
+ * (the trace against dK is linear: no matrix reduction is needed).  nb must be 1024.  Enqueue only. */
+int gpmp_dist_inverse_gram(const double* T, long ldt, const double* T2, long ldt2, double* M, long ldm, int n, int nb, int pr, int pc,
+                           int r, int c, int c2, int lower_only, gpmp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -421,7 +421,7 @@ def test_block_cyclic_universal_kriging_hip(tmp_path, pr, pc, n, m, nb, q):
 @pytest.mark.parametrize("pr,pc,n,nb", [(2, 3, 1900, 128), (3, 2, 1900, 128), (2, 4, 1900, 128), (4, 2, 1900, 128), (3, 3, 1900, 128), (1, 4, 1900, 128),
                                         (4, 1, 1900, 128), (2, 3, 2304, 256), (3, 3, 2304, 256),
                                         # nb = 1024: the trailing update is ONE launch over the staircase tile set (round 5)
-                                        (2, 4, 9000, 1024), (2, 3, 10240, 1024), (3, 2, 7000, 1024), (1, 4, 6144, 1024), (4, 1, 5000, 1024)])
+                                        (2, 4, 7000, 1024), (2, 3, 6500, 1024), (3, 2, 5200, 1024), (1, 4, 5120, 1024), (4, 1, 4500, 1024)])
 def test_step_abi_local_kernels_on_any_grid_single_process(pr, pc, n, nb):
     """gpmp_dist_exchange_pack / _unpack / _trailing_update for EVERY rank coordinate of non-square grids (lcm(Pr, Pc) strides,
     ragged last blocks), in ONE process: the buffers a rank would hold after the broadcasts are cut out of a global panel
@@ -735,3 +735,48 @@ def test_stream_ordered_fabric_detects_a_missing_stream_dependency():
     env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_order_mutation_probe.py")], env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0 and "MUTATION PROBE OK" in r.stdout, (r.stdout[-2000:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("pr,pc,n", [(2, 4, 9000), (2, 3, 7000), (3, 2, 6200), (1, 4, 5120), (4, 1, 4600)])
+def test_inverse_gram_blocks_one_launch_on_any_grid_single_process(pr, pc, n):
+    """gpmp_dist_inverse_gram (round 5): the blocks of T^T T2 on a block-cyclic inverse factor in ONE launch -- staircase tile set
+    (lower_only: the blocks J <= I) + the contraction start of every block row / column inside the GEMM's k loop -- for EVERY rank
+    coordinate and every pair of column sets, against NumPy on the local pieces of a random lower-triangular T (ragged last blocks)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gpmp_amd.num as gnp
+    from gpmp_amd import _lib
+
+    lib = _lib.load()
+    nb = 1024
+    rng = np.random.default_rng(pr * 10 + pc + n)
+    nblk = (n + nb - 1) // nb
+    bs = lambda I: min(nb, n - I * nb)                 # noqa: E731
+    idx = lambda blocks: np.concatenate([np.arange(I * nb, I * nb + bs(I)) for I in blocks]) if blocks else np.zeros(0, dtype=np.int64)   # noqa: E731
+    T = np.tril(rng.standard_normal((n, n)))
+    for r in range(pr):
+        rows = idx(list(range(r, nblk, pr)))
+        for c in range(pc):
+            cb = list(range(c, nblk, pc))
+            Tl = gnp.as_matrix(gnp.asarray(T[np.ix_(rows, idx(cb))]), copy=True) if len(rows) and cb else None
+            for c2 in sorted({c, (c + 1) % pc, (c + pc // 2) % pc}):
+                cb2 = list(range(c2, nblk, pc))
+                if not cb or not cb2:
+                    continue
+                T2l = Tl if c2 == c else (gnp.as_matrix(gnp.asarray(T[np.ix_(rows, idx(cb2))]), copy=True) if len(rows) else None)
+                want = T[np.ix_(rows, idx(cb))].T @ T[np.ix_(rows, idx(cb2))] if len(rows) else np.zeros((len(idx(cb)), len(idx(cb2))))
+                for lower in (0, 1):
+                    M = gnp.alloc_matrix(len(idx(cb)), len(idx(cb2)))
+                    M.fill_(-7.0)
+                    _lib.check(lib.gpmp_dist_inverse_gram(gnp._ptr(Tl), 0 if Tl is None else gnp._ld(Tl), gnp._ptr(T2l), 0 if T2l is None else gnp._ld(T2l),
+                                                          gnp._ptr(M), gnp._ld(M), n, nb, pr, pc, r, c, c2, lower, gnp._stream()), "inverse_gram")
+                    got = gnp.to_np(M)
+                    scale = max(1.0, np.max(np.abs(want)))
+                    for li, I in enumerate(cb):
+                        for lj, J in enumerate(cb2):
+                            blk_g = got[li * nb: li * nb + bs(I), lj * nb: lj * nb + bs(J)]
+                            blk_w = want[li * nb: li * nb + bs(I), lj * nb: lj * nb + bs(J)]
+                            if lower and J > I:
+                                assert np.all(blk_g == -7.0), (pr, pc, r, c, c2, I, J)          # not computed, not touched
+                            else:
+                                assert np.max(np.abs(blk_g - blk_w)) < 1e-11 * scale, (pr, pc, r, c, c2, I, J, lower)
