@@ -678,7 +678,8 @@ def _stream_ordered_entry_points(pr, pc, delay_cycles, n=2100, m=333, nb=256, wi
 
 @pytest.mark.parametrize("pr,pc,delay_cycles,factor_kw", [(2, 4, 0, {}), (2, 4, 3_000_000, {}), (3, 2, 1_000_000, {}), (4, 2, 1_000_000, {}),
                                                            (3, 3, 1_000_000, {}), (1, 8, 1_000_000, {}), (2, 4, 1_000_000, {"lookahead": False}),
-                                                           (2, 4, 1_000_000, {"reserve_cus": 16})],
+                                                           (2, 4, 1_000_000, {"reserve_cus": 16}), (2, 4, 1_000_000, {"_n": 4096, "_nb": 1024}),
+                                                           (3, 2, 0, {"_n": 5003, "_nb": 1024})],
                          ids=lambda v: "-".join(f"{k}={w}" for k, w in v.items()) if isinstance(v, dict) else str(v))
 def test_every_entry_point_on_the_stream_ordered_fabric(pr, pc, delay_cycles, factor_kw):
     """(round 5) The device-resident branch of gpmp_amd/dist (``backend == "nccl"``: what runs under RCCL) with RCCL's STREAM
@@ -692,9 +693,11 @@ def test_every_entry_point_on_the_stream_ordered_fabric(pr, pc, delay_cycles, fa
     NLL, REML, universal kriging with weights, leave-one-out, REML value + gradient against the oracle."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    n, m, d = 2100, 333, 4
-    with_model = (pr, pc, delay_cycles) == (2, 4, 0)
-    g = _stream_ordered_entry_points(pr, pc, delay_cycles, n=n, m=m, with_model=with_model, **factor_kw)
+    factor_kw = dict(factor_kw)
+    # (_n / _nb: the block size of config 5, 1024 -- the one-launch staircase trailing update and the one-launch blocks of T^T T)
+    n, nb, m, d = factor_kw.pop("_n", 2100), factor_kw.pop("_nb", 256), 333, 4
+    with_model = (pr, pc, delay_cycles) == (2, 4, 0) and nb == 256
+    g = _stream_ordered_entry_points(pr, pc, delay_cycles, n=n, m=m, nb=nb, with_model=with_model, **factor_kw)
     x, z = make_xz(n, d, 11)
     xt, _ = make_xz(m, d, 12)
     th = theta_aniso(d, scale=0.5)
