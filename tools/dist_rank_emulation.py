@@ -35,6 +35,10 @@ def main():
     ap.add_argument("--step-m", type=int, default=0, help="also time one emulated HEADLINE STEP on the block-cyclic factor: (Gram + factor + "
                     "zero-mean prediction at this many points) + (Gram + factor + NLL), what extra.strong_scaling_block_cyclic of bench.py "
                     "runs on the real grid; compute only (collectives stubbed)")
+    ap.add_argument("--link-gbps", type=float, default=0.0, help="model the TIME of every message: the stream that issues a broadcast / "
+                    "exchange / ring shift is held for bytes / (this many GB/s) + --link-latency-us (a spin kernel; both for the root and "
+                    "for a receiver: a broadcast occupies both ends).  0 = messages take no time (compute-only share)")
+    ap.add_argument("--link-latency-us", type=float, default=10.0)
     ap.add_argument("--lambdas", action="store_true", help="with --solve-m: also time the BACKWARD many-right-hand-side solve (the kriging "
                     "weights of return_lambdas=True), with and without the prefetch / bulk / chain overlap")
     a = ap.parse_args()
@@ -54,14 +58,34 @@ def main():
     grid.world, grid.rank, grid.pr, grid.pc, grid.r, grid.c = pr * pc, r * pc + c, pr, pc, r, c
     grid.row_groups, grid.col_groups, grid.diag_col_groups, grid.world_group = [None] * pr, [None] * pc, [None] * pc, None
 
+    # spin-kernel calibration for the link model: cycles of torch.cuda._sleep per microsecond
+    cyc_per_us = 0.0
+    if a.link_gbps > 0:
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); torch.cuda._sleep(20_000_000); e1.record(); torch.cuda.synchronize()
+        cyc_per_us = 20_000_000 / (e0.elapsed_time(e1) * 1e3)
+    held = {"us": 0.0, "messages": 0}
+
+    def hold(nbytes):
+        """the issuing stream is busy with this message for latency + bytes / bandwidth"""
+        if a.link_gbps > 0:
+            us = a.link_latency_us + nbytes / (a.link_gbps * 1e3)
+            held["us"] += us
+            held["messages"] += 1
+            torch.cuda._sleep(int(us * cyc_per_us))
+
     class Emulated(BlockCyclicCholesky):
-        def _bcast(self, t, src_rank, group, members):      # noqa: D401 -- no communication: shapes only
+        def _bcast(self, t, src_rank, group, members):      # noqa: D401 -- no communication: shapes (and, with --link-gbps, time) only
             if self.grid.rank != src_rank:
                 self.bytes_received += t.numel() * 8
+            hold(t.numel() * 8)
             return t
 
         def _ring_shift(self, t, shift):                     # the neighbour's part of T has this rank's shape here
             self.bytes_received += t.numel() * 8
+            hold(t.numel() * 8)
             return t
 
         def _all_reduce(self, t, op, group, what):          # (sub-communicators do not exist in the emulation)
@@ -179,6 +203,9 @@ def main():
                       "gram_s": t1 - t0, "factor_s": t2 - t1, "rank_share_tflops": share / (t2 - t1) / 1e12,
                       "frac_of_fp64_mfma_peak": share / (t2 - t1) / 1e12 / 78.6,
                       "bytes_received_GB": bytes_received / 1e9,
+                      "link_model": None if a.link_gbps <= 0 else {"GBps_per_message": a.link_gbps, "latency_us": a.link_latency_us,
+                                                                   "messages": held["messages"], "stream_seconds_held": held["us"] / 1e6,
+                                                                   "note": "every broadcast / exchange / ring shift holds its issuing stream for latency + bytes / bandwidth (all phases of this run together)"},
                       "phases_ms": factor_phases, "solve": solve, "grad": grad, "headline_step": step,
                       "note": "collectives stubbed: timing and fault check only, values are not a factorisation"}))
     dist.destroy_process_group()
