@@ -12,8 +12,8 @@ Right-looking schedule per block column k (owner column cd = k mod Pc):
   4. every process row r: panel piece broadcast along the row from (r, cd)                        [RCCL]
   5. every process column c: the blocks J > k with J mod Pc == c are exchanged inside the column
      (one broadcast per process row) -> the "transposed" operand of the update                    [RCCL]
-  6. every rank: A_IJ -= L_Ik L_Jk^T for its blocks I >= J > k, a staircase of GEMMs over groups of
-     4 local block rows                                                                              [local]
+  6. every rank: A_IJ -= L_Ik L_Jk^T for its blocks I >= J > k: ONE launch over the staircase of local
+     blocks (nb = 1024; other block sizes: a staircase of GEMMs over groups of 4 local block rows)  [local]
 Collectives are point-to-point-friendly broadcasts of (n - k nb) nb / Pr resp. / Pc doubles; scalars
 (log-det, quadratic form) use one all-reduce of a few doubles.
 """
