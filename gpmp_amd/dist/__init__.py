@@ -14,7 +14,8 @@ The host logic is backend independent (``LocalOps``): the product path uses ``Hi
 libgpmp_hip.so); the CPU tests inject a NumPy implementation and run the same schedule over gloo.
 """
 from .grid import ProcessGrid
-from .cholesky import BlockCyclicCholesky, HipLocalOps
+from .cholesky import BlockCyclicCholesky
+from .local_ops import HipLocalOps
 from .predict import sharded_predict, shard_bounds
 from .fit import distributed_criterion, fit_covparam
 from .model import DistributedModel

@@ -502,17 +502,15 @@ def logdet(A):
 
 
 def solve(A, B, overwrite_a=True, overwrite_b=True, assume_a="gen", sym_pos=False):
-    """scipy.linalg.solve as used on the path: SPD systems go through the HIP Cholesky; small general / symmetric
-    indefinite systems (the q x q blocks of the mean-space algebra) are plumbing-sized torch solves."""
+    """scipy.linalg.solve as used on the path: SPD systems go through the HIP Cholesky.  General / symmetric-indefinite systems
+    are the q x q (or (q + 1) x (q + 1)) blocks of the mean-space algebra: host LAPACK, like the other q x q steps.  A LARGE
+    general system is not something the GP path produces (universal kriging goes through the Schur complement or the contrast
+    space, core/kriging.py); user code written against the backend namespace gets the same host LAPACK call, never a vendor GPU
+    solver."""
     A, B = asarray(A), asarray(B)
     if assume_a == "pos" or sym_pos:
         return cholesky_factor(A).solve(B)
-    if A.shape[0] <= 256:
-        # the q x q (or (q + 1) x (q + 1)) systems of the mean-space algebra: host LAPACK, like the other q x q steps
-        return asarray(numpy.linalg.solve(to_np(A), to_np(B)))
-    # a LARGE general / symmetric-indefinite system is not something the GP path produces (universal kriging goes through the
-    # Schur complement or the contrast space, core/kriging.py); kept for user code written against the backend namespace
-    return torch.linalg.solve(A, B)
+    return asarray(numpy.linalg.solve(to_np(A), to_np(B)))
 
 
 def qr(A, mode="reduced"):

@@ -9,6 +9,7 @@ from scipy.stats import multivariate_normal as scipy_mvnormal
 from scipy.stats import norm as normal  # noqa: F401  (host-side distribution objects, as in the reference's NumPy backend)
 
 from . import _dev, _host_params, asarray, derivative_finite_diff, scaled_distance, to_np
+from . import svd as _svd
 
 ndarray = torch.Tensor
 
@@ -170,11 +171,29 @@ def inner(a, b):
 
 
 def norm(x, ord=None, axis=None):  # noqa: A002
-    return torch.linalg.norm(_t(x), ord=ord, dim=axis)
+    """numpy.linalg.norm.  Vector norms and the Frobenius norm are elementwise reductions on the device; a matrix 2-norm / nuclear
+    norm comes from the library's Jacobi SVD (square input); every other matrix norm is host LAPACK (never on the GP path)."""
+    x = _t(x)
+    vector = x.dim() == 1 or isinstance(axis, int)
+    if (vector and ord in (None, 2)) or (not vector and ord in (None, "fro")):
+        return torch.sqrt(torch.sum(x * x, dim=axis) if axis is not None else torch.sum(x * x))
+    if vector and ord in (1, numpy.inf, float("inf")):
+        a = torch.abs(x)
+        red = torch.sum if ord == 1 else torch.amax
+        return red(a, dim=axis) if axis is not None else red(a)
+    if not vector and x.dim() == 2 and axis is None and ord in (2, -2, "nuc") and x.shape[0] == x.shape[1] and x.shape[0] > 0:
+        sv = _svd(x)[1]
+        return sv[0] if ord == 2 else (sv[-1] if ord == -2 else torch.sum(sv))
+    return asarray(numpy.linalg.norm(to_np(x), ord=ord, axis=axis))
 
 
 def cond(x, p=None):
-    return torch.linalg.cond(_t(x), p=p)
+    """numpy.linalg.cond: 2-norm condition number from the library's Jacobi SVD (square input); other norms: host LAPACK."""
+    x = _t(x)
+    if p in (None, 2) and x.dim() == 2 and x.shape[0] == x.shape[1] and x.shape[0] > 0:
+        sv = _svd(x)[1]
+        return sv[0] / sv[-1]
+    return asarray(numpy.linalg.cond(to_np(x), p=p))
 
 
 def cdist(x, y):

@@ -595,7 +595,7 @@ def test_every_distributed_entry_point_under_rccl(pr, pc, transport):
     ``DistributedModel`` surface (predict with ``return_lambdas=True``, loo, criterion) and a short ``fit_covparam`` run, against
     the oracle.  RCCL wants one GPU per rank, so a one-GPU box runs the 1 x 1 grid (both transports) and skips the rest: that
     covers communicator creation with the high-priority options (gpmp_amd/dist/grid.py:14-45), the four communicator kinds, the
-    device-resident comm tensors (gpmp_amd/dist/cholesky.py:269-284) and the work / stream waits under RCCL's own streams --
+    device-resident comm tensors (`_comm_tensor` / `_gloo_cuda_guard`, gpmp_amd/dist/streams.py) and the work / stream waits under RCCL's own streams --
     not an exchange between two ranks."""
     import subprocess
     import sys

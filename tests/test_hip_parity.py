@@ -1062,6 +1062,16 @@ def test_backend_namespace_extras_match_numpy(gnp):
     np.testing.assert_allclose(gnp.to_np(gnp.percentile(A, 30.0)), np.percentile(a, 30.0), rtol=1e-12)
     np.testing.assert_allclose(gnp.to_np(gnp.cov(A)), np.cov(a), rtol=1e-12)
     np.testing.assert_allclose(gnp.to_np(gnp.norm(A)), np.linalg.norm(a), rtol=1e-13)
+    for kw in ({"axis": 0}, {"axis": 1}, {"ord": 1, "axis": 1}, {"ord": np.inf, "axis": 0}, {"ord": 1}, {"ord": "fro"}):
+        np.testing.assert_allclose(gnp.to_np(gnp.norm(A, **kw)), np.linalg.norm(a, **kw), rtol=1e-13, err_msg=str(kw))
+    np.testing.assert_allclose(gnp.to_np(gnp.norm(A[0], 1)), np.linalg.norm(a[0], 1), rtol=1e-13)
+    sq = rng.standard_normal((9, 9))                                      # a general square matrix: the library's Jacobi SVD
+    for o in (2, -2, "nuc"):
+        np.testing.assert_allclose(gnp.to_np(gnp.norm(gnp.asarray(sq), o)), np.linalg.norm(sq, o), rtol=1e-12, err_msg=str(o))
+    np.testing.assert_allclose(gnp.to_np(gnp.cond(gnp.asarray(sq))), np.linalg.cond(sq), rtol=1e-11)
+    np.testing.assert_allclose(gnp.to_np(gnp.cond(gnp.asarray(sq), 1)), np.linalg.cond(sq, 1), rtol=1e-11)
+    big, rhs = rng.standard_normal((300, 300)) + 20 * np.eye(300), rng.standard_normal((300, 2))
+    np.testing.assert_allclose(gnp.to_np(gnp.solve(gnp.asarray(big), gnp.asarray(rhs))), np.linalg.solve(big, rhs), rtol=1e-10)
     np.testing.assert_allclose(gnp.to_np(gnp.clip(A, -0.5, 0.5)), np.clip(a, -0.5, 0.5))
     np.testing.assert_allclose(gnp.to_np(gnp.transpose(A, 0, 1)), a.T)
     np.testing.assert_allclose(gnp.to_np(gnp.tile(gnp.asarray(a[0]), 3)), np.tile(a[0], 3))
