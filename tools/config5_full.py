@@ -188,6 +188,20 @@ def single(a):
         out["grad_value"], out["grad"] = val, crit.gradient_from_state(state)
         sec["value_and_grad"] = sync() - t6
         log(f"single: ML value + gradient at n={a.grad_n}: {sec['value_and_grad']:.2f} s; value {val!r}")
+        del crit, state
+        torch.cuda.empty_cache()
+        # leave-one-out at the same size: zero mean, and with a linear mean (1, x_1 .. x_8) through the Schur form (gpmp/core/loo.py:65-130)
+        from gpmp_amd.core.loo import loo as loo_single
+
+        t7 = sync()
+        lin = lambda xx, prm: gnp.hstack((gnp.ones((xx.shape[0], 1)), gnp.asarray(xx)))      # noqa: E731
+        for tag, mdl in (("zero", gp.Model(None, cov, None, th2, "zero")), ("lin", gp.Model(lin, cov, None, th2, "linear_predictor"))):
+            zl, s2, el = loo_single(mdl, gnp.asarray(gx), gnp.asarray(gz))
+            out[f"loo_{tag}_z"], out[f"loo_{tag}_s2"], out[f"loo_{tag}_e"] = gnp.to_np(zl), gnp.to_np(s2), gnp.to_np(el)
+            del zl, s2, el
+            torch.cuda.empty_cache()
+        sec["loo_two_mean_types"] = sync() - t7
+        log(f"single: leave-one-out at n={a.grad_n}, zero mean + linear mean (two factorisations + inverse factors): {sec['loo_two_mean_types']:.2f} s")
     out["seconds"] = json.dumps(sec)
     np.savez(a.out, **out)
     log(f"single: wrote {a.out}")
@@ -286,6 +300,7 @@ def dist_body(rank, world, a, Cholesky, exchange):
     torch.cuda.empty_cache()
     # ---- value + gradient at grad_n
     val = grad = None
+    loo_parts = {}
     if a.grad_n:
         gn = a.grad_n
         th2 = np.concatenate(([theta[0], math.log(NOISE)], theta[1:]))
@@ -298,15 +313,21 @@ def dist_body(rank, world, a, Cholesky, exchange):
         val, grad = chg.value_and_grad(x[:gn], z[:gn], th2, 2, noise=True)
         t6 = tick()
         sec["grad_factor"], sec["value_and_grad"] = t5 - t4, t6 - t5
-        received += chg.bytes_received
         say(f"n={gn}: factor (info {ginfo}) {sec['grad_factor']:.1f} s, ML value + gradient {sec['value_and_grad']:.1f} s")
+        # leave-one-out on the same distributed factor: zero mean, linear mean (each forms T = L^-1 in the block-cyclic layout)
+        Plin = np.hstack((np.ones((gn, 1)), x[:gn]))
+        loo_parts = {"zero": chg.loo(z[:gn]), "lin": chg.loo(z[:gn], P=Plin)}
+        t7 = tick()
+        sec["loo_two_mean_types"] = t7 - t6
+        say(f"n={gn}: leave-one-out, zero mean + linear mean (two distributed inverse factors): {sec['loo_two_mean_types']:.1f} s")
+        received += chg.bytes_received
         del chg
     import threading
 
     rec = {"rank": rank, "pid": os.getpid(), "thread": threading.get_ident() if a.threads else None, "coords": (grid.r, grid.c), "local_matrix": local_shape, "GB_received": received / 1e9,
            "device": getattr(a, "device_name", None) or torch.cuda.get_device_name(torch.cuda.current_device()),
            "peak_GB_allocated": torch.cuda.max_memory_allocated(torch.cuda.current_device()) / 1e9}
-    parts = exchange((rec, ri[rsel], ci[csel], Lloc, (j0, j1), grid.r, mean, var, lam_rows, (u0, u1), uk_mean, uk_var))
+    parts = exchange((rec, ri[rsel], ci[csel], Lloc, (j0, j1), grid.r, mean, var, lam_rows, (u0, u1), uk_mean, uk_var, loo_parts if grid.r == 0 else {}))
     if rank == 0:
         Ls = np.full((len(rows_np), len(cols_np)), np.nan)
         zpm, zpv = np.full(m, np.nan), np.full(m, np.nan)
@@ -315,7 +336,10 @@ def dist_body(rank, world, a, Cholesky, exchange):
         rpos = {int(g): i for i, g in enumerate(rows_np)}
         cpos = {int(g): i for i, g in enumerate(cols_np)}
         recs = []
-        for (rc, gr, gc, blk, (b0, b1), r_, mu, vv, lr, (c0, c1), um, uv) in parts:
+        loo_full = {f"loo_{tag}_{w}": np.full(a.grad_n, np.nan) for tag in ("zero", "lin") for w in ("z", "s2", "e")} if a.grad_n else {}
+        for (rc, gr, gc, blk, (b0, b1), r_, mu, vv, lr, (c0, c1), um, uv, lp) in parts:
+            for tag, (zl, s2l, el, idx) in lp.items():              # one rank per process column reports its column set
+                loo_full[f"loo_{tag}_z"][idx], loo_full[f"loo_{tag}_s2"][idx], loo_full[f"loo_{tag}_e"][idx] = zl, s2l, el
             if c1 > c0:
                 ukm[c0:c1], ukv[c0:c1] = um, uv
             recs.append(rc)
@@ -328,6 +352,7 @@ def dist_body(rank, world, a, Cholesky, exchange):
                     lam_s[np.ix_(ir, np.arange(b0, b1))] = lr
         np.savez(a.dist_out, info=info, nll=nll, logdet=logdet, reml=reml, uk_mean=ukm, uk_var=ukv, L_sample=Ls, mean=zpm, var=zpv, lam_sample=lam_s,
                  grad_value=np.nan if val is None else val, grad=np.zeros(0) if grad is None else grad,
+                 **loo_full,
                  seconds=json.dumps(sec), phases=json.dumps(phases), ranks=json.dumps(recs))
         for rc in recs:
             who = f"pid {rc['pid']}" + (f" thread {rc['thread']}" if rc.get("thread") else "")
@@ -425,6 +450,12 @@ def compare(a):
         errs["grad_value_rel"] = abs(float(d["grad_value"]) - float(s["grad_value"])) / abs(float(s["grad_value"]))
         errs["grad_rel"] = float(np.max(np.abs(g1 - g0)) / np.max(np.abs(g0)))
         tol.update(grad_value_rel=1e-11 * cs, grad_rel=1e-7)
+        # leave-one-out (rel 1e-8 at cond <= 1e6): predictions on the scale of z, variances and errors relative to their largest value
+        for tag in ("zero", "lin"):
+            errs[f"loo_{tag}_z_abs"] = float(np.max(np.abs(d[f"loo_{tag}_z"] - s[f"loo_{tag}_z"])))
+            errs[f"loo_{tag}_s2_rel"] = float(np.max(np.abs(d[f"loo_{tag}_s2"] - s[f"loo_{tag}_s2"])) / np.max(np.abs(s[f"loo_{tag}_s2"])))
+            errs[f"loo_{tag}_e_rel"] = float(np.max(np.abs(d[f"loo_{tag}_e"] - s[f"loo_{tag}_e"])) / np.max(np.abs(s[f"loo_{tag}_e"])))
+            tol.update({f"loo_{tag}_z_abs": 1e-8 * cs * zs, f"loo_{tag}_s2_rel": 1e-8 * cs, f"loo_{tag}_e_rel": 1e-8 * cs})
     ok = errs["info"] == 0 and bool(np.isfinite(d["mean"]).all() and np.isfinite(d["lam_sample"]).all()) and all(errs[k] <= t for k, t in tol.items())
     log("single-GPU seconds: " + str(s["seconds"]))
     log(f"distributed seconds (max-synchronised phases, ranks sharing ONE GPU, {'thread-ranks' if a.threads else 'over gloo'}): " + str(d["seconds"]))
