@@ -5,11 +5,12 @@ Two sides, run one after the other (each side alone fits the 288 GB of one MI355
 
   single   the single-GPU product path at n = 131072: lower-triangle Gram build (K = 137 GB), gpmp_potrf_lower_async in place,
            log-determinant, NLL, (L L^T - K) on sampled rows, one zero-mean prediction with the kriging weights at a few thousand
-           points, cond(K) by power / inverse iteration; and ML value + gradient at the largest n the DISTRIBUTED gradient fits
-           on a shared GPU (--grad-n).  Results -> an .npz.
+           points, cond(K) by power / inverse iteration, REML and universal kriging with a constant mean; and ML value + gradient
+           and leave-one-out (zero mean, linear mean) at the largest n the DISTRIBUTED gradient fits on a shared GPU (--grad-n).
+           Results -> an .npz.
   dist     the real BlockCyclicCholesky (gpmp_amd/dist/cholesky.py: the schedule, streams and kernels of the 8-GPU run) with the
-           ranks SHARING the GPU over gloo: local Gram, factor, NLL, prediction (+ weights: the backward solve), then value +
-           gradient at --grad-n; compared with the .npz of ``single``.
+           ranks SHARING the GPU over gloo: local Gram, factor, NLL, prediction (+ weights: the backward solve), REML, universal
+           kriging, then value + gradient and leave-one-out at --grad-n; compared with the .npz of ``single``.
 
 The pool's process guard allows at most SIX processes on the card, so with one PROCESS per rank the grid is 2 x 3 (six ranks,
 22.9 GB of local matrix each).  ``--threads`` runs the ranks as THREADS of one process instead (tools/thread_ranks.py: every rank has
@@ -20,7 +21,8 @@ The gradient's working set (factor + T + the neighbour's T + one block of T^T T 
 n = 131072 that is 500 GB over the ranks -- it needs the eight GPUs -- so the value + gradient is compared at --grad-n.
 
 What is checked is what the reference computes at gpmp/num/numpy_backend.py:465-469 (cholesky_solve) and
-gpmp/core/likelihood.py:18-52 (the zero-mean NLL); gpmp/core/kriging.py:35-67 (mean / variance / weights).
+gpmp/core/likelihood.py:18-52 (the zero-mean NLL), :92-129 (REML); gpmp/core/kriging.py:35-67 (mean / variance / weights), :105-200
+(universal kriging); gpmp/core/loo.py:65-130 (leave-one-out).
 
     python tools/config5_full.py all                                   # both sides + comparison ("CONFIG5 FULL OK"), 2 x 3 processes over gloo
     python tools/config5_full.py all --threads --grid 2x4              # the same on the 2 x 4 grid, eight thread-ranks in one process
