@@ -685,6 +685,7 @@ extern "C" int gpmp_scaled_distance(const double* x, const double* y, int n, int
                                     gpmp_stream_t stream) {
   GPMP_ARG(x != nullptr && y != nullptr, 1, "x or y is NULL");
   GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 5, "d outside [1, GPMP_MAX_DIM]");
+  GPMP_ARG(loginvrho_host != nullptr, 6, "loginvrho is NULL");
   GPMP_ARG(D != nullptr && ldd >= m, 7, "D is NULL or ldd < m");
   if (n <= 0 || m <= 0) return 0;
   GramParams gp;
@@ -708,6 +709,7 @@ extern "C" int gpmp_matern_pairwise(const double* x, const double* y, int n, int
   GPMP_ARG(x != nullptr, 1, "x is NULL");
   GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 4, "d outside [1, GPMP_MAX_DIM]");
   GPMP_ARG(p >= 0 && p <= GPMP_MAX_P, 5, "p outside [0, GPMP_MAX_P]");
+  GPMP_ARG(theta_host != nullptr, 6, "theta is NULL");
   GPMP_ARG(out != nullptr, 8, "out is NULL");
   if (n <= 0) return 0;
   PairParams pp;
@@ -887,6 +889,7 @@ extern "C" int gpmp_matern_grad_trace(const double* Kinv, long ldk, const double
   GPMP_ARG(n >= 1, 4, "n < 1");
   GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 5, "d outside [1, GPMP_MAX_DIM]");
   GPMP_ARG(p >= 0 && p <= GPMP_MAX_P, 6, "p outside [0, GPMP_MAX_P]");
+  GPMP_ARG(theta_host != nullptr, 7, "theta is NULL");
   GPMP_ARG(r >= 0 && r <= GPMP_MAX_RANK, 11, "r outside [0, GPMP_MAX_RANK]");
   GPMP_ARG(r == 0 || (F != nullptr && G != nullptr), 9, "F/G NULL with r > 0");
   GPMP_ARG(g_dev != nullptr && ws != nullptr, 13, "g or ws is NULL");

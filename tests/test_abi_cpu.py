@@ -124,3 +124,82 @@ def test_dist_layout_queries_match_the_block_cyclic_definition():
     assert lib.gpmp_dist_local_shape(100, 100, 1, 1, 0, 0, None, None) < 0 and lib.gpmp_last_error()
     assert lib.gpmp_dist_exchange_rows(1000, 128, 2, 2, 0, 5, 0) < 0
     assert lib.gpmp_dist_diag_msg_elems(1024) == 1024 * 1024 + 8 * 128 * 128 + 1 and lib.gpmp_dist_diag_msg_elems(200) == 200 * 208 + 2 * 128 * 128 + 1
+
+
+_NULL_PROBE = r'''
+import ctypes, sys
+sys.path.insert(0, sys.argv[1])
+from gpmp_amd import _lib
+lib = _lib.load()
+deep = sys.argv[2] == "deep"
+ints = sys.argv[2] == "ints"
+not_compute = {"gpmp_hip_abi_version", "gpmp_last_error", "gpmp_profile_begin", "gpmp_profile_begin_kinds", "gpmp_profile_end",
+               "gpmp_stream_create_reserving_cus", "gpmp_stream_destroy", "gpmp_stream_release", "gpmp_hint_machine_busy",
+               "gpmp_device_release", "gpmp_device_state_count", "gpmp_debug_device_table_selftest", "gpmp_coldots_ws_rows",
+               "gpmp_dist_exchange_rows"}
+dummies = []
+calls = 0
+for name, (res, args) in _lib.SIGNATURES.items():
+    if name in not_compute or res is not ctypes.c_int:
+        continue
+    ptr_pos = [i for i, a in enumerate(args) if a is ctypes.c_void_p]
+    # all: every pointer NULL; deep: one NULL at a time (the last pointer is the stream); ints: every size / leading dimension /
+    # index in turn negative, zero and huge, all pointers at host scratch
+    if ints:
+        cases = [(set(), i, v) for i, a in enumerate(args) if a in (ctypes.c_int, ctypes.c_long)
+                 for v in ((-1, 0, 2 ** 31 - 1) if a is ctypes.c_int else (-1, 0, 2 ** 62))]
+    else:
+        cases = [(set(ptr_pos), -1, 0)] if not deep else [({i}, -1, 0) for i in ptr_pos[:-1]]
+    for nulls, ipos, ival in cases:
+        vals = []
+        for i, a in enumerate(args):
+            if a is ctypes.c_void_p:
+                if i in nulls:
+                    vals.append(None)
+                else:
+                    buf = (ctypes.c_double * 8192)()
+                    dummies.append(buf)
+                    vals.append(ctypes.cast(buf, ctypes.c_void_p))
+            elif a is ctypes.c_double:
+                vals.append(1.0)
+            elif i == ipos:
+                vals.append(ival)
+            elif a is ctypes.c_long:
+                vals.append(256)
+            else:
+                vals.append(2)
+        rc = getattr(lib, name)(*vals)
+        calls += 1
+        if rc > 0 or (not ints and (rc == 0 or not lib.gpmp_last_error())):     # (ints: an empty problem may be a no-op, status 0)
+            print("NOT REJECTED", name, sorted(nulls), ipos, ival, rc)
+            sys.exit(1)
+print("REJECTED", calls)
+'''
+
+
+def _run_null_probe(mode):
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, "-c", _NULL_PROBE, ROOT, mode], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "REJECTED" in r.stdout and "NOT REJECTED" not in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    return int(r.stdout.split()[-1])
+
+
+def test_every_compute_entry_point_rejects_null_operands():
+    """all pointers NULL, positive sizes: every compute entry point of the header returns a negative status with a message -- no
+    dereference, no launch (run in a child process: a crash would be a finding, not the end of the test session)"""
+    assert _run_null_probe("all") >= 35
+
+
+def test_one_null_operand_at_a_time_is_rejected_without_a_device():
+    """every pointer position NULL in turn, the others pointing at host scratch: still a negative status (an argument error, or
+    'no device' from the first HIP call).  Only meaningful -- and only safe -- without a GPU: on a GPU box host scratch passed as a
+    device operand could be launched on."""
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present: host scratch must not be handed to kernels")
+    assert _run_null_probe("deep") >= 140
+    # ... and every integer argument in turn negative, zero and huge: a status <= 0, never a crash or a host loop over a bad count
+    assert _run_null_probe("ints") >= 600
