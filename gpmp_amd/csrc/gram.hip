@@ -887,11 +887,12 @@ extern "C" int gpmp_matern_grad_trace(const double* Kinv, long ldk, const double
   GPMP_ARG(Kinv != nullptr, 1, "Kinv is NULL");
   GPMP_ARG(x != nullptr, 3, "x is NULL");
   GPMP_ARG(n >= 1, 4, "n < 1");
+  GPMP_ARG(ldk >= n, 2, "ldk < n");
   GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 5, "d outside [1, GPMP_MAX_DIM]");
   GPMP_ARG(p >= 0 && p <= GPMP_MAX_P, 6, "p outside [0, GPMP_MAX_P]");
   GPMP_ARG(theta_host != nullptr, 7, "theta is NULL");
   GPMP_ARG(r >= 0 && r <= GPMP_MAX_RANK, 11, "r outside [0, GPMP_MAX_RANK]");
-  GPMP_ARG(r == 0 || (F != nullptr && G != nullptr), 9, "F/G NULL with r > 0");
+  GPMP_ARG(r == 0 || (F != nullptr && G != nullptr && ldf >= r), 9, "F/G NULL or ldf < r with r > 0");
   GPMP_ARG(g_dev != nullptr && ws != nullptr, 13, "g or ws is NULL");
   GradParams gp;
   gp.pp = nullptr;
@@ -948,7 +949,7 @@ extern "C" int gpmp_matern_grad_trace_cross(const double* M, long ldm, const dou
   GPMP_ARG(p >= 0 && p <= GPMP_MAX_P, 8, "p outside [0, GPMP_MAX_P]");
   GPMP_ARG(theta_host != nullptr, 9, "theta is NULL");
   GPMP_ARG(r >= 0 && r <= GPMP_MAX_RANK, 13, "r outside [0, GPMP_MAX_RANK]");
-  GPMP_ARG(r == 0 || (F != nullptr && G != nullptr), 11, "F/G NULL with r > 0");
+  GPMP_ARG(r == 0 || (F != nullptr && G != nullptr && ldf >= r), 11, "F/G NULL or ldf < r with r > 0");
   GPMP_ARG(g_dev != nullptr && ws != nullptr, 15, "g or ws is NULL");
   GradParams gp;
   gp.pp = nullptr;

@@ -173,6 +173,33 @@ for name, (res, args) in _lib.SIGNATURES.items():
         if rc > 0 or (not ints and (rc == 0 or not lib.gpmp_last_error())):     # (ints: an empty problem may be a no-op, status 0)
             print("NOT REJECTED", name, sorted(nulls), ipos, ival, rc)
             sys.exit(1)
+if sys.argv[2] == "lds":
+    # every leading dimension in turn SMALLER than the extent it strides over (4 against 12 rows / columns; the others 4096): an
+    # ARGUMENT error, i.e. caught by the entry point's own checks before anything reaches HIP
+    calls = 0
+    for name, (res, args) in _lib.SIGNATURES.items():
+        if name in not_compute or res is not ctypes.c_int or name == "gpmp_maternp_kernel":      # (its long is an element count)
+            continue
+        for pos, a0 in enumerate(args):
+            if a0 is not ctypes.c_long:
+                continue
+            vals = []
+            for i, a in enumerate(args):
+                if a is ctypes.c_void_p:
+                    buf = (ctypes.c_double * 8192)()
+                    dummies.append(buf)
+                    vals.append(ctypes.cast(buf, ctypes.c_void_p))
+                elif a is ctypes.c_double:
+                    vals.append(1.0)
+                elif a is ctypes.c_long:
+                    vals.append(4 if i == pos else 4096)
+                else:
+                    vals.append(128 if name.startswith("gpmp_dist") and i in (3, 4) else 12)
+            rc = getattr(lib, name)(*vals)
+            calls += 1
+            if rc >= 0 or b"argument" not in lib.gpmp_last_error():
+                print("NOT REJECTED", name, pos, rc, lib.gpmp_last_error())
+                sys.exit(1)
 print("REJECTED", calls)
 '''
 
@@ -203,3 +230,5 @@ def test_one_null_operand_at_a_time_is_rejected_without_a_device():
     assert _run_null_probe("deep") >= 140
     # ... and every integer argument in turn negative, zero and huge: a status <= 0, never a crash or a host loop over a bad count
     assert _run_null_probe("ints") >= 600
+    # ... and every leading dimension in turn too small for its matrix: an argument error from the entry point's own checks
+    assert _run_null_probe("lds") >= 45
