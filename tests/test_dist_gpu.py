@@ -725,6 +725,48 @@ def test_every_entry_point_on_the_stream_ordered_fabric(pr, pc, delay_cycles, fa
         assert mo["fit_last"] < mo["fit_first"]
 
 
+def test_stream_ordered_fabric_random_soak():
+    """Opt-in soak (GPMP_DIST_SOAK_CASES=<count>, GPMP_DIST_SOAK_SEED): random draws of grid (up to nine thread-ranks), size, block size,
+    look-ahead and message delay -- including sizes so small that ranks hold no block at all, and sizes one off a multiple of the block
+    -- each through every entry point of the test above, against the oracle.  The suite itself runs none (the cases above are fixed)."""
+    import time
+    import traceback
+
+    ncases = int(os.environ.get("GPMP_DIST_SOAK_CASES", "0"))
+    if ncases <= 0:
+        pytest.skip("opt-in: GPMP_DIST_SOAK_CASES=<count>")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    rng = np.random.default_rng(int(os.environ.get("GPMP_DIST_SOAK_SEED", "5")))
+    grids = [(1, 1), (1, 2), (2, 1), (2, 2), (1, 3), (3, 1), (2, 3), (3, 2), (1, 5), (5, 1), (2, 4), (4, 2), (1, 7), (1, 8), (8, 1), (3, 3)]
+    failures = []
+    for i in range(ncases):
+        pr, pc = grids[int(rng.integers(len(grids)))]
+        nb = int(rng.choice([128, 256, 512, 1024]))
+        kind = int(rng.integers(4))
+        if kind == 0:            # fewer blocks than process rows / columns: ranks without a block
+            n = int(rng.integers(40, nb * max(1, min(pr, pc)) + 2))
+        elif kind == 1:          # a multiple of the block size (+- 1)
+            n = nb * int(rng.integers(1, max(2, 2600 // nb))) + int(rng.integers(-1, 2))
+        else:
+            n = int(rng.integers(300, 2600))
+        n = max(n, 12)
+        delay = int(rng.choice([0, 300_000, 2_000_000]))
+        kw = {"_n": n, "_nb": nb}
+        if rng.random() < 0.25:
+            kw["lookahead"] = False
+        t0 = time.perf_counter()
+        try:
+            test_every_entry_point_on_the_stream_ordered_fabric(pr, pc, delay, kw)
+            status = "ok"
+        except Exception:  # noqa: BLE001 -- the soak reports every failing draw, not the first
+            status = "FAILED"
+            failures.append((i, pr, pc, n, nb, delay, kw, traceback.format_exc()[-1200:]))
+        print(f"[soak {i:3d}] grid {pr}x{pc} n={n} nb={nb} delay={delay} {'no look-ahead ' if 'lookahead' in kw else ''}"
+              f"{time.perf_counter() - t0:5.1f} s {status}", flush=True)
+    assert not failures, failures
+
+
 def test_stream_ordered_fabric_detects_a_missing_stream_dependency():
     """(round 5) mutation test of the evidence itself (tools/stream_order_mutation_probe.py): with the waits of the bulk stream, or of
     the side stream, removed from the schedule, the stream-ordered fabric must give a WRONG factorisation on the 2 x 4 grid (and the
