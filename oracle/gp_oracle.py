@@ -410,8 +410,11 @@ def maternp_dkernel_over_h(p, h):
     for k in range(p + 1):
         r[k] = ((k + 1) * q[k + 1] if k + 1 <= p else 0.0) - 0.5 * q[k]
     if p == 0:
+        # K = exp(-c h) is not differentiable at h = 0; the reference's autograd route goes through torch.cdist
+        # (gpmp/num/torch_backend.py:810-820), whose backward gives a coincident pair (the diagonal) the subgradient 0 -- pinned by
+        # the reference's own gradient at p = 0 in tests/golden/ref_gradients_p0.npz
         with np.errstate(divide="ignore", invalid="ignore"):
-            return 2.0 * c * np.exp(-t / 2) * r[0] / h
+            return np.where(h > 0.0, 2.0 * c * np.exp(-t / 2) * r[0] / h, 0.0)
     # r_0 = q_1 - 1/2 = 0 for p >= 1; divide r(t) by t analytically: r(t)/t = sum_{k>=1} r_k t^{k-1}
     s = np.zeros_like(t)
     for k in range(p, 0, -1):

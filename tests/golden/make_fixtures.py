@@ -7,6 +7,7 @@ Run in the build container only (the reference does not travel to the GPU box):
         GPMP_BACKEND=numpy python3 /root/repo/tests/golden/make_fixtures.py numpy
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg PYTHONPATH=/root/reference \
         GPMP_BACKEND=torch python3 /root/repo/tests/golden/make_fixtures.py torch
+    (single files: ... make_fixtures.py torch batch | torch gradients_p0 | numpy cpd | numpy remap_extra | numpy dataloader | numpy namespace)
 
 The "numpy" pass pins values (Matern, covariance, predict, NLL, REML, LOO, init guess,
 example02 flow) with the reference's NumPy backend -- the parity target named by
@@ -485,6 +486,39 @@ def gen_batch_criterion():
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
+def gen_gradients_p0():
+    """The exponential kernel (p = 0) is not differentiable at coincident points; what the reference's autograd route returns there
+    (torch.cdist backward: subgradient 0 on the diagonal) is part of the behaviour to match: ML / REML values + autograd gradients at
+    p = 0, plain and noisy kernel.  Own file (ref_gradients_p0.npz), own seed: the other gradient fixtures are unchanged."""
+    import torch
+
+    out = {}
+    rng = np.random.default_rng(44)
+    for tag, (n, d), noisy in (("p0a", (90, 3), False), ("p0b", (200, 5), False), ("p0n", (120, 2), True)):
+        xi, zi = make_xz(n, d, 45, noise=0.05 if noisy else 0.0)
+        out[f"grad_{tag}_xi"], out[f"grad_{tag}_zi"], out[f"grad_{tag}_p"] = xi, zi, np.array(0)
+        k = make_noisy_kernel(0) if noisy else make_kernel(0)
+        base = np.concatenate(([0.0, np.log(0.05 ** 2)], theta_aniso(d)[1:])) if noisy else theta_aniso(d)
+        thetas = np.stack([base + 0.2 * rng.standard_normal(base.size) for _ in range(3)])
+        out[f"grad_{tag}_thetas"] = thetas
+        mz = gp.core.Model(None, k, None, None, "zero")
+        mc = gp.core.Model(constant_mean, k, None, None, "linear_predictor")
+        ml = gp.core.Model(linear_mean, k, None, None, "linear_predictor")
+        for name, model, crit_fn in (("nll", mz, gp.kernel.negative_log_likelihood_zero_mean),
+                                     ("reml_const", mc, gp.kernel.negative_log_restricted_likelihood),
+                                     ("reml_lin", ml, gp.kernel.negative_log_restricted_likelihood)):
+            _, pre, _, grad = gp.kernel.make_selection_criterion_with_gradient(model, crit_fn, xi, zi)
+            vals, grads = [], []
+            for t in thetas:
+                tt = torch.as_tensor(t, dtype=torch.float64)
+                vals.append(float(pre(tt)))
+                grads.append(tonp(grad(tt)))
+            out[f"grad_{tag}_{name}_val"], out[f"grad_{tag}_{name}_grad"] = np.array(vals), np.stack(grads)
+    path = os.path.join(HERE, "ref_gradients_p0.npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
 def gen_dataloader(out):
     """examples/gpmp_example30_dataloader.py flow at small size: Dataset / DataLoader (no shuffle), loader-based initial
     guess, REMAP selection through the batch criterion (NumPy backend: finite-difference jacobian)."""
@@ -541,5 +575,7 @@ if __name__ == "__main__":
         numpy_pass()
     elif len(sys.argv) > 2 and sys.argv[2] == "batch":
         gen_batch_criterion()
+    elif len(sys.argv) > 2 and sys.argv[2] == "gradients_p0":        # (torch backend)
+        gen_gradients_p0()
     else:
         torch_pass()

@@ -110,6 +110,21 @@ def test_value_and_gradient_driver_noisy_kernel(env, golden, tag):
             assert rel_err(gr, g[f"grad_{tag}_{name}_grad"][i]) < 1e-7, (name, i)
 
 
+@pytest.mark.parametrize("tag", ["p0a", "p0b", "p0n"])
+def test_value_and_gradient_driver_exponential_kernel(env, golden, tag):
+    """p = 0 against the reference's autograd (ref_gradients_p0.npz): coincident points contribute the subgradient 0"""
+    g = golden("gradients_p0")
+    xi, zi, p = g[f"grad_{tag}_xi"], g[f"grad_{tag}_zi"], int(g[f"grad_{tag}_p"])
+    nz = int(tag == "p0n")
+    calls = {"nll": _Call(env, xi, zi, None, p, noise=nz), "reml_const": _Call(env, xi, zi, constant_mean(xi, None), p, noise=nz),
+             "reml_lin": _Call(env, xi, zi, linear_mean(xi, None), p, noise=nz)}
+    for i, t in enumerate(g[f"grad_{tag}_thetas"]):
+        for name, c in calls.items():
+            v, gr, info = c.value_grad(t)
+            assert info == 0 and abs(v - g[f"grad_{tag}_{name}_val"][i]) < 1e-9 * abs(v), (name, i)
+            assert rel_err(gr, g[f"grad_{tag}_{name}_grad"][i]) < 1e-7, (name, i)
+
+
 @pytest.mark.parametrize("tag", ["s", "m", "p3"])
 def test_loo_driver_vs_reference(env, golden, tag):
     g = golden("predict")
@@ -282,3 +297,76 @@ def test_mean_drivers_small_and_boundary_sizes_vs_oracle(env, n, d, q):
     (zl, s2, el), info = c.loo(th)
     ozl, os2, oel = orc.loo(om, x, z)
     assert info == 0 and rel_err(zl, ozl) < 1e-8 and rel_err(s2, os2) < 1e-8 and rel_err(el, oel) < 1e-8
+
+
+def test_fused_drivers_random_soak(env):
+    """Opt-in soak (GPMP_DRIVER_SOAK_CASES=<count>, GPMP_DRIVER_SOAK_SEED): the fused C-ABI drivers -- gpmp_reml, gpmp_nll_grad,
+    gpmp_loo, gpmp_predict_mean / gpmp_predict_zero_mean -- on random draws of n (q + 2 ... 1500, one off the 128-column blocks now and
+    then), m (0 ... 1500), d (1 ... 8), p (0 ... 4), q (0 ... 9 columns of [1, x, x^2]) with a 1e-3 noise variance (cond(K) <= ~1e6:
+    the SURVEY 8(c) tolerances apply unscaled), each against the oracle."""
+    import math
+    import os
+
+    from oracle import gp_oracle as orc
+
+    ncases = int(os.environ.get("GPMP_DRIVER_SOAK_CASES", "0"))
+    if ncases <= 0:
+        pytest.skip("opt-in: GPMP_DRIVER_SOAK_CASES=<count>")
+    torch, gnp, _lib, lib = env
+    dev = gnp._dev()
+    rng = np.random.default_rng(int(os.environ.get("GPMP_DRIVER_SOAK_SEED", "5")))
+    bad = []
+    for i in range(ncases):
+        d = int(rng.integers(1, 9))
+        p = int(rng.integers(0, 5))
+        q = min(int(rng.choice([0, 0, 1, 2, 3, 5, 9])), 1 + 2 * d)
+        kind = int(rng.integers(3))
+        n = (int(rng.integers(q + 2, 60)) if kind == 0 else 128 * int(rng.integers(1, 11)) + int(rng.integers(-1, 2)) if kind == 1
+             else int(rng.integers(60, 1500)))
+        m = int(rng.choice([0, 1, 2, 127, 128, 129, int(rng.integers(1, 1500))]))
+        x, xt = rng.random((n, d)), rng.random((m, d))
+        z = np.sin(3 * x[:, 0]) + x.sum(axis=1) + 0.05 * rng.standard_normal(n)
+        th = np.concatenate(([0.3 * rng.standard_normal(), math.log(1e-3)], -np.log(0.3 + rng.random(d))))
+        design = lambda a, prm=None: np.hstack((np.ones((len(a), 1)), a, a * a))[:, :q]      # noqa: E731
+        P = None if q == 0 else design(x)
+        kern = lambda a, b, t, pairwise=False: orc.noisy_maternp_covariance(a, b, p, t, pairwise)  # noqa: E731
+        om = orc.OracleModel(None, kern, None, th, "zero") if q == 0 else orc.OracleModel(design, kern, None, th, "linear_predictor")
+        c = _Call(env, x, z, P, p, noise=1)
+        errs = {}
+        if q == 0:
+            rv, rg = orc.nll_zero_mean_value_and_grad(x, z, p, th, noise_index=1)
+        else:
+            rv, rg = orc.reml_value_and_grad(x, z, P, p, th, noise_index=1)
+            v, info = c.reml(th)
+            errs["reml"] = abs(v - rv) / max(1.0, abs(rv), float(n)) if info == 0 else math.inf
+        v2, g, info = c.value_grad(th)
+        # (the criterion is a sum of terms of size ~ n -- n log 2 pi, log|K|, the quadratic form -- that may cancel: scale by n, as
+        #  tests/test_random_sweep_gpu.py does)
+        errs["value"] = abs(v2 - rv) / max(1.0, abs(rv), float(n)) if info == 0 else math.inf
+        errs["grad"] = rel_err(g, rg)
+        (zl, s2, el), info = c.loo(th)
+        ozl, os2, oel = orc.loo(om, x, z)
+        errs["loo"] = max(rel_err(zl, ozl), rel_err(s2, os2), rel_err(el, oel)) if info == 0 else math.inf
+        if m > 0:
+            rm, rvv = orc.predict(om, x, z, xt, zero_neg_variances=False)[:2]
+            if q == 0:
+                t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)  # noqa: E731
+                X, Z, T = t(x), t(z), t(xt)
+                ws = torch.empty(int(lib.gpmp_predict_ws_elems(n, m)), dtype=torch.float64, device=dev)
+                zpm, zpv = torch.empty(m, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.float64, device=dev)
+                inf_ = torch.zeros(1, dtype=torch.int32, device=dev)
+                _lib.check(lib.gpmp_predict_zero_mean(gnp._ptr(X), gnp._ptr(Z), gnp._ptr(T), n, m, d, p, _lib.host_vec(th), 1, 0, gnp._ptr(ws),
+                                                      gnp._ptr(zpm), gnp._ptr(zpv), gnp._ptr(inf_), gnp._stream()), "gpmp_predict_zero_mean")
+                pm, pv, info = gnp.to_np(zpm), gnp.to_np(zpv), int(inf_.item())
+            else:
+                pm, pv, info = _predict_mean_call(env, x, z, P, xt, design(xt), th, p, noise=1, clamp=0)
+            zs = float(np.max(np.abs(z)))
+            errs["mean"] = float(np.max(np.abs(pm - rm))) / zs if info == 0 else math.inf
+            errs["var"] = float(np.max(np.abs(pv - rvv))) / math.exp(th[0]) if info == 0 else math.inf
+        tol = {"reml": 1e-11, "value": 1e-11, "grad": 1e-7, "loo": 1e-8, "mean": 1e-9, "var": 1e-9}
+        over = {k: v for k, v in errs.items() if not v <= tol[k]}
+        if over:
+            bad.append((i, n, m, d, p, q, over))
+        print(f"[driver soak {i:3d}] n={n} m={m} d={d} p={p} q={q}: " + " ".join(f"{k} {v:.1e}" for k, v in errs.items()) + (" FAILED" if over else ""),
+              flush=True)
+    assert not bad, bad

@@ -972,6 +972,27 @@ def test_gradients_noisy_kernel(gp, gnp, golden, tag):
             assert rel_err(gr, g[f"grad_{tag}_{name}_grad"][i]) < 1e-7
 
 
+@pytest.mark.parametrize("tag", ["p0a", "p0b", "p0n"])
+def test_gradients_exponential_kernel_vs_reference_autograd(gp, gnp, golden, tag):
+    """p = 0: the kernel is not differentiable at coincident points and the reference's autograd gives the diagonal the subgradient 0
+    (ref_gradients_p0.npz, generated by the reference) -- the analytic gradient must do the same, not return NaN"""
+    g = golden("gradients_p0")
+    xi, zi, p = g[f"grad_{tag}_xi"], g[f"grad_{tag}_zi"], int(g[f"grad_{tag}_p"])
+    k = gp.kernel.MaternCovariance(p, noise=(tag == "p0n"))
+    cases = (
+        ("nll", gp.Model(None, k, None, None, "zero"), gp.kernel.negative_log_likelihood_zero_mean),
+        ("reml_const", gp.Model(constant_mean, k, None, None), gp.kernel.negative_log_restricted_likelihood),
+        ("reml_lin", gp.Model(linear_mean, k, None, None), gp.kernel.negative_log_restricted_likelihood),
+    )
+    for name, model, crit in cases:
+        _, pre, _, grad = gp.kernel.make_selection_criterion_with_gradient(model, crit, xi, zi)
+        assert grad is not None
+        for i, t in enumerate(g[f"grad_{tag}_thetas"]):
+            v, gr = pre(t), grad(t)
+            assert np.all(np.isfinite(gr)) and abs(v - g[f"grad_{tag}_{name}_val"][i]) < 1e-9 * abs(v), (name, i)
+            assert rel_err(gr, g[f"grad_{tag}_{name}_grad"][i]) < 1e-7, (name, i)
+
+
 def test_dataloader_flow_example30(gp, gnp, golden):
     """examples/gpmp_example30_dataloader.py at small size: gpmp_amd.dataloader.Dataset / DataLoader, loader-based initial
     guesses, select_parameters_with_remap(dataloader=...) through the batch criterion"""
