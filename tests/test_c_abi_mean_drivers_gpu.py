@@ -315,14 +315,17 @@ def test_fused_drivers_random_soak(env):
     torch, gnp, _lib, lib = env
     dev = gnp._dev()
     rng = np.random.default_rng(int(os.environ.get("GPMP_DRIVER_SOAK_SEED", "5")))
+    wide = os.environ.get("GPMP_DRIVER_SOAK_WIDE", "0") == "1"
     bad = []
     for i in range(ncases):
-        d = int(rng.integers(1, 9))
-        p = int(rng.integers(0, 5))
+        if wide:                 # GPMP_DRIVER_SOAK_WIDE=1: the whole range the kernels accept (GPMP_MAX_DIM = 64, GPMP_MAX_P = 16), smaller n
+            d, p = int(rng.integers(1, 65)), int(rng.integers(0, 17))
+        else:
+            d, p = int(rng.integers(1, 9)), int(rng.integers(0, 5))
         q = min(int(rng.choice([0, 0, 1, 2, 3, 5, 9])), 1 + 2 * d)
         kind = int(rng.integers(3))
-        n = (int(rng.integers(q + 2, 60)) if kind == 0 else 128 * int(rng.integers(1, 11)) + int(rng.integers(-1, 2)) if kind == 1
-             else int(rng.integers(60, 1500)))
+        n = (int(rng.integers(q + 2, 60)) if kind == 0 else 128 * int(rng.integers(1, 11 if not wide else 4)) + int(rng.integers(-1, 2)) if kind == 1
+             else int(rng.integers(60, 1500 if not wide else 500)))
         m = int(rng.choice([0, 1, 2, 127, 128, 129, int(rng.integers(1, 1500))]))
         x, xt = rng.random((n, d)), rng.random((m, d))
         z = np.sin(3 * x[:, 0]) + x.sum(axis=1) + 0.05 * rng.standard_normal(n)
