@@ -847,6 +847,54 @@ def test_empty_prediction_set(gp, gnp):
     assert zpm.shape == (0,) and zpv.shape == (0,)
 
 
+def test_every_input_form_gives_the_same_results(gp, gnp):
+    """The input contract (gpmp/core/utils.py:19-81, numpy_backend.py:174-188: anything array-like -> an fp64 array): Fortran-ordered
+    and strided NumPy views, float32 arrays, a one-column zi, CPU and device tensors, NON-CONTIGUOUS device views -- every form must
+    give what the plain contiguous fp64 arrays give (the kernels read row-major memory through raw pointers: a view handed through
+    unchanged would be read with the wrong strides).  Plain lists are not part of the contract: the shape checks come first and
+    raise AttributeError on them, in the reference too (utils.py:57)."""
+    import torch
+
+    n, m, d = 300, 77, 3
+    rng = np.random.default_rng(8)
+    xi = np.round(rng.random((n, d)) * 64) / 64            # (exactly representable in float32: the float32 form is the same numbers)
+    xt = np.round(rng.random((m, d)) * 64) / 64
+    zi = np.round((np.sin(3 * xi[:, 0]) + xi.sum(axis=1)) * 256) / 256
+    th = theta_aniso(d)
+    dev = gnp._dev()
+
+    def run(a, b, c):
+        out = []
+        for model in (gp.Model(None, gp.kernel.MaternCovariance(2), None, th, "zero"),
+                      gp.Model(linear_mean, gp.kernel.MaternCovariance(2), None, th, "linear_predictor")):
+            zpm, zpv = model.predict(a, b, c)
+            nll = model.negative_log_likelihood_zero_mean(th, a, b) if model.meantype == "zero" else model.negative_log_restricted_likelihood(th, a, b)
+            zl, s2, el = model.loo(a, b)
+            out.append([np.asarray(gnp.to_np(v), dtype=float).reshape(-1) for v in (zpm, zpv, nll, zl, s2, el)])
+        return out
+
+    ref = run(xi, zi, xt)
+    wide_i, wide_t = torch.as_tensor(np.hstack((xi, xi)), device=dev), torch.as_tensor(np.repeat(xt, 2, axis=0), device=dev)
+    forms = {
+        "fortran order": (np.asfortranarray(xi), zi, np.asfortranarray(xt)),
+        "strided numpy views": (np.hstack((xi, xi))[:, :d], np.repeat(zi, 2)[::2], np.repeat(xt, 2, axis=0)[::2]),
+        "float32": (xi.astype(np.float32), zi.astype(np.float32), xt.astype(np.float32)),
+        "one-column zi": (xi, zi.reshape(-1, 1), xt),
+        "cpu tensors": (torch.as_tensor(xi), torch.as_tensor(zi), torch.as_tensor(xt)),
+        "device tensors": (torch.as_tensor(xi, device=dev), torch.as_tensor(zi, device=dev), torch.as_tensor(xt, device=dev)),
+        "non-contiguous device views": (wide_i[:, :d], torch.as_tensor(np.repeat(zi, 2), device=dev)[::2], wide_t[::2]),
+        "transposed device storage": (torch.as_tensor(np.ascontiguousarray(xi.T), device=dev).T, torch.as_tensor(zi, device=dev),
+                                      torch.as_tensor(np.ascontiguousarray(xt.T), device=dev).T),
+    }
+    with pytest.raises(AttributeError):
+        run(xi.tolist(), zi.tolist(), xt.tolist())
+    for name, (a, b, c) in forms.items():
+        got = run(a, b, c)
+        for mi in range(2):
+            for k, (g_, r_) in enumerate(zip(got[mi], ref[mi])):
+                assert g_.shape == r_.shape and np.array_equal(g_, r_), (name, mi, k, float(np.max(np.abs(g_ - r_))))
+
+
 # ------------------------------------------------------------------------------ likelihoods
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_likelihoods_vs_reference(gp, gnp, golden, tag):
