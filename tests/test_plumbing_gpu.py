@@ -222,3 +222,62 @@ def test_gemm_with_fitted_tile_width_vs_numpy(gnp, M, N, K):
     cols = np.concatenate((np.arange(0, 260), np.arange(N - 260, N), rng.choice(N, 300, replace=False)))
     ref = gnp.to_np(A) @ gnp.to_np(B)[:, cols]
     assert np.max(np.abs(C1[:, torch.as_tensor(cols, device=C1.device)].cpu().numpy() - ref)) < 1e-12 * np.sqrt(K) * 10
+
+
+def test_backend_functions_accept_strided_device_views(gnp):
+    """The dense-algebra names of the backend (cholesky, cholesky_solve, solve_triangular, matmul, coldots, scaled_distance, logdet,
+    inv, einsum) on every memory form a device tensor can take -- transposed storage, row- / column-strided views, a wider leading
+    dimension, strided vectors, a column of a matrix -- in every combination of their operands: the kernels read row-major memory
+    through raw pointers, so each form must be brought to that layout (or passed with its leading dimension) first."""
+    import itertools
+
+    import scipy.linalg as sla
+    import torch
+
+    dev = gnp._dev()
+    rng = np.random.default_rng(3)
+    n, m = 300, 70
+    A = rng.standard_normal((n, n)); K = A @ A.T / n + np.eye(n)
+    B = rng.standard_normal((n, m)); v = rng.standard_normal(n); x = rng.random((n, 3)); y = rng.random((m, 3))
+    def views(a):
+        t = torch.as_tensor(a, device=dev)
+        out = {"plain": t}
+        if a.ndim == 2:
+            out["transposed storage"] = torch.as_tensor(np.ascontiguousarray(a.T), device=dev).T
+            out["row-strided"] = torch.as_tensor(np.repeat(a, 2, axis=0), device=dev)[::2]
+            out["wider ld"] = torch.as_tensor(np.hstack((a, a)), device=dev)[:, :a.shape[1]]
+            out["col-strided"] = torch.as_tensor(np.repeat(a, 2, axis=1), device=dev)[:, ::2]
+        else:
+            out["strided"] = torch.as_tensor(np.repeat(a, 2), device=dev)[::2]
+            out["column of a matrix"] = torch.as_tensor(np.stack((a, a), axis=1), device=dev)[:, 0]
+        return out
+    L = np.linalg.cholesky(K)
+    checks = {
+      "cholesky": (lambda K_: np.tril(gnp.to_np(gnp.cholesky(K_))), [K], L),
+      "cholesky_solve": (lambda K_, B_: gnp.to_np(gnp.cholesky_solve(K_, B_)[0]) if isinstance(gnp.cholesky_solve(K_, B_), tuple) else gnp.to_np(gnp.cholesky_solve(K_, B_)), [K, B], np.linalg.solve(K, B)),
+      "cholesky_solve vec": (lambda K_, v_: (lambda r: gnp.to_np(r[0] if isinstance(r, tuple) else r))(gnp.cholesky_solve(K_, v_)), [K, v], np.linalg.solve(K, v)),
+      "solve_triangular": (lambda L_, B_: gnp.to_np(gnp.solve_triangular(L_, B_, lower=True)), [L, B], sla.solve_triangular(L, B, lower=True)),
+      "solve_triangular vec": (lambda L_, v_: gnp.to_np(gnp.solve_triangular(L_, v_, lower=True)), [L, v], sla.solve_triangular(L, v, lower=True)),
+      "solve_triangular upper": (lambda U_, B_: gnp.to_np(gnp.solve_triangular(U_, B_, lower=False)), [L.T.copy(), B], sla.solve_triangular(L.T, B, lower=False)),
+      "matmul": (lambda A_, B_: gnp.to_np(gnp.matmul(A_, B_)), [A, B], A @ B),
+      "matmul vec": (lambda A_, v_: gnp.to_np(gnp.matmul(A_, v_)), [A, v], A @ v),
+      "coldots": (lambda B_, v_: gnp.to_np(gnp.coldots(B_, v_.reshape(-1, 1))), [B, v], np.vstack((v @ B, np.sum(B * B, axis=0)))),
+      "scaled_distance": (lambda x_, y_: gnp.to_np(gnp.scaled_distance(np.zeros(3), x_, y_)), [x, y], np.sqrt(((x[:, None, :] - y[None, :, :]) ** 2).sum(-1))),
+      "logdet": (lambda K_: np.array(gnp.logdet(K_)), [K], np.linalg.slogdet(K)[1]),
+      "inv": (lambda K_: gnp.to_np(gnp.inv(K_)), [K], np.linalg.inv(K)),
+      "einsum": (lambda B_, C_: gnp.to_np(gnp.einsum("i..., i...", B_, C_)), [B, B], np.einsum("i..., i...", B, B)),
+    }
+    bad = []
+    for name, (fn, args, ref) in checks.items():
+        vs = [views(a) for a in args]
+        for combo in itertools.product(*[list(v.items()) for v in vs]):
+            label = ", ".join(k for k, _ in combo)
+            try:
+                got = fn(*[t for _, t in combo])
+                err = float(np.max(np.abs(np.asarray(got) - ref)) / max(1.0, np.max(np.abs(ref))))
+                ok = err < 1e-9
+            except Exception as e:  # noqa: BLE001
+                ok, err = False, repr(e)[:200]
+            if not ok:
+                bad.append((name, label, err))
+    assert not bad, bad
