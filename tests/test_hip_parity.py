@@ -847,6 +847,29 @@ def test_empty_prediction_set(gp, gnp):
     assert zpm.shape == (0,) and zpv.shape == (0,)
 
 
+@pytest.mark.parametrize("n", [50, 1500, 3000])
+def test_non_finite_inputs_behave_as_in_the_reference(gp, gnp, n):
+    """a NaN / inf coordinate makes K non-finite: numpy.linalg.cholesky raises LinAlgError in the reference (numpy_backend.py:136),
+    so NLL and predict raise (a LinAlgError subclass here) and the criterion wrapper returns +inf (numpy_backend.py:344-350); a NaN
+    observation leaves K intact and gives NaN.  Sizes on both sides of the one-stream / look-ahead factorisation: the pivot test
+    must catch a NaN pivot (not (d > 0)), wherever it is met."""
+    x, z = make_xz(n, 3, 1)
+    th = theta_aniso(3)
+    model = gp.Model(None, gp.kernel.MaternCovariance(2), None, th, "zero")
+    for bad in (np.nan, np.inf):
+        xb = x.copy()
+        xb[n // 2, 1] = bad
+        with pytest.raises(np.linalg.LinAlgError):
+            model.negative_log_likelihood_zero_mean(th, xb, z)
+        with pytest.raises(np.linalg.LinAlgError):
+            model.predict(xb, z, x[:5])
+        pre = gp.kernel.make_selection_criterion_with_gradient(model, gp.kernel.negative_log_likelihood_zero_mean, xb, z)[1]
+        assert pre(th) == math.inf
+    zb = z.copy()
+    zb[3] = np.nan
+    assert math.isnan(float(model.negative_log_likelihood_zero_mean(th, x, zb)))
+
+
 def test_every_input_form_gives_the_same_results(gp, gnp):
     """The input contract (gpmp/core/utils.py:19-81, numpy_backend.py:174-188: anything array-like -> an fp64 array): Fortran-ordered
     and strided NumPy views, float32 arrays, a one-column zi, CPU and device tensors, NON-CONTIGUOUS device views -- every form must
