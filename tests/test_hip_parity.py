@@ -645,6 +645,88 @@ def test_gram_lower_only_and_noise(gp, gnp):
     np.testing.assert_allclose(Kl[tile >= 0], ref[tile >= 0], rtol=1e-14)
 
 
+def test_gram_entry_points_random_soak(gp, gnp):
+    """Opt-in soak (GPMP_GRAM_SOAK_CASES=<count>, GPMP_GRAM_SOAK_SEED) of the Gram entry points at the C ABI itself: random n, m
+    (1 ... 700: every ragged tile edge of the 128 x 64 tile), d (1 ... 64), p (0 ... 16), noise layout, the ii path (full / lower
+    tiles only, with a diagonal term), the it path, leading dimensions wider than the matrix (even and odd) and an output pointer
+    that is 8- but not 16-byte aligned (the kernels then take their scalar stores), against the oracle at rel 2e-14 (1e-14
+    at p <= 10 on the fixtures; 6e-14 above p = 10, see the tolerance);
+    gpmp_scaled_distance and gpmp_matern_pairwise on the same draws; the bytes around the output must stay untouched."""
+    import os
+
+    import torch
+
+    from gpmp_amd import _lib
+    from oracle import gp_oracle as orc
+
+    ncases = int(os.environ.get("GPMP_GRAM_SOAK_CASES", "0"))
+    if ncases <= 0:
+        pytest.skip("opt-in: GPMP_GRAM_SOAK_CASES=<count>")
+    lib = _lib.load()
+    dev = gnp._dev()
+    rng = np.random.default_rng(int(os.environ.get("GPMP_GRAM_SOAK_SEED", "5")))
+    bad = []
+    for i in range(ncases):
+        n, m = int(rng.integers(1, 700)), int(rng.integers(1, 700))
+        d, p, noise = int(rng.integers(1, 65)), int(rng.integers(0, 17)), int(rng.integers(0, 2))
+        x, y = rng.random((n, d)), rng.random((m, d))
+        th = np.concatenate(([0.3 * rng.standard_normal()], [math.log(1e-2)] if noise else [], -np.log((0.3 + rng.random(d)) * math.sqrt(d))))
+        mode = int(rng.integers(3))                      # 0: ii full, 1: ii lower tiles only, 2: it
+        cols = n if mode < 2 else m
+        ld = cols + int(rng.choice([0, 1, 2, 7, 64]))
+        off = int(rng.choice([0, 1, 2, 3]))              # doubles before the matrix: off odd -> 8-byte aligned only
+        buf = torch.full((off + n * ld + 5,), -7.0, dtype=torch.float64, device=dev)
+        K = buf[off:off + n * ld].view(n, ld)
+        X, Y = torch.as_tensor(x, device=dev), torch.as_tensor(y, device=dev)
+        diag = float(rng.choice([0.0, 1e-3])) if mode < 2 else 0.0
+        _lib.check(lib.gpmp_matern_gram(gnp._ptr(X), None if mode < 2 else gnp._ptr(Y), n, cols, d, p, _lib.host_vec(th), noise, diag, int(mode == 1),
+                                        K.data_ptr(), ld, gnp._stream()), "gpmp_matern_gram")
+        got = buf.cpu().numpy()
+        Kg = got[off:off + n * ld].reshape(n, ld)
+        thk = th if not noise else np.concatenate((th[:1], th[2:]))            # the Matern part (the noise term is the caller's diag_add)
+        # (the oracle's it form: the ABI adds exactly the caller's diag_add on the ii path, the reference's nugget is the caller's business)
+        ref = orc.maternp_covariance_it(x, x.copy() if mode < 2 else y, p, thk) + (diag * np.eye(n) if mode < 2 else 0.0)
+        errs = {}
+        if mode == 1:
+            tile = np.add.outer(np.arange(n) // 64, -(np.arange(n) // 64)) >= 0       # tiles on / below the diagonal are written
+            errs["gram"] = float(np.max(np.abs(Kg[:, :cols][tile] - ref[tile]) / np.abs(ref[tile])))
+            lowtri = np.tril(np.ones((n, n), bool))
+            errs["lower"] = float(np.max(np.abs(Kg[:, :cols][lowtri] - ref[lowtri]) / np.abs(ref[lowtri])))
+        else:
+            errs["gram"] = float(np.max(np.abs(Kg[:, :cols] - ref) / np.maximum(np.abs(ref), 1e-300)))
+        errs["untouched"] = float(not (np.all(got[:off] == -7.0) and np.all(got[off + n * ld:] == -7.0) and np.all(Kg[:, cols:] == -7.0)))
+        # the distance matrix and the pairwise form on the same points
+        D = torch.full((n, m + 3), -7.0, dtype=torch.float64, device=dev)
+        loginv = thk[1:]
+        _lib.check(lib.gpmp_scaled_distance(gnp._ptr(X), gnp._ptr(Y), n, m, d, _lib.host_vec(loginv), D.data_ptr(), m + 3, gnp._stream()), "gpmp_scaled_distance")
+        Dg = D.cpu().numpy()
+        Dref = orc.scaled_distance(loginv, x, y)
+        # the reference scales the points first and subtracts then (numpy_backend.py:432-436): for near-coincident points the distance
+        # carries the rounding of the two products, eps (|xs_i| + |ys_j|) ABSOLUTE -- and which way they round hangs on the last bit
+        # of exp(loginvrho) (libm here, NumPy's own there).  Tolerance: rel 1e-14 + 4 eps (|xs_i| + |ys_j|); reported in units of it.
+        xs_n, ys_n = np.max(np.abs(np.exp(loginv) * x), axis=1), np.max(np.abs(np.exp(loginv) * y), axis=1)
+        errs["dist"] = float(np.max(np.abs(Dg[:, :m] - Dref) / (1e-14 * Dref + 4 * np.finfo(float).eps * np.add.outer(xs_n, ys_n))))
+        errs["untouched"] += float(not np.all(Dg[:, m:] == -7.0))
+        k = min(n, m)
+        out = torch.full((k + 2,), -7.0, dtype=torch.float64, device=dev)
+        _lib.check(lib.gpmp_matern_pairwise(gnp._ptr(X), gnp._ptr(Y), k, d, p, _lib.host_vec(th), noise, out.data_ptr(), gnp._stream()), "gpmp_matern_pairwise")
+        og = out.cpu().numpy()
+        pref = orc.maternp_covariance_it(x[:k], y[:k], p, thk, pairwise=True)
+        errs["pairwise"] = float(np.max(np.abs(og[:k] - pref) / np.maximum(np.abs(pref), 1e-300)))
+        errs["untouched"] += float(not np.all(og[k:] == -7.0))
+        # rel 1e-14 on values that are not themselves rounding noise of exp(-t) far in the tail (K < 1e-280 underflows gradually)
+        # (p > 10: the coefficients exp(sum of gammaln) of matern.py:59-63 carry the rounding of gammaln(2p + 1) ~ 75, an ulp of which
+        #  is 1.4e-14 relative on the coefficient -- SciPy's gammaln there, libm's lgamma here: p = 15 differs by a constant 2.2e-14)
+        tk = 2e-14 if p <= 10 else 6e-14
+        tol = {"gram": tk, "lower": tk, "dist": 1.0, "pairwise": tk, "untouched": 0.0}
+        over = {k_: v for k_, v in errs.items() if not v <= tol[k_]}
+        if over:
+            bad.append((i, n, m, d, p, noise, mode, ld, off, over))
+        print(f"[gram soak {i:3d}] n={n} m={m} d={d} p={p} noise={noise} mode={mode} ld={ld} off={off}: " + " ".join(f"{k_} {v:.1e}" for k_, v in errs.items())
+              + (" FAILED" if over else ""), flush=True)
+    assert not bad, bad
+
+
 # ------------------------------------------------------------------------------ Cholesky / solves
 @pytest.mark.parametrize("n", [1, 6, 64, 127, 128, 129, 300, 512, 640, 1000, 1537])
 def test_cholesky_and_solves_vs_lapack(gp, gnp, n):
