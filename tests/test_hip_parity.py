@@ -645,6 +645,86 @@ def test_gram_lower_only_and_noise(gp, gnp):
     np.testing.assert_allclose(Kl[tile >= 0], ref[tile >= 0], rtol=1e-14)
 
 
+def test_gemm_entry_point_random_soak(gp, gnp):
+    """Opt-in soak (GPMP_GEMM_SOAK_CASES=<count>, GPMP_GEMM_SOAK_SEED) of gpmp_dgemm: random M, N (1 ... 1500), K (1 ... 3000; now and
+    then one side > 4096 for the wide-tile instances), all four transposition forms, alpha / beta in {0, 1, -1, 0.5, -1.5}, leading
+    dimensions wider than the operands (odd ones too), operands that are only 8-byte aligned, the lower-tiles-only form (square
+    outputs), the small-footprint kernel bit, the op(B)-upper-triangular bit (with a B that is), C aliasing nothing -- against
+    NumPy; beta = 0 must not read C (it holds NaN then); nothing outside C's M x N window may change."""
+    import os
+
+    import torch
+
+    from gpmp_amd import _lib
+
+    ncases = int(os.environ.get("GPMP_GEMM_SOAK_CASES", "0"))
+    if ncases <= 0:
+        pytest.skip("opt-in: GPMP_GEMM_SOAK_CASES=<count>")
+    lib = _lib.load()
+    dev = gnp._dev()
+    rng = np.random.default_rng(int(os.environ.get("GPMP_GEMM_SOAK_SEED", "5")))
+    bad = []
+    for i in range(ncases):
+        big = rng.random() < 0.06
+        M, N = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
+        K = int(rng.integers(1, 3000))
+        if big:
+            if rng.random() < 0.5:
+                M = int(rng.integers(4096, 9000))
+            else:
+                N = int(rng.integers(4096, 9000))
+            K = int(rng.integers(1, 1200))
+        ta, tb = int(rng.integers(2)), int(rng.integers(2))
+        flags = 0
+        if rng.random() < 0.25:
+            N = M
+            flags |= 1
+        if rng.random() < 0.2 and ta == 0 and tb == 1 and K <= 512:
+            flags |= 2
+        upper = rng.random() < 0.2 and (flags & 1) == 0
+        if upper:
+            flags |= 4
+        alpha, beta = float(rng.choice([1.0, -1.0, 0.5, -1.5])), float(rng.choice([0.0, 1.0, -1.0, 0.5]))
+        ar, ac = (K, M) if ta else (M, K)
+        br, bc = (N, K) if tb else (K, N)
+        A, B, C = rng.standard_normal((ar, ac)), rng.standard_normal((br, bc)), rng.standard_normal((M, N))
+        if upper:                                       # op(B) (K x N) upper triangular: op(B)[l, j] = 0 for l > j
+            opB = np.triu(B.T if tb else B)
+            B = np.ascontiguousarray(opB.T) if tb else opB
+
+        def place(a, fill):
+            r, c = a.shape
+            ld, off = c + int(rng.choice([0, 1, 3, 8])), int(rng.choice([0, 1, 2]))
+            buf = torch.full((off + r * ld + 4,), fill, dtype=torch.float64, device=dev)
+            view = buf[off:off + r * ld].view(r, ld)
+            view[:, :c] = torch.as_tensor(a, device=dev)
+            return buf, view, ld, off
+
+        _, Av, lda, _ = place(A, 3.0)
+        _, Bv, ldb, _ = place(B, 5.0)
+        Cbuf, Cv, ldc, coff = place(C if beta != 0.0 else np.full((M, N), np.nan), -7.0)
+        _lib.check(lib.gpmp_dgemm(ta, tb, M, N, K, alpha, Av.data_ptr(), lda, Bv.data_ptr(), ldb, beta, Cv.data_ptr(), ldc, flags, gnp._stream()), "gpmp_dgemm")
+        got = Cbuf.cpu().numpy()
+        Cg = got[coff:coff + M * ldc].reshape(M, ldc)
+        ref = alpha * ((A.T if ta else A) @ (B.T if tb else B)) + (beta * C if beta != 0.0 else 0.0)
+        scale = abs(alpha) * math.sqrt(K) * 16.0 + abs(beta) * 4.0        # (entries ~ N(0, 1): a length-K dot product is ~ sqrt(K))
+        if flags & 1:
+            tile = np.add.outer(np.arange(M) // 128, -(np.arange(N) // 128)) >= 0      # written: the 128 x 128 tiles on / below the diagonal
+            mask = np.tril(np.ones((M, N), bool))
+            err = float(np.max(np.abs(Cg[:, :N] - ref)[mask])) / scale
+            keep = (beta == 0.0) or bool(np.all(Cg[:, :N][~tile] == C[~tile]))       # tiles above the diagonal: not touched
+        else:
+            err = float(np.max(np.abs(Cg[:, :N] - ref))) / scale
+            keep = True
+        untouched = bool(np.all(got[:coff] == -7.0) and np.all(got[coff + M * ldc:] == -7.0) and np.all(Cg[:, N:] == -7.0))
+        ok = err < 1e-14 and keep and untouched and bool(np.all(np.isfinite(Cg[:, :N][mask] if flags & 1 else Cg[:, :N])))
+        if not ok:
+            bad.append((i, ta, tb, M, N, K, alpha, beta, flags, lda, ldb, ldc, err, keep, untouched))
+        print(f"[gemm soak {i:3d}] ta={ta} tb={tb} M={M} N={N} K={K} alpha={alpha} beta={beta} flags={flags} ld={lda},{ldb},{ldc}: err/scale {err:.1e}"
+              + ("" if ok else " FAILED"), flush=True)
+    assert not bad, bad
+
+
 def test_gram_entry_points_random_soak(gp, gnp):
     """Opt-in soak (GPMP_GRAM_SOAK_CASES=<count>, GPMP_GRAM_SOAK_SEED) of the Gram entry points at the C ABI itself: random n, m
     (1 ... 700: every ragged tile edge of the 128 x 64 tile), d (1 ... 64), p (0 ... 16), noise layout, the ii path (full / lower
