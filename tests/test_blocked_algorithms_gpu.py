@@ -116,3 +116,110 @@ def test_blocked_algorithms_random_soak(gnp):
             bad.append((i, n, m, over))
         print(f"[linalg soak {i:3d}] n={n} m={m}: " + " ".join(f"{k} {v:.1e}" for k, v in errs.items()) + (" FAILED" if over else ""), flush=True)
     assert not bad, bad
+
+
+def test_linalg_entry_points_random_soak_at_the_c_abi(gnp):
+    """Opt-in soak (GPMP_LINALG_ABI_SOAK_CASES=<count>, GPMP_LINALG_ABI_SOAK_SEED) of the factorisation and solve entry points called as
+    a C host would: matrices inside larger buffers (leading dimensions wider than n, odd ones too; 8-byte-aligned starts), guard
+    values around every operand, dinv recomputed or passed, scratch passed or NULL, both solve directions, the right-hand solve,
+    trtri / lauum, the log-determinant -- against LAPACK; and a matrix whose leading minor of a random order k is not positive
+    definite must report exactly that k (LAPACK's dpotrf info), from the one-stream route and from the look-ahead route."""
+    import ctypes
+    import os
+
+    import scipy.linalg as sla
+    import torch
+
+    from gpmp_amd import _lib
+
+    ncases = int(os.environ.get("GPMP_LINALG_ABI_SOAK_CASES", "0"))
+    if ncases <= 0:
+        pytest.skip("opt-in: GPMP_LINALG_ABI_SOAK_CASES=<count>")
+    lib = _lib.load()
+    dev = gnp._dev()
+    rng = np.random.default_rng(int(os.environ.get("GPMP_LINALG_ABI_SOAK_SEED", "5")))
+    bad = []
+
+    def place(a, fill=-7.0):
+        r, c = a.shape
+        ld, off = c + int(rng.choice([0, 1, 3, 8])), int(rng.choice([0, 1, 2]))
+        buf = torch.full((off + r * ld + 4,), fill, dtype=torch.float64, device=dev)
+        view = buf[off:off + r * ld].view(r, ld)
+        view[:, :c] = torch.as_tensor(a, device=dev)
+        return buf, view, ld, off
+
+    def window(buf, view_shape, ld, off, cols):
+        got = buf.cpu().numpy()
+        r = view_shape[0]
+        W = got[off:off + r * ld].reshape(r, ld)
+        clean = bool(np.all(got[:off] == -7.0) and np.all(got[off + r * ld:] == -7.0) and np.all(W[:, cols:] == -7.0))
+        return W[:, :cols], clean
+
+    for i in range(ncases):
+        kind = int(rng.integers(3))
+        n = int(rng.integers(1, 300)) if kind == 0 else (int(rng.choice([128, 1024, 2048, 4096])) + int(rng.integers(-2, 3)) if kind == 1 else int(rng.integers(300, 5200)))
+        m = int(rng.choice([1, 2, 3, 4, 5, 16, 100, 511, 512, 513, int(rng.integers(1, 1500))]))
+        G = rng.standard_normal((n, max(n // 2, 1)))
+        K = G @ G.T / max(n // 2, 1) + np.eye(n)                      # cond ~ 10
+        B = rng.standard_normal((n, m))
+        Lref = np.linalg.cholesky(K)
+        errs, clean = {}, True
+        Abuf, Av, lda, aoff = place(K)
+        ndinv = max(int(lib.gpmp_dinv_elems(n)), 1)
+        dinv = torch.empty(ndinv, dtype=torch.float64, device=dev)
+        info = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        _lib.check(lib.gpmp_potrf_lower_async(Av.data_ptr(), n, lda, gnp._ptr(dinv), gnp._ptr(info), gnp._stream()), "potrf")
+        Lw, c = window(Abuf, (n,), lda, aoff, n)
+        clean &= c
+        L = np.tril(Lw)
+        errs["info"] = float(int(info.item()) != 0)
+        errs["L"] = rel_err(L, Lref)
+        for trans in (0, 1):
+            Bbuf, Bv, ldb, boff = place(B)
+            use_dinv, use_scratch = bool(rng.integers(2)), bool(rng.integers(2))
+            scratch = torch.empty(ndinv, dtype=torch.float64, device=dev) if (use_scratch or not use_dinv) else None
+            _lib.check(lib.gpmp_trsm_lower(Av.data_ptr(), n, lda, gnp._ptr(dinv) if use_dinv else None, Bv.data_ptr(), m, ldb, trans,
+                                           None if scratch is None else gnp._ptr(scratch), gnp._stream()), "trsm")
+            Xw, c = window(Bbuf, (n,), ldb, boff, m)
+            clean &= c
+            errs[f"trsm{trans}"] = rel_err(Xw, sla.solve_triangular(Lref, B, lower=True, trans=trans))
+        # X L^T = R for a k x n right-hand side R (the panel solve of the blocked factorisation): X = R L^-T
+        k = int(rng.integers(1, 400))
+        R = rng.standard_normal((k, n))
+        Rbuf, Rv, ldr, roff = place(R)
+        _lib.check(lib.gpmp_trsm_right_lower(Av.data_ptr(), n, lda, gnp._ptr(dinv), Rv.data_ptr(), k, ldr, gnp._stream()), "trsm_right")
+        Xw, c = window(Rbuf, (k,), ldr, roff, n)
+        clean &= c
+        errs["trsm_right"] = rel_err(Xw, sla.solve_triangular(Lref, R.T, lower=True).T)
+        if n <= 3000:
+            Tbuf, Tv, ldt, toff = place(np.full((n, n), np.nan))
+            _lib.check(lib.gpmp_trtri_lower(Av.data_ptr(), n, lda, gnp._ptr(dinv), Tv.data_ptr(), ldt, gnp._stream()), "trtri")
+            Tw, c = window(Tbuf, (n,), ldt, toff, n)
+            clean &= c
+            errs["trtri"] = rel_err(Tw @ Lref, np.eye(n)) + (float(np.max(np.abs(np.triu(Tw, 1)))) if n > 1 else 0.0)
+            Ibuf, Iv, ldi, ioff = place(np.full((n, n), 9.0))
+            _lib.check(lib.gpmp_lauum_lower(Tv.data_ptr(), n, ldt, Iv.data_ptr(), ldi, gnp._stream()), "lauum")
+            Iw, c = window(Ibuf, (n,), ldi, ioff, n)
+            clean &= c
+            errs["lauum"] = rel_err(np.tril(Iw), np.tril(np.linalg.inv(K)))
+        out = torch.zeros(1, dtype=torch.float64, device=dev)
+        _lib.check(lib.gpmp_logdet_chol(Av.data_ptr(), n, lda, gnp._ptr(out), gnp._stream()), "logdet")
+        errs["logdet"] = abs(float(out.item()) - np.linalg.slogdet(K)[1]) / max(1.0, abs(np.linalg.slogdet(K)[1]))
+        # a leading minor of random order j + 1 that is not positive definite: info = j + 1, as LAPACK
+        j = int(rng.integers(0, n))
+        Kb = K.copy()
+        Kb[j, j] -= Lref[j, j] ** 2 + 1.0                            # the pivot of step j becomes -1
+        _, lapack_info = sla.lapack.dpotrf(Kb, lower=True)
+        Bb, Bvw, ldbb, _ = place(Kb)
+        info.fill_(-1)
+        _lib.check(lib.gpmp_potrf_lower_async(Bvw.data_ptr(), n, ldbb, gnp._ptr(dinv), gnp._ptr(info), gnp._stream()), "potrf (not PD)")
+        errs["info_not_pd"] = float(int(info.item()) != lapack_info or lapack_info != j + 1)
+        errs["guards"] = float(not clean)
+        tol = {"info": 0.0, "L": 1e-12, "trsm0": 1e-11, "trsm1": 1e-11, "trsm_right": 1e-11, "trtri": 1e-11, "lauum": 1e-10, "logdet": 1e-13,
+               "info_not_pd": 0.0, "guards": 0.0}
+        over = {k_: v for k_, v in errs.items() if not v <= tol[k_]}
+        if over:
+            bad.append((i, n, m, k, j, over))
+        print(f"[abi soak {i:3d}] n={n} m={m} k={k} lda={lda} not-PD minor {j + 1}: " + " ".join(f"{k_} {v:.1e}" for k_, v in errs.items())
+              + (" FAILED" if over else ""), flush=True)
+    assert not bad, bad
