@@ -373,3 +373,32 @@ def test_batch_driver_random_soak(env):
                     bad.append((i, b, sizes[b], ev, eg, cond))
         print(f"[batch soak {i:3d}] B={B} nmax={nmax} d={d} q={q} p={p} noise={noise} shared={shared}: value {worst_v:.1e} gradient {worst_g:.1e}", flush=True)
     assert not bad, bad
+
+
+def test_batch_workspace_beyond_2_to_the_31_elements(env):
+    """40 000 problems of 256 points in ONE call: 2.6e9 matrix elements per workspace section (every per-problem offset beyond problem
+    32 768 exceeds 32 bits) -- a C host may do this (B <= 65535; the Python layer cuts its calls by a memory budget).  Values and
+    gradients of the first, the last and sampled problems against the single-problem driver; all factorisations succeed."""
+    torch, gnp, _lib, lib = env
+    if torch.cuda.get_device_properties(0).total_memory < 150e9:
+        pytest.skip("needs 150 GB of HBM")
+    B, n, d, q = 40000, 256, 3, 2
+    rng = np.random.default_rng(17)
+    dev = gnp._dev()
+    X = torch.as_tensor(rng.random((B, n, d)), device=dev)
+    Z = torch.sin(3 * X[:, :, 0]) + X.sum(dim=2)
+    P = torch.cat((torch.ones((B, n, 1), dtype=torch.float64, device=dev), X[:, :, :1]), dim=2).contiguous()
+    th = np.concatenate(([0.2, math.log(1e-3)], -np.log(0.3 + 0.2 * np.arange(d))))
+    nws = int(lib.gpmp_batch_ws_elems(n, d, q, B, 1))
+    assert nws > 2 ** 31
+    ws = torch.empty(nws, dtype=torch.float64, device=dev)
+    vals = torch.empty(B, dtype=torch.float64, device=dev)
+    grads = torch.empty((B, len(th)), dtype=torch.float64, device=dev)
+    info = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    _lib.check(lib.gpmp_nll_grad_batch(gnp._ptr(X), n * d, gnp._ptr(Z), n, gnp._ptr(P), q, n * q, q, None, n, d, B, 2, _lib.host_vec(th), 0, 1,
+                                       gnp._ptr(ws), gnp._ptr(vals), gnp._ptr(grads), gnp._ptr(info), gnp._stream()), "gpmp_nll_grad_batch")
+    assert bool((info == 0).all()) and bool(torch.isfinite(vals).all()) and bool(torch.isfinite(grads).all())
+    v_all, g_all = vals.cpu().numpy(), grads.cpu().numpy()
+    for b in (0, 1, 32767, 32768, 32769, 39998, B - 1, int(rng.integers(B)), int(rng.integers(B))):
+        v, g, i1 = _single(env, X[b].cpu().numpy(), Z[b].cpu().numpy(), P[b].cpu().numpy(), th, noise=1)
+        assert i1 == 0 and abs(v_all[b] - v) < 1e-10 * max(1.0, abs(v)) and rel_err(g_all[b], g) < 1e-8, (b, v_all[b], v)
