@@ -281,3 +281,47 @@ def test_backend_functions_accept_strided_device_views(gnp):
             if not ok:
                 bad.append((name, label, err))
     assert not bad, bad
+
+
+def test_repeated_calls_do_not_grow_device_memory_host_memory_or_descriptors(gnp):
+    """400 rounds of every model-level entry point (predict with and without weights, NLL, REML, leave-one-out, criterion value and
+    gradient) on the same inputs: allocated device bytes, the process's resident set and its open descriptors stay where they were
+    after the warm-up (the library owns per-device streams / events / flag blocks; none may be created per call)."""
+    import os
+
+    import gpmp_amd as gp
+    import torch
+
+    from tests.helpers import make_xz, theta_aniso
+
+    def lin(x, p):
+        return gnp.hstack((gnp.ones((x.shape[0], 1)), gnp.asarray(x)))
+
+    def rss_mb():
+        return int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 1e6
+
+    x, z = make_xz(600, 3, 1)
+    xt, _ = make_xz(200, 3, 2)
+    th = theta_aniso(3)
+    mz = gp.Model(None, gp.kernel.MaternCovariance(2), None, th, "zero")
+    ml = gp.Model(lin, gp.kernel.MaternCovariance(2), None, th, "linear_predictor")
+    crit = gp.kernel.make_selection_criterion_with_gradient(ml, gp.kernel.negative_log_restricted_likelihood, x, z)
+
+    def step():
+        mz.predict(x, z, xt)
+        ml.predict(x, z, xt, return_lambdas=True)
+        mz.negative_log_likelihood_zero_mean(th, x, z)
+        ml.negative_log_restricted_likelihood(th, x, z)
+        ml.loo(x, z)
+        crit[1](th)
+        crit[3](th)
+
+    for _ in range(40):
+        step()
+    torch.cuda.synchronize()
+    a0, r0, f0 = torch.cuda.memory_allocated(), rss_mb(), len(os.listdir("/proc/self/fd"))
+    for _ in range(400):
+        step()
+    torch.cuda.synchronize()
+    a1, r1, f1 = torch.cuda.memory_allocated(), rss_mb(), len(os.listdir("/proc/self/fd"))
+    assert a1 == a0 and f1 == f0 and r1 - r0 < 20.0, (a0, a1, r0, r1, f0, f1)
