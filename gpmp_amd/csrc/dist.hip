@@ -36,7 +36,7 @@ struct Layout {
 };
 
 int make_layout(Layout& L, int n, int nb, int pr, int pc, int r, int c) {
-  GPMP_ARG(n > 0, 1, "n <= 0");
+  GPMP_ARG(n > 0 && n <= GPMP_MAX_EXTENT, 1, "n outside [1, GPMP_MAX_EXTENT]");
   GPMP_ARG(nb > 0 && nb % NB == 0 && nb <= 2 * OUTER_BLOCKS * NB, 2, "block size must be a multiple of 128 in (0, 1024]");
   GPMP_ARG(pr > 0 && pc > 0, 3, "empty process grid");
   GPMP_ARG(r >= 0 && r < pr && c >= 0 && c < pc, 5, "rank coordinates outside the grid");
@@ -114,7 +114,7 @@ extern "C" int gpmp_dist_panel_solve(const double* msg, int bk, double* P, int r
                                      gpmp_stream_t stream) {
   GPMP_ARG(msg != nullptr, 1, "msg is NULL");
   GPMP_ARG(bk > 0 && bk <= 2 * OUTER_BLOCKS * NB, 2, "diagonal block outside (0, 1024]");
-  GPMP_ARG(rows >= 0, 4, "rows < 0");
+  GPMP_ARG(rows >= 0 && rows <= GPMP_MAX_EXTENT, 4, "rows outside [0, GPMP_MAX_EXTENT]");
   if (rows == 0) return 0;
   GPMP_ARG(P != nullptr && ldp >= bk, 5, "P is NULL or ldp < bk");
   GPMP_ARG(panel != nullptr && ldo >= bk, 7, "panel is NULL or ldo < bk");

@@ -63,7 +63,7 @@ extern "C" int gpmp_nll_zero_mean(const double* x, const double* z, int n, int d
                                   int noise, double* ws, double* nll_dev, int* info_dev, gpmp_stream_t stream) {
   GPMP_ARG(x != nullptr, 1, "x is NULL");
   GPMP_ARG(z != nullptr, 2, "z is NULL");
-  GPMP_ARG(n > 0, 3, "n <= 0");
+  GPMP_ARG(n > 0 && n <= GPMP_MAX_EXTENT, 3, "n outside [1, GPMP_MAX_EXTENT]");
   GPMP_ARG(theta_host != nullptr, 6, "theta is NULL");
   GPMP_ARG(ws != nullptr, 8, "ws is NULL");
   GPMP_ARG(nll_dev != nullptr, 9, "nll_dev is NULL");
@@ -123,8 +123,8 @@ extern "C" int gpmp_predict_zero_mean(const double* xi, const double* zi, const 
   GPMP_ARG(xi != nullptr, 1, "xi is NULL");
   GPMP_ARG(zi != nullptr, 2, "zi is NULL");
   GPMP_ARG(xt != nullptr, 3, "xt is NULL");
-  GPMP_ARG(n > 0, 4, "n <= 0");
-  GPMP_ARG(m > 0, 5, "m <= 0");
+  GPMP_ARG(n > 0 && n <= GPMP_MAX_EXTENT, 4, "n outside [1, GPMP_MAX_EXTENT]");
+  GPMP_ARG(m > 0 && m <= GPMP_MAX_EXTENT, 5, "m outside [1, GPMP_MAX_EXTENT]");
   GPMP_ARG(theta_host != nullptr, 8, "theta is NULL");
   GPMP_ARG(ws != nullptr, 11, "ws is NULL");
   GPMP_ARG(zpm_dev != nullptr && zpv_dev != nullptr, 12, "output is NULL");

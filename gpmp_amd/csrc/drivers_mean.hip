@@ -226,7 +226,7 @@ int check_common(const double* x, const double* z, const double* P, long ldp, in
   GPMP_ARG(z != nullptr, 2, "z is NULL");
   GPMP_ARG(q >= 0 && q <= QMAX, 7, "q outside [0, GPMP_MAX_RANK - 1]");
   GPMP_ARG(q == 0 || (P != nullptr && ldp >= q), 3, "P is NULL or ldp < q");
-  GPMP_ARG(n > q, 5, "n <= q");
+  GPMP_ARG(n > q && n <= GPMP_MAX_EXTENT, 5, "n <= q or above GPMP_MAX_EXTENT");
   GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 6, "d outside [1, GPMP_MAX_DIM]");
   GPMP_ARG(theta_host != nullptr, 9, "theta is NULL");
   GPMP_ARG(ws != nullptr, 11, "ws is NULL");
@@ -443,8 +443,8 @@ extern "C" int gpmp_predict_mean(const double* xi, const double* zi, const doubl
   GPMP_ARG(Pi != nullptr && ldpi >= q, 3, "Pi is NULL or ldpi < q");
   GPMP_ARG(xt != nullptr, 5, "xt is NULL");
   GPMP_ARG(Pt != nullptr && ldpt >= q, 6, "Pt is NULL or ldpt < q");
-  GPMP_ARG(n > q, 8, "n <= q");
-  GPMP_ARG(m > 0, 9, "m <= 0");
+  GPMP_ARG(n > q && n <= GPMP_MAX_EXTENT, 8, "n <= q or above GPMP_MAX_EXTENT");
+  GPMP_ARG(m > 0 && m <= GPMP_MAX_EXTENT, 9, "m outside [1, GPMP_MAX_EXTENT]");
   GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 10, "d outside [1, GPMP_MAX_DIM]");
   GPMP_ARG(theta_host != nullptr, 13, "theta is NULL");
   GPMP_ARG(ws != nullptr, 16, "ws is NULL");

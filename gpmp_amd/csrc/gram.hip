@@ -646,8 +646,8 @@ extern "C" int gpmp_matern_gram(const double* x, const double* y, int n, int m, 
                                 const double* theta_host, int noise, double diag_add, int lower_only,
                                 double* K, long ldk, gpmp_stream_t stream) {
   GPMP_ARG(x != nullptr, 1, "x is NULL");
-  GPMP_ARG(n >= 0, 3, "n < 0");
-  GPMP_ARG(m >= 0, 4, "m < 0");
+  GPMP_ARG(n >= 0 && n <= GPMP_MAX_EXTENT, 3, "n outside [0, GPMP_MAX_EXTENT]");
+  GPMP_ARG(m >= 0 && m <= GPMP_MAX_EXTENT, 4, "m outside [0, GPMP_MAX_EXTENT]");
   GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 5, "d outside [1, GPMP_MAX_DIM]");
   GPMP_ARG(p >= 0 && p <= GPMP_MAX_P, 6, "p outside [0, GPMP_MAX_P]");
   GPMP_ARG(theta_host != nullptr, 7, "theta is NULL");
@@ -687,6 +687,7 @@ extern "C" int gpmp_scaled_distance(const double* x, const double* y, int n, int
   GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 5, "d outside [1, GPMP_MAX_DIM]");
   GPMP_ARG(loginvrho_host != nullptr, 6, "loginvrho is NULL");
   GPMP_ARG(D != nullptr && ldd >= m, 7, "D is NULL or ldd < m");
+  GPMP_ARG(n <= GPMP_MAX_EXTENT && m <= GPMP_MAX_EXTENT, 3, "n or m above GPMP_MAX_EXTENT");
   if (n <= 0 || m <= 0) return 0;
   GramParams gp;
   gp.nprob = 1; gp.stride_x = gp.stride_k = 0; gp.ns = nullptr; gp.pp = nullptr;
@@ -711,6 +712,7 @@ extern "C" int gpmp_matern_pairwise(const double* x, const double* y, int n, int
   GPMP_ARG(p >= 0 && p <= GPMP_MAX_P, 5, "p outside [0, GPMP_MAX_P]");
   GPMP_ARG(theta_host != nullptr, 6, "theta is NULL");
   GPMP_ARG(out != nullptr, 8, "out is NULL");
+  GPMP_ARG(n <= GPMP_MAX_EXTENT, 3, "n above GPMP_MAX_EXTENT");
   if (n <= 0) return 0;
   PairParams pp;
   pp.x = x; pp.y = y; pp.out = out; pp.n = n; pp.d = d; pp.same = (y == nullptr || y == x);
@@ -886,7 +888,7 @@ extern "C" int gpmp_matern_grad_trace(const double* Kinv, long ldk, const double
                                       gpmp_stream_t stream) {
   GPMP_ARG(Kinv != nullptr, 1, "Kinv is NULL");
   GPMP_ARG(x != nullptr, 3, "x is NULL");
-  GPMP_ARG(n >= 1, 4, "n < 1");
+  GPMP_ARG(n >= 1 && n <= GPMP_MAX_EXTENT, 4, "n outside [1, GPMP_MAX_EXTENT]");
   GPMP_ARG(ldk >= n, 2, "ldk < n");
   GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 5, "d outside [1, GPMP_MAX_DIM]");
   GPMP_ARG(p >= 0 && p <= GPMP_MAX_P, 6, "p outside [0, GPMP_MAX_P]");
@@ -944,7 +946,7 @@ extern "C" int gpmp_matern_grad_trace_cross(const double* M, long ldm, const dou
                                             double* g_dev, double* ws, gpmp_stream_t stream) {
   GPMP_ARG(M != nullptr, 1, "M is NULL");
   GPMP_ARG(x != nullptr && y != nullptr, 3, "x or y is NULL");
-  GPMP_ARG(n >= 1 && m >= 1 && ldm >= m, 4, "n < 1, m < 1 or ldm < m");
+  GPMP_ARG(n >= 1 && m >= 1 && n <= GPMP_MAX_EXTENT && m <= GPMP_MAX_EXTENT && ldm >= m, 4, "n or m outside [1, GPMP_MAX_EXTENT], or ldm < m");
   GPMP_ARG(d >= 1 && d <= GPMP_MAX_DIM, 7, "d outside [1, GPMP_MAX_DIM]");
   GPMP_ARG(p >= 0 && p <= GPMP_MAX_P, 8, "p outside [0, GPMP_MAX_P]");
   GPMP_ARG(theta_host != nullptr, 9, "theta is NULL");

@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) jacobi_step_kernel(double* __restrict__ G
 using namespace gpmp;
 
 extern "C" int gpmp_jacobi_sweep(double* G, long ldg, double* W, long ldw, int n, double tiny_norm, double* conv_dev, gpmp_stream_t stream) {
-  GPMP_ARG(n >= 0, 5, "n < 0");
+  GPMP_ARG(n >= 0 && n <= GPMP_MAX_EXTENT, 5, "n outside [0, GPMP_MAX_EXTENT]");
   if (n <= 1) return 0;
   GPMP_ARG(G != nullptr && W != nullptr, 1, "G or W is NULL");
   GPMP_ARG(ldg >= n && ldw >= n, 2, "leading dimension < n");

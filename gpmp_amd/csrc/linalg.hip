@@ -699,7 +699,7 @@ extern "C" size_t gpmp_dinv_elems(int n) {
 extern "C" int gpmp_potrf_lower_async(double* A, int n, long lda, double* dinv, int* info_dev,
                                       gpmp_stream_t stream) {
   GPMP_ARG(A != nullptr, 1, "A is NULL");
-  GPMP_ARG(n >= 0, 2, "n < 0");
+  GPMP_ARG(n >= 0 && n <= GPMP_MAX_EXTENT, 2, "n outside [0, GPMP_MAX_EXTENT]");
   GPMP_ARG(lda >= n, 3, "lda < n");
   GPMP_ARG(dinv != nullptr, 4, "dinv is NULL");
   GPMP_ARG(info_dev != nullptr, 5, "info is NULL");
@@ -710,12 +710,12 @@ extern "C" int gpmp_potrf_lower_async(double* A, int n, long lda, double* dinv, 
 extern "C" int gpmp_potrf_trsm_lower_async(double* A, int n, long lda, double* dinv, int* info_dev, double* B, int m, long ldb,
                                            gpmp_stream_t stream) {
   GPMP_ARG(A != nullptr, 1, "A is NULL");
-  GPMP_ARG(n >= 0, 2, "n < 0");
+  GPMP_ARG(n >= 0 && n <= GPMP_MAX_EXTENT, 2, "n outside [0, GPMP_MAX_EXTENT]");
   GPMP_ARG(lda >= n, 3, "lda < n");
   GPMP_ARG(dinv != nullptr, 4, "dinv is NULL");
   GPMP_ARG(info_dev != nullptr, 5, "info_dev is NULL");
   GPMP_ARG(B != nullptr, 6, "B is NULL");
-  GPMP_ARG(m >= 0 && ldb >= m, 8, "ldb < m");
+  GPMP_ARG(m >= 0 && m <= GPMP_MAX_EXTENT && ldb >= m, 8, "m outside [0, GPMP_MAX_EXTENT] or ldb < m");
   if (n == 0) return 0;
   hipStream_t st = as_stream(stream);
   GPMP_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
@@ -738,6 +738,7 @@ extern "C" int gpmp_potrf_trsm_lower_async(double* A, int n, long lda, double* d
 
 extern "C" int gpmp_trtri_diag_blocks(const double* L, int n, long ldl, double* dinv, gpmp_stream_t stream) {
   GPMP_ARG(L != nullptr, 1, "L is NULL");
+  GPMP_ARG(n <= GPMP_MAX_EXTENT, 2, "n above GPMP_MAX_EXTENT");
   GPMP_ARG(ldl >= n, 3, "ldl < n");
   GPMP_ARG(dinv != nullptr, 4, "dinv is NULL");
   return launch_trtri_blocks(L, ldl, n, dinv, as_stream(stream));
@@ -746,10 +747,10 @@ extern "C" int gpmp_trtri_diag_blocks(const double* L, int n, long ldl, double* 
 extern "C" int gpmp_trsm_lower(const double* L, int n, long ldl, const double* dinv, double* B, int m,
                                long ldb, int trans, double* scratch, gpmp_stream_t stream) {
   GPMP_ARG(L != nullptr, 1, "L is NULL");
-  GPMP_ARG(n >= 0, 2, "n < 0");
+  GPMP_ARG(n >= 0 && n <= GPMP_MAX_EXTENT, 2, "n outside [0, GPMP_MAX_EXTENT]");
   GPMP_ARG(ldl >= n, 3, "ldl < n");
   GPMP_ARG(B != nullptr, 5, "B is NULL");
-  GPMP_ARG(m >= 0 && ldb >= m, 7, "ldb < m");
+  GPMP_ARG(m >= 0 && m <= GPMP_MAX_EXTENT && ldb >= m, 7, "m outside [0, GPMP_MAX_EXTENT] or ldb < m");
   GPMP_ARG(dinv != nullptr || scratch != nullptr, 9, "dinv and scratch both NULL");
   if (n == 0 || m == 0) return 0;
   hipStream_t st = as_stream(stream);
@@ -767,16 +768,17 @@ extern "C" int gpmp_trsm_lower(const double* L, int n, long ldl, const double* d
 extern "C" int gpmp_trsm_right_lower(const double* L, int k, long ldl, const double* dinv, double* B, int M, long ldb,
                                      gpmp_stream_t stream) {
   GPMP_ARG(L != nullptr, 1, "L is NULL");
-  GPMP_ARG(k >= 0 && ldl >= k, 3, "ldl < k");
+  GPMP_ARG(k >= 0 && k <= GPMP_MAX_EXTENT && ldl >= k, 3, "k outside [0, GPMP_MAX_EXTENT] or ldl < k");
   GPMP_ARG(dinv != nullptr, 4, "dinv is NULL");
   GPMP_ARG(B != nullptr, 5, "B is NULL");
-  GPMP_ARG(M >= 0 && ldb >= k, 7, "ldb < k");
+  GPMP_ARG(M >= 0 && M <= GPMP_MAX_EXTENT && ldb >= k, 7, "M outside [0, GPMP_MAX_EXTENT] or ldb < k");
   return trsm_right(L, k, ldl, dinv, B, M, ldb, as_stream(stream));
 }
 
 extern "C" int gpmp_trtri_lower(const double* L, int n, long ldl, const double* dinv, double* T, long ldt,
                                 gpmp_stream_t stream) {
   GPMP_ARG(L != nullptr, 1, "L is NULL");
+  GPMP_ARG(n <= GPMP_MAX_EXTENT, 2, "n above GPMP_MAX_EXTENT");
   GPMP_ARG(ldl >= n, 3, "ldl < n");
   GPMP_ARG(dinv != nullptr, 4, "dinv is NULL");
   GPMP_ARG(T != nullptr && ldt >= n, 5, "T is NULL or ldt < n");
@@ -786,6 +788,7 @@ extern "C" int gpmp_trtri_lower(const double* L, int n, long ldl, const double* 
 
 extern "C" int gpmp_lauum_lower(const double* T, int n, long ldt, double* Kinv, long ldk, gpmp_stream_t stream) {
   GPMP_ARG(T != nullptr && ldt >= n, 1, "T is NULL or ldt < n");
+  GPMP_ARG(n <= GPMP_MAX_EXTENT, 2, "n above GPMP_MAX_EXTENT");
   GPMP_ARG(Kinv != nullptr && ldk >= n, 4, "Kinv is NULL or ldk < n");
   if (n <= 0) return 0;
   GemmOpts o;
@@ -797,7 +800,7 @@ extern "C" int gpmp_lauum_lower(const double* T, int n, long ldt, double* Kinv, 
 extern "C" int gpmp_dgemm(int ta, int tb, int M, int N, int K, double alpha, const double* A, long lda,
                           const double* B, long ldb, double beta, double* C, long ldc, int lower_only,
                           gpmp_stream_t stream) {
-  GPMP_ARG(M >= 0 && N >= 0 && K >= 0, 3, "negative size");
+  GPMP_ARG(M >= 0 && N >= 0 && K >= 0 && M <= GPMP_MAX_EXTENT && N <= GPMP_MAX_EXTENT && K <= GPMP_MAX_EXTENT, 3, "size outside [0, GPMP_MAX_EXTENT]");
   GPMP_ARG(A != nullptr && B != nullptr && C != nullptr, 7, "NULL matrix");
   GPMP_ARG(lda >= (ta ? M : K), 8, "lda too small");
   GPMP_ARG(ldb >= (tb ? K : N), 10, "ldb too small");

@@ -180,7 +180,7 @@ extern "C" int gpmp_coldots_ws_rows(int n) {
 extern "C" int gpmp_coldots(const double* V, int n, int m, long ldv, const double* Y, int r, long ldy,
                             double* out, long ldo, double* ws, gpmp_stream_t stream) {
   GPMP_ARG(V != nullptr, 1, "V is NULL");
-  GPMP_ARG(n >= 0 && m >= 0, 2, "negative size");
+  GPMP_ARG(n >= 0 && m >= 0 && n <= GPMP_MAX_EXTENT && m <= GPMP_MAX_EXTENT, 2, "size outside [0, GPMP_MAX_EXTENT]");
   GPMP_ARG(ldv >= m, 4, "ldv < m");
   GPMP_ARG(r >= 0 && r <= GPMP_MAX_RANK, 6, "r outside [0, GPMP_MAX_RANK]");
   GPMP_ARG(r == 0 || (Y != nullptr && ldy >= r), 5, "Y is NULL or ldy < r");
@@ -210,7 +210,7 @@ extern "C" int gpmp_coldots(const double* V, int n, int m, long ldv, const doubl
 extern "C" int gpmp_coldots_pair(const double* A, long lda, const double* B, long ldb, int n, int m, double* out, double* ws,
                                  gpmp_stream_t stream) {
   GPMP_ARG(A != nullptr && B != nullptr, 1, "A or B is NULL");
-  GPMP_ARG(n >= 0 && m >= 0, 5, "negative size");
+  GPMP_ARG(n >= 0 && m >= 0 && n <= GPMP_MAX_EXTENT && m <= GPMP_MAX_EXTENT, 5, "size outside [0, GPMP_MAX_EXTENT]");
   GPMP_ARG(lda >= m && ldb >= m, 2, "leading dimension < m");
   GPMP_ARG(out != nullptr && ws != nullptr, 7, "out or ws is NULL");
   if (m == 0) return 0;
@@ -227,7 +227,7 @@ extern "C" int gpmp_coldots_pair(const double* A, long lda, const double* B, lon
 
 extern "C" int gpmp_logdet_chol(const double* L, int n, long ldl, double* out_dev, gpmp_stream_t stream) {
   GPMP_ARG(L != nullptr, 1, "L is NULL");
-  GPMP_ARG(n >= 0 && ldl >= n, 3, "n < 0 or ldl < n");
+  GPMP_ARG(n >= 0 && n <= GPMP_MAX_EXTENT && ldl >= n, 3, "n outside [0, GPMP_MAX_EXTENT] or ldl < n");
   GPMP_ARG(out_dev != nullptr, 4, "out is NULL");
   hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, n, ldl, out_dev);
   GPMP_HIP_TRY(hipGetLastError());
@@ -236,13 +236,13 @@ extern "C" int gpmp_logdet_chol(const double* L, int n, long ldl, double* out_de
 
 extern "C" int gpmp_tril(double* A, int n, long lda, gpmp_stream_t stream) {
   GPMP_ARG(A != nullptr, 1, "A is NULL");
-  GPMP_ARG(lda >= n, 3, "lda < n");
+  GPMP_ARG(lda >= n && n <= GPMP_MAX_EXTENT, 3, "lda < n or n above GPMP_MAX_EXTENT");
   if (n <= 0) return 0;
   return launch_tril(A, n, lda, as_stream(stream));
 }
 extern "C" int gpmp_symmetrize_from_lower(double* A, int n, long lda, gpmp_stream_t stream) {
   GPMP_ARG(A != nullptr, 1, "A is NULL");
-  GPMP_ARG(lda >= n, 3, "lda < n");
+  GPMP_ARG(lda >= n && n <= GPMP_MAX_EXTENT, 3, "lda < n or n above GPMP_MAX_EXTENT");
   if (n <= 0) return 0;
   return launch_symmetrize(A, n, lda, as_stream(stream));
 }

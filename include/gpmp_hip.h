@@ -51,6 +51,8 @@ typedef void* gpmp_stream_t;
 #define GPMP_MAX_DIM 64      /* largest input dimension d handled by the Gram kernels */
 #define GPMP_MAX_P 16        /* largest Matern half-integer index p (nu = p + 1/2) */
 #define GPMP_MAX_RANK 72     /* largest low-rank correction width in gpmp_matern_grad_trace */
+#define GPMP_MAX_EXTENT (1 << 30) /* largest row / column / contraction count any entry point accepts: element OFFSETS are 64-bit
+                                    (n = 131072 squared is in the tests), extents and launch arithmetic are 32-bit */
 #define GPMP_BATCH_MAX_N 4096 /* largest (padded) problem size of the batched small-problem driver */
 #define GPMP_BATCH_MAX_Q 16   /* largest number of mean-design columns of the batched small-problem driver */
 

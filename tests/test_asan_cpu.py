@@ -133,3 +133,29 @@ def test_host_side_sanitizer_build_runs_clean():
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ASAN-CHILD-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("mode", ["all", "deep", "ints", "lds"])
+def test_argument_probes_run_clean_under_the_host_sanitizers(mode):
+    """tests/test_abi_cpu.py's probes (every pointer NULL; one NULL at a time; every integer negative / zero / huge; every leading
+    dimension too small) against the ASan + UBSan build of the library: an argument check that reads through a bad pointer, or a
+    size computation that overflows a signed integer before the check rejects it, is reported here."""
+    import torch
+
+    from tests.test_abi_cpu import _NULL_PROBE
+
+    if torch.cuda.device_count() > 0 and mode != "all":
+        pytest.skip("a GPU is present: host scratch must not be handed to kernels")
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no ROCm clang here")
+    rt = subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.exists(rt):
+        pytest.skip("ASan runtime not found")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "gpmp_amd", "csrc"), "-j8", "asan"], check=True, capture_output=True)
+    env = dict(os.environ, LD_PRELOAD=rt, GPMP_HIP_LIB=os.path.join(ROOT, "gpmp_amd", "libgpmp_hip_asan.so"),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=97:verify_asan_link_order=0",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1:exitcode=98")
+    r = subprocess.run([sys.executable, "-c", _NULL_PROBE, ROOT, mode], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "REJECTED" in r.stdout and "NOT REJECTED" not in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, r.stderr[-4000:]
